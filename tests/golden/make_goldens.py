@@ -1,0 +1,297 @@
+"""Golden-vector generator — BUILD-CONTAINER ONLY.
+
+Runs the REAL reference (imported from /root/reference through ref_harness.py) on
+closed-form weights/inputs (closed_form.py) and writes small .npz fixtures next to
+this file.  The parity tests (and the GPU box) only ever read the fixtures.
+
+    python tests/golden/make_goldens.py            # all sets
+    python tests/golden/make_goldens.py dist       # one set
+
+Sets: idx, swin, bert_fuse, heads_loss, step, dist.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import closed_form as cf  # noqa: E402
+import ref_harness as H  # noqa: E402
+
+SCRATCH = '/tmp/clover_golden_scratch'
+MAXSUB = 4096
+
+
+def pack(out, name, t):
+    """Store a strided subsample (<= MAXSUB values) + [sum, l2, numel] of a tensor."""
+    a = t.detach().cpu().double().numpy().reshape(-1)
+    stride = max(1, a.size // MAXSUB)
+    out[name + '.sub'] = a[::stride][:MAXSUB].astype(np.float32)
+    out[name + '.stats'] = np.array([a.sum(), np.sqrt((a * a).sum()), a.size], dtype=np.float64)
+
+
+def full(out, name, t):
+    out[name] = t.detach().cpu().numpy()
+
+
+def save(fname, out):
+    path = os.path.join(HERE, fname)
+    np.savez_compressed(path, **out)
+    print(f'wrote {fname}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def ref_model(drop=0.0):
+    H.make_bert_dir(SCRATCH, hidden=cf.TINY_BERT['hidden_size'], layers=cf.TINY_BERT['num_hidden_layers'],
+                    heads=cf.TINY_BERT['num_attention_heads'], inter=cf.TINY_BERT['intermediate_size'],
+                    vocab=cf.TINY_BERT['vocab_size'], max_pos=cf.TINY_BERT['max_position_embeddings'])
+    cfg = cf.tiny_model_cfg(drop)
+    # the reference classes take bert_config only through **kwargs (ignored); MLMHead has no kwargs
+    m = H.build_reference_model(cfg, SCRATCH)
+    manifest = {k: list(v.shape) for k, v in m.state_dict().items()}
+    sd = cf.cf_state(manifest)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert all('relative_position_index' in k for k in missing), missing
+    assert not unexpected, unexpected
+    return m, manifest
+
+
+# --------------------------------------------------------------------------- #
+def gen_idx():
+    H.install_shims()
+    import mmaction.models.backbones.swin_transformer_3d as S
+    out = {}
+    for ws in [(8, 7, 7), (4, 7, 7), (2, 7, 7)]:
+        att = S.WindowAttention3D(6, ws, 3)
+        out['rpi_%d_%d_%d' % ws] = att.relative_position_index.numpy()
+    cfg_ws, cfg_ss = (8, 7, 7), (4, 3, 3)
+    for fs in [(4, 56, 56), (8, 56, 56), (16, 56, 56), (2, 28, 28), (2, 14, 14), (4, 7, 7), (16, 7, 7), (16, 14, 14), (3, 10, 12)]:
+        ws, ss = S.get_window_size(fs, cfg_ws, cfg_ss)
+        tag = '%d_%d_%d' % fs
+        out['gws_' + tag] = np.array(list(ws) + list(ss), dtype=np.int64)
+        Dp, Hp, Wp = [int(np.ceil(f / w)) * w for f, w in zip(fs, ws)]
+        S.compute_mask.cache_clear()
+        m = S.compute_mask(Dp, Hp, Wp, ws, ss, torch.device('cpu'), torch.float32)
+        out['mask_' + tag] = (m != 0).numpy().astype(np.int8)
+        assert set(np.unique(m.numpy()).tolist()) <= {0.0, -100.0}
+        # roll + partition and reverse + roll applied to arange
+        ar = torch.arange(Dp * Hp * Wp, dtype=torch.int64).view(1, Dp, Hp, Wp, 1)
+        sh = torch.roll(ar, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3)) if any(ss) else ar
+        part = S.window_partition(sh, ws)
+        out['part_' + tag] = part[..., 0].numpy()
+        rev = S.window_reverse(part.view(-1, *(ws + (1,))), ws, 1, Dp, Hp, Wp)
+        rev = torch.roll(rev, shifts=ss, dims=(1, 2, 3)) if any(ss) else rev
+        assert torch.equal(rev, ar)
+    # mask-blend weight via a real forward with constant weights
+    vm = cf.cf_batch(3)['v_token_mask'][:, 0][:, None]
+    sw = S.SwinTransformer3D(embed_dim=48, depths=[2], num_heads=[3], mask_token=True, pretrained2d=False)
+    _, w = sw(torch.zeros(3, 3, 4, 112, 112), vm)
+    out['blend_mask'] = vm.numpy()
+    out['blend_w'] = w.numpy().astype(np.int8)
+    # patch merging gather order on arange (norm/reduction bypassed by capturing the cat)
+    pm = S.PatchMerging(dim=1)
+    x = torch.arange(2 * 2 * 5 * 6, dtype=torch.float32).view(2, 2, 5, 6, 1)
+    grabbed = {}
+    pm.norm.register_forward_pre_hook(lambda mod, a: grabbed.__setitem__('x', a[0].clone()))
+    pm(x)
+    out['merge_in'] = x.numpy()
+    out['merge_cat'] = grabbed['x'].numpy()
+    b = cf.cf_batch(4)
+    out['ssl_token_ids'] = b['token_ids'].numpy()
+    out['ssl_mlm_label'] = b['mlm_label'].numpy()
+    tid, lab = b['token_ids'][:, 0], b['mlm_label'][:, 0]
+    out['ssl_ids'] = torch.where(lab == -100, tid.clone(), lab.clone()).numpy()
+    idx = torch.where(lab.reshape(-1) != -100)
+    out['mlm_rows'] = idx[0].numpy()
+    out['mlm_row_labels'] = lab.reshape(-1)[idx].numpy()
+    save('g_idx.npz', out)
+
+
+def gen_swin():
+    m, manifest = ref_model()
+    m.eval()
+    bb = m.backbone
+    out = {}
+    batch = cf.cf_batch(2, tag='swin')
+    x = batch['imgs'][:, 0]
+    vm = batch['v_token_mask']
+    taps = {}
+    hooks = [bb.patch_embed.register_forward_hook(lambda mod, a, o: taps.__setitem__('patch_embed', o))]
+    for i, layer in enumerate(bb.layers):
+        for j, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(
+                lambda mod, a, o, k=f'layers.{i}.blocks.{j}': taps.__setitem__(k, o)))
+    y = bb(x)
+    for k, v in taps.items():
+        pack(out, 'clean.' + k, v)
+    full(out, 'clean.out', y)
+    taps.clear()
+    ym, w = bb(x.clone(), vm)
+    for k, v in taps.items():
+        pack(out, 'masked.' + k, v)
+    full(out, 'masked.out', ym)
+    out['masked.w'] = w.numpy().astype(np.int8)
+    for h in hooks:
+        h.remove()
+    # grads of a closed-form scalar functional of both outputs
+    gw = cf.cf_float('swin.gw', tuple(y.shape), 1.0)
+    bb.zero_grad()
+    ((y * gw).sum() + (ym * gw.flip(0)).sum()).backward()
+    for k in ['layers.0.blocks.1.attn.qkv.weight', 'layers.0.blocks.1.attn.relative_position_bias_table',
+              'layers.1.blocks.0.attn.relative_position_bias_table', 'mask_token', 'patch_embed.proj.weight',
+              'layers.0.downsample.reduction.weight', 'layers.1.blocks.1.mlp.fc1.weight', 'norm.weight']:
+        p = dict(bb.named_parameters())[k]
+        pack(out, 'grad.' + k, p.grad)
+    save('g_swin.npz', out)
+    with open(os.path.join(HERE, 'manifest_tiny.json'), 'w') as f:
+        json.dump(manifest, f, indent=0)
+
+
+def gen_bert_fuse():
+    m, _ = ref_model()
+    m.eval()
+    out = {}
+    b = cf.cf_batch(3, tag='bf')
+    ids, mask = b['token_ids'][:, 0], b['input_mask'][:, 0]
+    t = m.text_backbone(ids, mask)['last_hidden_state']
+    full(out, 'bert.last_hidden_state', t)
+    vt = cf.cf_float('bf.vt', (3, 2, 196, 96), 1.0)
+    f = m.multimodal_backbone(visual_token=vt, text_input_mask=mask, text_input_embeds=t)
+    full(out, 'fuse.t_last_hidden_state', f['t_last_hidden_state'])
+    pack(out, 'fuse.v_last_hidden_state', f['v_last_hidden_state'])
+    save('g_bert_fuse.npz', out)
+
+
+def gen_heads_loss():
+    m, _ = ref_model()
+    m.eval()
+    H.init_dist_single()
+    out = {}
+    vis = cf.cf_float('hl.vis', (4, 96, 2, 14, 14), 1.0)
+    txt = cf.cf_float('hl.txt', (4, 16, 128), 1.0)
+    full(out, 'mm.vision', m.ssl_head.forward_vision(vis))
+    full(out, 'mm.vision_b1', m.ssl_head.forward_vision(vis[:1]))
+    full(out, 'mm.text', m.ssl_head.forward_text(txt))
+    row = cf.cf_float('hl.row', (4, 128), 1.0)
+    full(out, 'V.head', m.mlm_ssl_V_head(row))
+    full(out, 'T.head', m.mlm_ssl_T_head(row))
+    full(out, 'mlm.scores', m.mlm_head(txt[:2]))
+    logits = cf.cf_float('hl.logits', (7, 1024), 4.0)
+    tgt = cf.cf_int('hl.tgt', (7,), 0, 1024)
+    full(out, 'focal', m.mlm_loss_func(logits, tgt))
+    for G in [1, 2, 4, 8]:
+        e = [cf.cf_float(f'hl.e{k}.{G}', (G, 128), 1.0) for k in range(4)]
+        l = m.ssl_loss(*e)
+        full(out, f'nce.G{G}.nce_loss', l['nce_loss'])
+        full(out, f'nce.G{G}.rank_t_tm_loss', l['rank_t_tm_loss'])
+    # gradient of the loss wrt the four embeddings at G=4
+    e = [cf.cf_float(f'hl.e{k}.4', (4, 128), 1.0).requires_grad_() for k in range(4)]
+    l = m.ssl_loss(*e)
+    (l['nce_loss'] + l['rank_t_tm_loss']).backward()
+    for k in range(4):
+        full(out, f'nce.G4.grad{k}', e[k].grad)
+    save('g_heads_loss.npz', out)
+
+
+GRAD_KEYS = ['backbone.patch_embed.proj.weight', 'backbone.mask_token',
+             'backbone.layers.0.blocks.1.attn.relative_position_bias_table',
+             'backbone.layers.1.blocks.1.attn.qkv.weight',
+             'text_backbone.bert.embeddings.word_embeddings.weight',
+             'text_backbone.bert.encoder.layer.1.attention.self.query.weight',
+             'multimodal_backbone.vis_space_pos', 'multimodal_backbone.fc_in.weight',
+             'multimodal_backbone.bert_encoder.layer.0.intermediate.dense.weight',
+             'mlm_head.predictions.decoder.weight', 'ssl_head.img_projector.0.weight',
+             'mlm_ssl_V_head.img_fc1.weight', 'mlm_ssl_T_head.fc2.bias']
+
+
+def _step(m, batch):
+    aux = {k: batch[k] for k in cf.AUX}
+    losses = m(batch['imgs'], batch['label'], return_loss=True, **aux)
+    loss, log_vars = m._parse_losses(losses)
+    return loss, log_vars
+
+
+def gen_step():
+    m, _ = ref_model()
+    m.eval()
+    H.init_dist_single()
+    out = {}
+    for B in [1, 2, 4]:
+        batch = cf.cf_batch(B, tag=f'step{B}')
+        m.zero_grad()
+        loss, lv = _step(m, batch)
+        loss.backward()
+        for k, v in lv.items():
+            out[f'B{B}.{k}'] = np.float64(v)
+        named = dict(m.named_parameters())
+        for k in GRAD_KEYS:
+            pack(out, f'B{B}.grad.{k}', named[k].grad)
+        unused = [k for k, p in named.items() if p.grad is None]
+        out[f'B{B}.n_unused'] = np.int64(len(unused))
+        if B == 1:
+            with open(os.path.join(HERE, 'unused_params_tiny.json'), 'w') as f:
+                json.dump(sorted(unused), f, indent=0)
+    # train_step contract
+    batch = cf.cf_batch(2, tag='step2')
+    o = m.train_step(batch, None)
+    out['train_step.num_samples'] = np.int64(o['num_samples'])
+    out['train_step.loss'] = np.float64(o['loss'].item())
+    save('g_step.npz', out)
+
+
+def _dist_worker(rank, W, port, ret):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=W)
+    m, _ = ref_model()
+    m.eval()
+    ddp = DDP(m, broadcast_buffers=False, find_unused_parameters=True)
+    G = 4
+    batch = cf.cf_batch(G, tag='dist')
+    per = G // W
+    shard = {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}
+    aux = {k: shard[k] for k in cf.AUX}
+    losses = ddp(shard['imgs'], shard['label'], return_loss=True, **aux)
+    loss, lv = m._parse_losses(losses)
+    loss.backward()
+    if rank == 0:
+        named = dict(m.named_parameters())
+        res = {'log_vars': lv, 'grads': {k: named[k].grad.detach().numpy().copy() for k in GRAD_KEYS}}
+        ret.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_dist():
+    import torch.multiprocessing as mp
+    out = {}
+    ctx = mp.get_context('spawn')
+    for W in [1, 2, 4]:
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_dist_worker, args=(r, W, 29600 + W, q)) for r in range(W)]
+        for p in procs:
+            p.start()
+        res = q.get(timeout=600)
+        for p in procs:
+            p.join()
+        for k, v in res['log_vars'].items():
+            out[f'W{W}.{k}'] = np.float64(v)
+        for k, g in res['grads'].items():
+            pack(out, f'W{W}.grad.{k}', torch.from_numpy(g))
+        print(W, res['log_vars'])
+    save('g_dist.npz', out)
+
+
+SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
+            step=gen_step, dist=gen_dist)
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(SETS)
+    torch.set_num_threads(8)
+    for s in which:
+        SETS[s]()

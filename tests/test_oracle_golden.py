@@ -1,0 +1,137 @@
+"""Pins the oracle (oracle/) against goldens produced by the reference itself
+(tests/golden/make_goldens.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+import gutil
+from oracle import indexing as ix
+from oracle import model as om
+
+
+# ------------------------------------------------------------------ G-idx (bit-exact)
+def test_relative_position_index():
+    g = gutil.load('g_idx.npz')
+    for ws in [(8, 7, 7), (4, 7, 7), (2, 7, 7)]:
+        assert np.array_equal(ix.relative_position_index(ws), g['rpi_%d_%d_%d' % ws])
+    # the [:N,:N] slice of the configured (8,7,7) index is NOT the native (4,7,7) index: +676
+    full = ix.relative_position_index((8, 7, 7))
+    assert np.array_equal(full[:196, :196], g['rpi_4_7_7'] + 676)
+
+
+FS = [(4, 56, 56), (8, 56, 56), (16, 56, 56), (2, 28, 28), (2, 14, 14), (4, 7, 7), (16, 7, 7), (16, 14, 14), (3, 10, 12)]
+
+
+@pytest.mark.parametrize('fs', FS)
+def test_window_geometry(fs):
+    g = gutil.load('g_idx.npz')
+    tag = '%d_%d_%d' % fs
+    ws, ss = ix.get_window_size(fs, (8, 7, 7), (4, 3, 3))
+    assert list(ws) + list(ss) == g['gws_' + tag].tolist()
+    Dp, Hp, Wp = [int(np.ceil(f / w)) * w for f, w in zip(fs, ws)]
+    m = ix.compute_mask(Dp, Hp, Wp, ws, ss)
+    assert set(np.unique(m).tolist()) <= {0.0, -100.0}
+    assert np.array_equal((m != 0).astype(np.int8), g['mask_' + tag])
+    rid = ix.window_region_ids(Dp, Hp, Wp, ws, ss)
+    assert np.array_equal((rid[:, :, None] != rid[:, None, :]).astype(np.int8), g['mask_' + tag])
+    assert np.array_equal(ix.shifted_window_token_index(Dp, Hp, Wp, ws, ss), g['part_' + tag])
+
+
+def test_blend_merge_mlm_indices():
+    g = gutil.load('g_idx.npz')
+    w = ix.mask_blend_weight(g['blend_mask'], 2, 28, 28)
+    assert np.array_equal(w.astype(np.int8), g['blend_w'])
+    assert np.array_equal(ix.patch_merging_gather(g['merge_in']), g['merge_cat'])
+    tid, lab = g['ssl_token_ids'][:, 0], g['ssl_mlm_label'][:, 0]
+    assert np.array_equal(ix.input_ssl_ids(tid, lab), g['ssl_ids'])
+    rows, labels = ix.mlm_rows(lab)
+    assert np.array_equal(rows, g['mlm_rows']) and np.array_equal(labels, g['mlm_row_labels'])
+
+
+# ------------------------------------------------------------------ float sets
+@pytest.fixture(scope='module')
+def P():
+    return cf.cf_state(gutil.manifest())
+
+
+@pytest.fixture(scope='module')
+def ocfg():
+    return cf.oracle_cfg_from(cf.tiny_model_cfg())
+
+
+def test_swin(P, ocfg):
+    g = gutil.load('g_swin.npz')
+    Pg = {k: v.clone().requires_grad_() for k, v in P.items() if k.startswith('backbone.')}
+    batch = cf.cf_batch(2, tag='swin')
+    x, vm = batch['imgs'][:, 0], batch['v_token_mask']
+    taps = {}
+    y = om.swin_forward(Pg, 'backbone.', x, ocfg['backbone'], taps=taps)
+    for k, v in taps.items():
+        gutil.assert_packed(g, 'clean.' + k, v if k != 'patch_embed' else v)
+    gutil.assert_close(y, g['clean.out'], name='clean.out')
+    taps = {}
+    ym, w = om.swin_forward(Pg, 'backbone.', x.clone(), ocfg['backbone'], vm, taps=taps)
+    for k, v in taps.items():
+        gutil.assert_packed(g, 'masked.' + k, v)
+    gutil.assert_close(ym, g['masked.out'], name='masked.out')
+    assert np.array_equal(w.numpy().astype(np.int8), g['masked.w'])
+    gw = cf.cf_float('swin.gw', tuple(y.shape), 1.0)
+    ((y * gw).sum() + (ym * gw.flip(0)).sum()).backward()
+    for k in [n[5:-4] for n in g.files if n.startswith('grad.') and n.endswith('.sub')]:
+        gutil.assert_packed(g, 'grad.' + k, Pg['backbone.' + k].grad, rtol=2e-4)
+
+
+def test_bert_and_fusion(P, ocfg):
+    g = gutil.load('g_bert_fuse.npz')
+    b = cf.cf_batch(3, tag='bf')
+    ids, mask = b['token_ids'][:, 0], b['input_mask'][:, 0]
+    t = om.bert_forward(P, 'text_backbone.', ids, mask, ocfg['bert'])
+    gutil.assert_close(t, g['bert.last_hidden_state'], name='bert')
+    vt = cf.cf_float('bf.vt', (3, 2, 196, 96), 1.0)
+    f = om.fusion_forward(P, 'multimodal_backbone.', vt, mask, t, ocfg['fusion'])
+    gutil.assert_close(f['t_last_hidden_state'], g['fuse.t_last_hidden_state'], name='fuse.t')
+    gutil.assert_packed(g, 'fuse.v_last_hidden_state', f['v_last_hidden_state'])
+
+
+def test_heads_and_losses(P):
+    g = gutil.load('g_heads_loss.npz')
+    vis = cf.cf_float('hl.vis', (4, 96, 2, 14, 14), 1.0)
+    txt = cf.cf_float('hl.txt', (4, 16, 128), 1.0)
+    gutil.assert_close(om.nce_mm_forward_vision(P, 'ssl_head.', vis), g['mm.vision'])
+    gutil.assert_close(om.nce_mm_forward_vision(P, 'ssl_head.', vis[:1]), g['mm.vision_b1'])
+    gutil.assert_close(om.nce_mm_forward_text(P, 'ssl_head.', txt), g['mm.text'])
+    row = cf.cf_float('hl.row', (4, 128), 1.0)
+    gutil.assert_close(om.nce_vision_head(P, 'mlm_ssl_V_head.', row), g['V.head'])
+    gutil.assert_close(om.nce_text_head(P, 'mlm_ssl_T_head.', row), g['T.head'])
+    gutil.assert_close(om.mlm_head(P, 'mlm_head.', txt[:2]), g['mlm.scores'])
+    logits = cf.cf_float('hl.logits', (7, 1024), 4.0)
+    tgt = cf.cf_int('hl.tgt', (7,), 0, 1024)
+    gutil.assert_close(om.focal_loss_multiclass(logits, tgt), g['focal'])
+    for G in [1, 2, 4, 8]:
+        e = [cf.cf_float(f'hl.e{k}.{G}', (G, 128), 1.0) for k in range(4)]
+        l = om.exclusive_nce_rank_loss(*e, gather=False)
+        gutil.assert_close(l['nce_loss'], g[f'nce.G{G}.nce_loss'], atol=2e-5, name=f'nce G{G}')
+        gutil.assert_close(l['rank_t_tm_loss'], g[f'nce.G{G}.rank_t_tm_loss'], name=f'rank G{G}')
+    e = [cf.cf_float(f'hl.e{k}.4', (4, 128), 1.0).requires_grad_() for k in range(4)]
+    l = om.exclusive_nce_rank_loss(*e, gather=False)
+    (l['nce_loss'] + l['rank_t_tm_loss']).backward()
+    for k in range(4):
+        gutil.assert_close(e[k].grad, g[f'nce.G4.grad{k}'], rtol=2e-4, name=f'grad{k}')
+
+
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_step_config1(P, ocfg, B):
+    """BASELINE config 1: full forward_train -> 5 losses + total, plus selected grads."""
+    g = gutil.load('g_step.npz')
+    Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
+    batch = cf.cf_batch(B, tag=f'step{B}')
+    losses = om.forward_train(Pg, batch, ocfg, gather=False)
+    loss, lv = om.parse_losses(losses)
+    for k in ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']:
+        assert abs(lv[k] - float(g[f'B{B}.{k}'])) <= 2e-4 * max(1.0, abs(float(g[f'B{B}.{k}']))), (k, lv[k], float(g[f'B{B}.{k}']))
+    loss.backward()
+    for k in [n[len(f'B{B}.grad.'):-4] for n in g.files if n.startswith(f'B{B}.grad.') and n.endswith('.sub')]:
+        gutil.assert_packed(g, f'B{B}.grad.{k}', Pg[k].grad, rtol=5e-3, atol=1e-6)  # fp32 summation-order noise through the /0.05 logits
+    unused = sorted(k for k, p in Pg.items() if p.grad is None)
+    assert unused == gutil.unused_params()
