@@ -1,0 +1,224 @@
+"""Headline benchmark: video-text pairs/sec of the full Clover pre-training step
+(forward + backward + gradient all-reduce + clip + AdamW) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+
+Workload = BASELINE.json configs[1] (N=1) / configs[2] (N>1): VideoSwin-T + BERT-base + 3-layer
+fusion, per-GPU batch 8 clips x 8 frames x 224^2 + 32-token captions, all five losses on, bf16
+MFMA compute with fp32 master weights.  Synthetic data (SURVEY §8d generator, seed 1000+rank),
+random-init weights, inputs resident in HBM before the timed region.  Weak scaling: per-GPU
+batch fixed; `value` = global pairs / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+AUX = ['token_ids', 'segment_ids', 'input_mask', 'mlm_label', 'v_token_mask']
+GF_PER_PAIR = {('T', 8): 334.4, ('B', 8): 885.2, ('B', 16): 1846.0, ('B', 32): 3663.2}   # BASELINE.md §2, fwd+bwd
+
+
+def model_cfg(variant='T', frames=8):
+    """configs/exp_local/pretrain_webvid_cc3m.py:22-112 with the Swin-T backbone of
+    configs/_base_/models/swin3d/swin3d_tiny.py (BASELINE configs[1])."""
+    swin = dict(T=dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], drop_path_rate=0.1),
+                B=dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], drop_path_rate=0.3))[variant]
+    cf = swin['embed_dim'] * 8
+    return dict(
+        type='CloverPretrain', freeze_stage=None, separate_test=True, use_Cmask=True,
+        backbone=dict(type='SwinTransformer3D', patch_size=(2, 4, 4), stride=(2, 4, 4), window_size=(8, 7, 7),
+                      mask_token=True, pretrained2d=False, pretrained=None, **swin),
+        freeze_text_backbone=None, text_vocab_size=30522,
+        mm_backbone=dict(type='CrossModalTransformerFromPretrained', use_text_cls=True, use_prompt=False,
+                         pretrained_model='bert-base-uncased', num_hidden_layers=3, img_in_size=cf, hidden_size=768,
+                         num_frames=frames // 2, spacial_tokens=49, token_types=2, layer_norm_eps=1e-12,
+                         word_pos_start=False, bert_config=dict(BERT_BASE)),
+        text_backbone=dict(type='BertFromPretrained', num_hidden_layers=12, bert_config=dict(BERT_BASE)),
+        cls_head=None,
+        ssl_head=dict(type='NCEHeadForMM', visual_in_channels=cf, text_in_channels=768, img_hidden_dim=1536,
+                      vts_embed_dim=768, ln=True, spatial_type='avg', text_agg_type='cls', dropout_ratio=0),
+        mlm_head=dict(type='MLMHead', hidden_size=768, vocab_size=30522),
+        mlm_ssl_head=dict(
+            V=dict(type='NCEHeadForVision', visual_in_channels=768, cross_in_channels=768, hidden_dim=768, ln=True,
+                   vts_embed_dim=768, dropout_ratio=0),
+            T=dict(type='NCEHeadForText', cross_in_channels=768, vts_embed_dim=768, text_bn=False, dropout_ratio=0.1)),
+        mlm_loss=dict(type='SoftmaxFocalLossMultiClass', gamma=2.0),
+        loss_type=dict(type='CrossEntropyLoss'),
+        ssl_loss=dict(type='ExclusiveNCEwithRankingLoss', temperature=0.05, use_rank=True, use_rank_ttm=True,
+                      use_rank_trtm=False, margin_ttm=5., margin_trtm=10.),
+        symmetry_rank=True, train_cfg=dict(aux_info=list(AUX)))
+
+
+def synthetic_batch(B, frames, L, seed, size=224):
+    """SURVEY §8d generator: N(0,1) clips; [CLS] ids [SEP] pad; 30 % MLM positions (80 % -> [MASK]);
+    block-wise ~10-cell 7x7 video mask."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(B, 1, 3, frames, size, size, generator=g)
+    ids = torch.zeros(B, 1, L, dtype=torch.long)
+    mlm = torch.full((B, 1, L), -100, dtype=torch.long)
+    vm = torch.zeros(B, 1, 7, 7, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(6, L - 1, (1,), generator=g))
+        ids[b, 0, 0] = 101
+        ids[b, 0, 1:1 + n] = torch.randint(1000, 30000, (n,), generator=g)
+        ids[b, 0, 1 + n] = 102
+        sel = torch.rand(n, generator=g) < 0.3
+        sel[0] = True
+        pos = torch.nonzero(sel).flatten() + 1
+        mlm[b, 0, pos] = ids[b, 0, pos]
+        to_mask = pos[torch.rand(len(pos), generator=g) < 0.8]
+        ids[b, 0, to_mask] = 103
+        r0, c0 = int(torch.randint(0, 5, (1,), generator=g)), int(torch.randint(0, 4, (1,), generator=g))
+        vm[b, 0, r0:r0 + 3, c0:c0 + 4] = 1
+        vm[b, 0, r0, c0] = 0
+        vm[b, 0, r0 + 2, c0 + 3] = 0
+    return dict(imgs=imgs, label=torch.zeros(B, dtype=torch.long), token_ids=ids,
+                segment_ids=torch.zeros_like(ids), input_mask=(ids != 0).long(), mlm_label=mlm, v_token_mask=vm)
+
+
+def oracle_cfg(cfg):
+    bb = {k: cfg['backbone'][k] for k in ('patch_size', 'embed_dim', 'depths', 'num_heads', 'window_size')}
+    return dict(backbone=bb,
+                bert=dict(num_hidden_layers=cfg['text_backbone']['num_hidden_layers'], num_attention_heads=12,
+                          layer_norm_eps=1e-12),
+                fusion=dict(num_hidden_layers=cfg['mm_backbone']['num_hidden_layers'], num_attention_heads=12,
+                            layer_norm_eps=1e-12),
+                temperature=0.05, margin=5.0, gamma=2.0, vocab=30522)
+
+
+def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
+    """The oracle (fp32 CPU restatement of the reference step, parity-pinned to the reference by
+    tests/golden) timed on this box's host cores: forward + losses + backward, B = 2."""
+    from oracle import model as om
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    P = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
+         for k, v in state.items() if 'relative_position_index' not in k}
+    B = 2
+    batch = synthetic_batch(B, frames, L, seed=999)
+    ocfg = oracle_cfg(cfg)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        t0 = time.time()
+        losses = om.forward_train(P, batch, ocfg, gather=False)
+        loss, _ = om.parse_losses(losses)
+        loss.backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        for p in P.values():
+            p.grad = None
+        if time.time() - t_start > budget_s and times:
+            break
+    per = sum(times) / len(times)
+    return dict(value=round(B / per, 4), unit='pairs/s', cores=ncores, kind='port',
+                sample=f'oracle forward_train+backward, fp32, B={B}, {frames}f x 224^2, L={L}, '
+                       f'{len(times)} timed iters after 1 warm-up ({per:.2f} s/iter)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=8)
+    ap.add_argument('--tokens', type=int, default=32)
+    ap.add_argument('--variant', default='T', choices=['T', 'B'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    import clover_amd
+    from clover_amd import ops
+    from clover_amd.engine import CloverEngine
+
+    torch.manual_seed(1234)                              # identical init on every rank (== DDP broadcast)
+    cfg = model_cfg(args.variant, args.frames)
+    model = clover_amd.build_model(cfg).to(dev)
+    model.train()                                        # dropout / DropPath active, as in training
+    state_cpu = None
+    if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
+        state_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.frames, args.tokens, 1000 + rank).items()}
+    engine = CloverEngine(model, batch, lr=5e-5 / 1024 * args.batch * world, weight_decay=0.005, grad_clip=15.0,
+                          max_iters=100000)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = engine.step(batch)
+    sync()
+    if not args.no_kernel_timing:
+        ops.PROF = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = engine.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROF = ops.PROF, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log_vars = {k: float(v) for k, v in out['log_vars'].items()}
+    gnorm = engine.grad_norm()
+
+    if rank == 0:
+        gb = args.batch * world
+        pairs_s = gb * args.steps / dt
+        gf = GF_PER_PAIR.get((args.variant, args.frames))
+        res = {
+            'metric': 'video-text pairs/sec (8f x 224^2, 32-tok), full pre-training step',
+            'value': round(pairs_s, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'VideoSwin-{args.variant} + BERT-base + 3-layer fusion, MLM + tri-modal '
+                                   f'exclusive InfoNCE + rank losses, {args.frames}f x 224^2, {args.tokens}-tok',
+                       'per_gpu_batch': args.batch, 'global_batch': gb, 'parallelism': f'dp{world}',
+                       'params_M': round(engine.num_params / 1e6, 1)},
+            'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
+            'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
+            'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
+        }
+        if prof:
+            res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, args.steps)
+        if state_cpu is not None:
+            res['cpu_baseline'] = cpu_baseline(cfg, state_cpu, args.frames, args.tokens)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

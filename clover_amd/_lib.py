@@ -1,0 +1,73 @@
+"""ctypes binding of libclover_hip.so — the C ABI declared in include/clover_hip.h.
+
+The product path has NO CPU fallback: every op in ``clover_amd.ops`` goes through this
+library, and a missing/unloadable library raises at first use (``lib()``).  Build it with
+``python __graft_entry__.py`` (or ``make -C clover_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libclover_hip.so')
+ABI_VERSION = 1
+
+ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
+          -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
+
+
+class ClvAttnGeom(C.Structure):
+    """Mirror of ``struct ClvAttnGeom`` (include/clover_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in
+                ('mode', 'groups', 'N', 'nH', 'hd', 'D', 'H', 'W', 'wd', 'wh', 'ww', 'sd', 'sh', 'sw',
+                 'ldq', 'ldk', 'ldv', 'ldo', 'bias_ld')] + [('scale', C.c_float)]
+
+
+_p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
+SIGNATURES = {
+    'clv_abi_version': (C.c_int, []),
+    'clv_attn_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_bwd': (C.c_int, [_p] * 14 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_layernorm_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _p]),
+    'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
+    'clv_layernorm_bwd': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _p]),
+    'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
+    'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),
+    'clv_im2col_patches': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p]),
+    'clv_focal_ce_fwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
+    'clv_focal_ce_bwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
+    'clv_infonce_work_floats': (C.c_int64, [_i32, _i32]),
+    'clv_infonce_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _f, _f, _p]),
+    'clv_infonce_bwd': (C.c_int, [_p] * 10 + [_i32, _i32, _f, _f, _p]),
+    'clv_sumsq': (C.c_int, [_p, _p, _i64, _p]),
+    'clv_adamw_step': (C.c_int, [_p] * 6 + [_i64] + [_f] * 9 + [_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when it is missing — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'clover_amd: {LIB_PATH} is missing — the HIP extension is not built. '
+                'Run `python __graft_entry__.py` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        v = L.clv_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f'clover_amd: ABI version mismatch (library {v}, binding {ABI_VERSION}); rebuild')
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'clover_amd: {what} failed: {ERRORS.get(rc, rc)}')

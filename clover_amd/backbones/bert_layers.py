@@ -1,0 +1,193 @@
+"""BERT building blocks with HuggingFace's module/parameter names, MI355X-native compute.
+
+The reference delegates these to the un-vendored ``transformers==4.6.1`` (install.sh:25;
+call sites bert_from_hugface.py:13-15,30, cross_transformer.py:24-29,109-110,
+mlm_itm_head.py:33-41).  Semantics restated from that version: embeddings = word +
+token_type(0) + absolute position -> LayerNorm(eps) -> dropout; each layer = post-LN
+self-attention (scores/sqrt(d) + additive mask (1-m)*-10000, softmax, dropout, context) ->
+dense + dropout + residual + LN -> GELU(erf) FFN -> dense + dropout + residual + LN.
+
+Q/K/V keep their three separate Parameters (checkpoint compatibility) but run as ONE
+[3H,H] GEMM; attention is the fused HIP kernel (``clv_attn_fwd`` mode 0); residual adds are
+fused into the LayerNorm kernel.
+"""
+import json
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..nn import LayerNorm, Linear, to_bf16
+
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12,
+                 hidden_act='gelu')
+
+
+def resolve_bert_config(pretrained_model='bert-base-uncased', bert_config=None, **overrides):
+    """Config resolution without network: explicit ``bert_config`` dict > a local directory
+    ``<pretrained_model>/config.json`` (what the reference's from_pretrained reads offline) >
+    the built-in bert-base-uncased table."""
+    cfg = dict(BERT_BASE)
+    if bert_config is not None:
+        cfg.update(bert_config)
+    elif pretrained_model and os.path.isfile(os.path.join(str(pretrained_model), 'config.json')):
+        with open(os.path.join(str(pretrained_model), 'config.json')) as f:
+            cfg.update({k: v for k, v in json.load(f).items() if k in cfg})
+    elif pretrained_model not in (None, 'bert-base-uncased'):
+        raise FileNotFoundError(f'no local BERT config for {pretrained_model!r} (no network access); '
+                                'pass bert_config=dict(...) or a directory with config.json')
+    cfg.update({k: v for k, v in overrides.items() if v is not None})
+    if cfg['hidden_act'] != 'gelu':
+        raise NotImplementedError('only erf-GELU BERT is supported')
+    return cfg
+
+
+def load_pretrained_dir(module, pretrained_model, prefix=''):
+    """Load ``<dir>/model.safetensors`` / ``pytorch_model.bin`` if present (non-strict)."""
+    d = str(pretrained_model)
+    sd = None
+    if os.path.isfile(os.path.join(d, 'model.safetensors')):
+        from safetensors.torch import load_file
+        sd = load_file(os.path.join(d, 'model.safetensors'))
+    elif os.path.isfile(os.path.join(d, 'pytorch_model.bin')):
+        sd = torch.load(os.path.join(d, 'pytorch_model.bin'), map_location='cpu')
+    if sd is None:
+        return False
+    if prefix:
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=False)
+    return True
+
+
+def init_bert_weights(module, std=0.02):
+    """HF BertPreTrainedModel._init_weights."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            m.weight.data.normal_(mean=0.0, std=std)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.Embedding):
+            m.weight.data.normal_(mean=0.0, std=std)
+        elif isinstance(m, nn.LayerNorm):
+            m.bias.data.zero_()
+            m.weight.data.fill_(1.0)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg['vocab_size'], cfg['hidden_size'], padding_idx=0)
+        self.position_embeddings = nn.Embedding(cfg['max_position_embeddings'], cfg['hidden_size'])
+        self.token_type_embeddings = nn.Embedding(cfg['type_vocab_size'], cfg['hidden_size'])
+        self.LayerNorm = LayerNorm(cfg['hidden_size'], eps=cfg['layer_norm_eps'])
+        self.dropout = nn.Dropout(cfg['hidden_dropout_prob'])
+
+    def forward(self, input_ids, past_key_values_length=0):
+        L = input_ids.shape[1]
+        pos = torch.arange(past_key_values_length, past_key_values_length + L, device=input_ids.device)
+        e = self.word_embeddings(input_ids) + self.token_type_embeddings.weight[0] + self.position_embeddings(pos)[None]
+        return self.dropout(self.LayerNorm(to_bf16(e)))
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        H = cfg['hidden_size']
+        self.num_attention_heads = cfg['num_attention_heads']
+        self.query = Linear(H, H)
+        self.key = Linear(H, H)
+        self.value = Linear(H, H)
+        self.attn_dropout_p = cfg['attention_probs_dropout_prob']
+
+    def forward(self, x, kmask):
+        w = torch.cat([self.query.weight, self.key.weight, self.value.weight], dim=0)
+        b = torch.cat([self.query.bias, self.key.bias, self.value.bias], dim=0)
+        qkv = F.linear(to_bf16(x), to_bf16(w), to_bf16(b))
+        return ops.seq_attention(qkv.contiguous(), kmask, self.num_attention_heads)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, cfg, in_features=None):
+        super().__init__()
+        H = cfg['hidden_size']
+        self.dense = Linear(in_features or H, H)
+        self.LayerNorm = LayerNorm(H, eps=cfg['layer_norm_eps'])
+        self.dropout = nn.Dropout(cfg['hidden_dropout_prob'])
+
+    def forward(self, hidden, residual):
+        return self.LayerNorm(self.dropout(self.dense(hidden)), residual=residual)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = BertSelfAttention(cfg)
+        self.output = BertSelfOutput(cfg)
+
+    def forward(self, x, kmask):
+        return self.output(self.self(x, kmask), x)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = Linear(cfg['hidden_size'], cfg['intermediate_size'])
+
+    def forward(self, x):
+        return ops.gelu(self.dense(x))
+
+
+class BertLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = BertAttention(cfg)
+        self.intermediate = BertIntermediate(cfg)
+        self.output = BertSelfOutput(cfg, in_features=cfg['intermediate_size'])
+
+    def forward(self, x, kmask):
+        a = self.attention(x, kmask)
+        return self.output(self.intermediate(a), a)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(cfg) for _ in range(cfg['num_hidden_layers'])])
+
+    def forward(self, x, kmask):
+        for layer in self.layer:
+            x = layer(x, kmask)
+        return x
+
+
+class BertPooler(nn.Module):
+    """Present for state_dict compatibility; statically unused on the pre-training path
+    (only last_hidden_state is read, multimodal_transformer_pretrain.py:101,111)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = Linear(cfg['hidden_size'], cfg['hidden_size'])
+
+
+class BertModel(nn.Module):
+    def __init__(self, cfg, add_pooling_layer=True):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = BertEmbeddings(cfg)
+        self.encoder = BertEncoder(cfg)
+        self.pooler = BertPooler(cfg) if add_pooling_layer else None
+
+    def forward(self, input_ids=None, attention_mask=None):
+        kmask = extended_attention_mask(attention_mask)
+        h = self.encoder(self.embeddings(input_ids), kmask)
+        return {'last_hidden_state': h}
+
+
+def extended_attention_mask(mask):
+    """transformers 4.6.1 get_extended_attention_mask for a 2-D mask, as the [B,S] fp32 additive
+    key mask the attention kernel takes: (1 - mask) * -10000.0."""
+    return ((1.0 - mask.to(torch.float32)) * -10000.0).contiguous()

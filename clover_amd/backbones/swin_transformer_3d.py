@@ -1,0 +1,414 @@
+"""Video Swin Transformer backbone, MI355X-native.
+
+Registered as ``SwinTransformer3D`` with the reference's constructor kwargs and
+``state_dict`` key names (mmaction/models/backbones/swin_transformer_3d.py:18-247), so
+reference / VideoSwin checkpoints load unchanged.  What differs is how it runs:
+
+* activations stay channels-last ``[B,T',H,W,C]`` bf16 end-to-end (the reference bounces
+  between ``B C D H W`` and ``B D H W C`` at every stage, :634,645,237-239);
+* patch embedding + LayerNorm + mask-token blend is one HIP kernel that reads the fp32 clip
+  once and emits the clean AND the masked token tensors (``clv_patch_embed_fwd``);
+* cyclic shift, window partition, relative-position bias, shift mask, softmax, PV, window
+  reverse and un-shift are one HIP kernel on the natural token layout (``clv_attn_fwd``):
+  no rolled / partitioned copies and no [B_,nH,N,N] score tensor ever reach HBM;
+* ``forward_pair`` runs the clean and the masked pass of the pre-training step
+  (multimodal_transformer_pretrain.py:91,114) as ONE pass over 2B clips — every weight is
+  read once and every GEMM has twice the rows; results equal two separate passes because
+  no op mixes samples (LayerNorm only).
+"""
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..builder import BACKBONES
+from ..nn import GELU, DropPath, LayerNorm, Linear, trunc_normal_
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------- geometry (host, cached)
+def get_window_size(x_size, window_size, shift_size=None):
+    """Clamp window to the feature size, zero the shift on clamped axes (reference :302-315)."""
+    use_ws = list(window_size)
+    use_ss = list(shift_size) if shift_size is not None else None
+    for i in range(len(x_size)):
+        if x_size[i] <= window_size[i]:
+            use_ws[i] = x_size[i]
+            if use_ss is not None:
+                use_ss[i] = 0
+    if shift_size is None:
+        return tuple(use_ws)
+    return tuple(use_ws), tuple(use_ss)
+
+
+def build_relative_position_index(window_size):
+    """[N,N] int64 index into the (2wd-1)(2wh-1)(2ww-1)-row bias table (reference :345-359)."""
+    wd, wh, ww = window_size
+    coords = torch.stack(torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing='ij'))
+    cf = torch.flatten(coords, 1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += wd - 1
+    rel[:, :, 1] += wh - 1
+    rel[:, :, 2] += ww - 1
+    rel[:, :, 0] *= (2 * wh - 1) * (2 * ww - 1)
+    rel[:, :, 1] *= (2 * ww - 1)
+    return rel.sum(-1)
+
+
+def region_id_windows(Dp, Hp, Wp, window_size, shift_size):
+    """Region ids of compute_mask (reference :548-562) per (window, token): int32 [nW, N].
+    The reference's additive mask is ``-100 * (rid[w,i] != rid[w,j])``; the attention kernel
+    evaluates that predicate in registers instead of reading an [nW,N,N] tensor."""
+    img = np.zeros((Dp, Hp, Wp), dtype=np.int32)
+    cnt = 0
+    ws, ss = window_size, shift_size
+    # same python slice triples as the reference, degenerate cases (shift 0) included
+    for d in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
+        for h in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
+            for w in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
+                img[d, h, w] = cnt
+                cnt += 1
+    x = img.reshape(Dp // ws[0], ws[0], Hp // ws[1], ws[1], Wp // ws[2], ws[2])
+    return np.ascontiguousarray(x.transpose(0, 2, 4, 1, 3, 5).reshape(-1, ws[0] * ws[1] * ws[2]))
+
+
+@lru_cache(maxsize=64)
+def _window_geometry_cached(x_size, cfg_ws, cfg_ss, device_str):
+    ws, ss = get_window_size(x_size, cfg_ws, cfg_ss)
+    padded = tuple(int(np.ceil(x_size[i] / ws[i])) * ws[i] for i in range(3))
+    rid = None
+    if any(s > 0 for s in ss):
+        rid = torch.from_numpy(region_id_windows(padded[0], padded[1], padded[2], ws, ss)).to(device_str)
+    return ws, ss, rid, padded
+
+
+def window_geometry(x_size, cfg_ws, cfg_ss, device):
+    """(effective window, effective shift, region ids on `device` or None)."""
+    ws, ss, rid, _ = _window_geometry_cached(tuple(x_size), tuple(cfg_ws), tuple(cfg_ss), str(device))
+    return ws, ss, rid
+
+
+def gathered_bias(table, rel_index, N):
+    """table[index[:N,:N]] -> fp32 [nH, N, Npad] (Npad = N rounded up to 16), reference :382-384.
+    Plain torch gather: autograd scatters the kernel's dbias back into the 2535-row table."""
+    nH = table.shape[1]
+    b = table.float()[rel_index[:N, :N].reshape(-1)].reshape(N, N, nH).permute(2, 0, 1)
+    npad = (N + 15) // 16 * 16
+    if npad != N:
+        b = F.pad(b, (0, npad - N))
+    return b.contiguous()
+
+
+def mask_blend_weight(mask, T, H, W):
+    """w [B,1,T,H,W] of the reference's mask-token blend (:226-229)."""
+    _, _, mh, mw = mask.shape
+    w = mask.unsqueeze(-1).unsqueeze(-3).expand(-1, T, -1, H // mh, -1, W // mw)
+    return w.flatten(2, 3).flatten(3, 4).unsqueeze(1)
+
+
+# --------------------------------------------------------------------------- modules
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class WindowAttention3D(nn.Module):
+    """Parameters of the reference module (:331-367); the compute is ``ops.window_attention``
+    on the un-partitioned token grid."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.window_size = window_size
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
+            raise NotImplementedError('qk_scale override is not supported by the HIP attention kernel')
+        if attn_drop != 0.:
+            raise NotImplementedError('attn_drop_rate > 0 is not supported (Clover configs use 0)')
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * window_size[0] - 1) * (2 * window_size[1] - 1) * (2 * window_size[2] - 1), num_heads))
+        self.register_buffer('relative_position_index', build_relative_position_index(window_size))
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        trunc_normal_(self.relative_position_bias_table, std=.02)
+
+    def forward(self, x, ws, ss, rid):
+        """x bf16 [B,Dp,Hp,Wp,C] (already LN'd and padded) -> same shape."""
+        N = ws[0] * ws[1] * ws[2]
+        qkv = self.qkv(x)
+        bias = gathered_bias(self.relative_position_bias_table, self.relative_position_index, N)
+        o = ops.window_attention(qkv, bias, rid if any(s > 0 for s in ss) else None, ws, ss, self.num_heads)
+        return self.proj_drop(self.proj(o))
+
+
+class SwinTransformerBlock3D(nn.Module):
+    def __init__(self, dim, num_heads, window_size=(2, 7, 7), shift_size=(0, 0, 0), mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=GELU, norm_layer=LayerNorm,
+                 use_checkpoint=False):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.window_size, self.shift_size = window_size, shift_size
+        self.mlp_ratio = mlp_ratio
+        self.use_checkpoint = use_checkpoint
+        for i in range(3):
+            assert 0 <= shift_size[i] < window_size[i], 'shift_size must in 0-window_size'
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention3D(dim, window_size=window_size, num_heads=num_heads, qkv_bias=qkv_bias,
+                                      qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward_part1(self, x):
+        B, D, H, W, C = x.shape
+        ws, ss, rid = window_geometry((D, H, W), self.window_size, self.shift_size, x.device)
+        x = self.norm1(x)
+        pad_d1 = (ws[0] - D % ws[0]) % ws[0]
+        pad_b = (ws[1] - H % ws[1]) % ws[1]
+        pad_r = (ws[2] - W % ws[2]) % ws[2]
+        if pad_d1 or pad_b or pad_r:
+            x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b, 0, pad_d1))
+        x = self.attn(x, ws, ss, rid)
+        if pad_d1 or pad_b or pad_r:
+            x = x[:, :D, :H, :W, :].contiguous()
+        return x
+
+    def forward_part2(self, x):
+        return self.drop_path(self.mlp(self.norm2(x)))
+
+    def forward(self, x, mask_matrix=None):
+        """x bf16 [B,D,H,W,C].  ``mask_matrix`` is accepted for signature compatibility and unused:
+        the shift mask is evaluated from region ids inside the kernel."""
+        x = x + self.drop_path(self.forward_part1(x))
+        return x + self.forward_part2(x)
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer=LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        B, D, H, W, C = x.shape
+        if (H % 2 == 1) or (W % 2 == 1):
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x0 = x[:, :, 0::2, 0::2, :]
+        x1 = x[:, :, 1::2, 0::2, :]
+        x2 = x[:, :, 0::2, 1::2, :]
+        x3 = x[:, :, 1::2, 1::2, :]
+        x = torch.cat([x0, x1, x2, x3], -1)
+        return self.reduction(self.norm(x))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size=(1, 7, 7), mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., norm_layer=LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.window_size = window_size
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock3D(dim=dim, num_heads=num_heads, window_size=window_size,
+                                   shift_size=(0, 0, 0) if (i % 2 == 0) else self.shift_size, mlp_ratio=mlp_ratio,
+                                   qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                   drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                   norm_layer=norm_layer, use_checkpoint=use_checkpoint)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        """x bf16 channels-last [B,D,H,W,C] -> [B,D,H',W',C'] (the reference takes/returns B C D H W)."""
+        for blk in self.blocks:
+            x = blk(x)
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return x
+
+
+class PatchEmbed3D(nn.Module):
+    def __init__(self, patch_size=(2, 4, 4), in_chans=3, embed_dim=96, norm_layer=None, stride=(2, 4, 4)):
+        super().__init__()
+        if tuple(patch_size) != (2, 4, 4) or tuple(stride) != (2, 4, 4) or in_chans != 3:
+            raise NotImplementedError('the HIP patch-embed kernel covers patch=stride=(2,4,4), in_chans=3 '
+                                      '(every Clover / VideoSwin config)')
+        self.patch_size = tuple(patch_size)
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=stride)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def pad(self, x):
+        _, _, D, H, W = x.size()
+        if W % self.patch_size[2] != 0:
+            x = F.pad(x, (0, self.patch_size[2] - W % self.patch_size[2]))
+        if H % self.patch_size[1] != 0:
+            x = F.pad(x, (0, 0, 0, self.patch_size[1] - H % self.patch_size[1]))
+        if D % self.patch_size[0] != 0:
+            x = F.pad(x, (0, 0, 0, 0, 0, self.patch_size[0] - D % self.patch_size[0]))
+        return x
+
+    def tokens(self, x, mask_token=None, vmask=None, want_clean=True):
+        """fp32 clip [B,3,T,H,W] -> (clean, masked) bf16 channels-last tokens."""
+        x = self.pad(x)
+        g, b = (self.norm.weight, self.norm.bias) if self.norm is not None else (None, None)
+        eps = self.norm.eps if self.norm is not None else 1e-5
+        return ops.patch_embed(x, self.proj.weight, self.proj.bias, g, b, mask_token, vmask, want_clean, eps)
+
+    def forward(self, x):
+        """Reference contract: [B,3,T,H,W] -> [B,C,T',H',W']."""
+        clean, _ = self.tokens(x)
+        return clean.permute(0, 4, 1, 2, 3)
+
+
+@BACKBONES.register_module()
+class SwinTransformer3D(nn.Module):
+    def __init__(self, pretrained=None, pretrained2d=True, patch_size=(2, 4, 4), stride=(2, 4, 4), in_chans=3,
+                 embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=(8, 7, 7), mlp_ratio=4.,
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1,
+                 norm_layer=LayerNorm, patch_norm=True, frozen_stages=-1, use_checkpoint=False, mask_token=False):
+        super().__init__()
+        if norm_layer is nn.LayerNorm:
+            norm_layer = LayerNorm
+        self.pretrained = pretrained
+        self.pretrained2d = pretrained2d
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.patch_norm = patch_norm
+        self.frozen_stages = frozen_stages
+        self.window_size = tuple(window_size)
+        self.patch_size = tuple(patch_size)
+        self.fp16_enabled = False
+        self.patch_embed = PatchEmbed3D(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, stride=stride,
+                                        norm_layer=norm_layer if self.patch_norm else None)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i_layer in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i_layer), depth=depths[i_layer], num_heads=num_heads[i_layer],
+                window_size=self.window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if i_layer < self.num_layers - 1 else None, use_checkpoint=use_checkpoint))
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.norm = norm_layer(self.num_features)
+        if mask_token:
+            self.mask_token = nn.Parameter(torch.zeros(1, self.embed_dim, 1, 1, 1))
+            trunc_normal_(self.mask_token, mean=0., std=.02)
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.patch_embed.eval()
+            for p in self.patch_embed.parameters():
+                p.requires_grad = False
+        if self.frozen_stages >= 1:
+            self.pos_drop.eval()
+            for i in range(0, self.frozen_stages):
+                m = self.layers[i]
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def inflate_weights(self, state_dict):
+        """2D Swin -> 3D inflation of a checkpoint state_dict (reference :130-181)."""
+        state_dict = {k: v for k, v in state_dict.items()
+                      if 'relative_position_index' not in k and 'attn_mask' not in k}
+        w = state_dict['patch_embed.proj.weight']
+        state_dict['patch_embed.proj.weight'] = w.unsqueeze(2).repeat(1, 1, self.patch_size[0], 1, 1) / self.patch_size[0]
+        for k in [k for k in state_dict if 'relative_position_bias_table' in k]:
+            pre = state_dict[k]
+            cur = self.state_dict()[k]
+            L1, nH1 = pre.size()
+            _, nH2 = cur.size()
+            L2 = (2 * self.window_size[1] - 1) * (2 * self.window_size[2] - 1)
+            wd = self.window_size[0]
+            if nH1 != nH2:
+                continue
+            if L1 != L2:
+                S1 = int(L1 ** 0.5)
+                pre = F.interpolate(pre.permute(1, 0).view(1, nH1, S1, S1),
+                                    size=(2 * self.window_size[1] - 1, 2 * self.window_size[2] - 1), mode='bicubic')
+                pre = pre.view(nH2, L2).permute(1, 0)
+            state_dict[k] = pre.repeat(2 * wd - 1, 1)
+        return self.load_state_dict(state_dict, strict=False)
+
+    def init_weights(self, pretrained=None):
+        def _init_weights(m):
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        if pretrained:
+            self.pretrained = pretrained
+        if isinstance(self.pretrained, str):
+            self.apply(_init_weights)
+            ckpt = torch.load(self.pretrained, map_location='cpu')
+            sd = ckpt.get('state_dict', ckpt)
+            if self.pretrained2d:
+                self.inflate_weights(sd)
+            else:
+                sd = {(k[len('backbone.'):] if k.startswith('backbone.') else k): v for k, v in sd.items()}
+                self.load_state_dict(sd, strict=False)
+        elif self.pretrained is None:
+            self.apply(_init_weights)
+        else:
+            raise TypeError('pretrained must be a str or None')
+
+    # ---- channels-last core -------------------------------------------------------------
+    def _stages(self, x):
+        x = self.pos_drop(x)
+        for layer in self.layers:
+            x = layer(x)
+        return self.norm(x)
+
+    def forward_tokens(self, x, mask=None):
+        """[B,3,T,H,W] -> channels-last features [B,T',h,w,Cf] (masked pass if `mask` given)."""
+        if mask is None:
+            t, _ = self.patch_embed.tokens(x)
+        else:
+            _, t = self.patch_embed.tokens(x, self.mask_token, mask, want_clean=False)
+        return self._stages(t)
+
+    def forward_pair(self, x, mask):
+        """Clean + masked pass of the pre-training step as ONE 2B-clip pass.
+        Returns (clean [B,T',h,w,Cf], masked [B,T',h,w,Cf]) channels-last bf16."""
+        B = x.shape[0]
+        clean, masked = self.patch_embed.tokens(x, self.mask_token, mask)
+        y = self._stages(torch.cat([clean, masked], dim=0))
+        return y[:B], y[B:]
+
+    def forward(self, x, mask=None):
+        """Reference contract: [B,3,T,H,W] -> [B,Cf,T',h,w]; with ``mask`` -> (x, w)."""
+        y = self.forward_tokens(x, mask).permute(0, 4, 1, 2, 3)
+        if mask is not None:
+            _, _, T, H, W = (x.shape[0], 0, (x.shape[2] + 1) // 2, (x.shape[3] + 3) // 4, (x.shape[4] + 3) // 4)
+            w = mask_blend_weight(mask, T, H, W).type_as(y)
+            return y, w
+        return y
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()

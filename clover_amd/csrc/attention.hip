@@ -1,0 +1,558 @@
+// Fused multi-head attention for the Clover path (gfx950, bf16 MFMA 16x16x32).
+//
+//   mode 1: WindowAttention3D (reference swin_transformer_3d.py:375-400) with the
+//           cyclic shift + window partition/reverse (:459-476) folded into the
+//           load/store index math — q/k/v/o live in the natural [B,D,H,W,*] layout.
+//   mode 0: BERT self-attention over a [B,S,*] sequence with an additive key mask.
+//
+// One workgroup (4 waves) = one (group, head).  K (row-major) and V (transposed)
+// are staged in LDS; each wave owns 16-query tiles.  QKᵀ is computed SWAPPED
+// (Sᵀ = K·Qᵀ) so that a lane holds, for ONE query (lane&15), the scores of keys
+// t*16 + (lane>>4)*4 + r — a row softmax is then lane-local plus two xor-shuffles,
+// and the bf16 P fragment feeds the PV MFMA (Oᵀ = Vᵀ·Pᵀ) without any transpose:
+// the MFMA k-index κ = (lane>>4)*8 + j simply enumerates the keys
+// {2s*16 + (lane>>4)*4 + (j&3), j<4} ∪ {(2s+1)*16 + ...} and Vᵀ is read with the
+// same enumeration.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+constexpr int THREADS = WAVES * 64;
+
+struct Geom {
+    ClvAttnGeom g;
+    int nWh, nWw, nW;  // windows per axis / per clip (mode 1)
+};
+
+__device__ __forceinline__ int64_t tok_row(const Geom& G, int grp, int n) {
+    if (G.g.mode == 0) return (int64_t)grp * G.g.N + n;
+    const int b = grp / G.nW, wi = grp - b * G.nW;
+    const int wz = wi / (G.nWh * G.nWw), wr = wi - wz * (G.nWh * G.nWw);
+    const int wy = wr / G.nWw, wx = wr - wy * G.nWw;
+    const int tz = n / (G.g.wh * G.g.ww), tr = n - tz * (G.g.wh * G.g.ww);
+    const int ty = tr / G.g.ww, tx = tr - ty * G.g.ww;
+    int d = wz * G.g.wd + tz + G.g.sd; if (d >= G.g.D) d -= G.g.D;   // roll(-shift): shifted[d'] = x[(d'+s) mod D]
+    int h = wy * G.g.wh + ty + G.g.sh; if (h >= G.g.H) h -= G.g.H;
+    int w = wx * G.g.ww + tx + G.g.sw; if (w >= G.g.W) w -= G.g.W;
+    return (((int64_t)b * G.g.D + d) * G.g.H + h) * G.g.W + w;
+}
+
+// XCD-aware remap: consecutive logical ids (the heads of one window) share an XCD/L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int HD>
+__device__ __forceinline__ void load_frags(Frag8 (&f)[(HD + 31) / 32], const bf16_t* rowp, bool valid, int lane) {
+    constexpr int KS = (HD + 31) / 32;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int hd0 = s * 32 + (lane >> 4) * 8;
+        if (valid && hd0 < HD) f[s].u4 = *reinterpret_cast<const uint4*>(rowp + hd0);
+        else f[s].u4 = make_uint4(0, 0, 0, 0);
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void lds_frags(Frag8 (&f)[(HD + 31) / 32], const bf16_t* rowp, int lane) {
+    constexpr int KS = (HD + 31) / 32;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int hd0 = s * 32 + (lane >> 4) * 8;
+        if (hd0 < HD) f[s].u4 = *reinterpret_cast<const uint4*>(rowp + hd0);
+        else f[s].u4 = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// Stage `N` rows of a [tokens][ld] bf16 matrix (cols h*HD .. +HD) of group `grp` row-major into
+// LDS rm[NK][HD+8]; pad rows are zeroed.  Transposed operands are NOT materialised: they are read
+// with the gfx950 LDS transpose read (tr4 below).
+template <int HD, int NK>
+__device__ __forceinline__ void stage(const Geom& G, const bf16_t* base, int ld, int grp, int h,
+                                      bf16_t* rm, int tid) {
+    constexpr int CH = HD / 8, LDR = HD + 8;
+    for (int idx = tid; idx < NK * CH; idx += THREADS) {
+        const int n = idx / CH, c = idx - n * CH;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (n < G.g.N) {
+            const int64_t row = tok_row(G, grp, n);
+            val = *reinterpret_cast<const uint4*>(base + row * ld + h * HD + c * 8);
+        }
+        *reinterpret_cast<uint4*>(rm + n * LDR + c * 8) = val;
+    }
+}
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: from a row-major LDS matrix (leading dim LD elements) return, for this lane,
+// M[row0 + 0..3][c0 + (lane&15)] — i.e. 4 consecutive ROWS of one column, the k-contiguous half of an
+// MFMA operand whose k index runs along the rows.  Lane i of each 16-lane group addresses the i-th
+// 8-byte piece of the 4x16 block (row i>>2, cols (i&3)*4..+3); the hardware transposes the block.
+__device__ __forceinline__ uint2 tr4(const bf16_t* base, int LD, int row0, int c0, int lr) {
+    const bf16_t* p = base + (row0 + (lr >> 2)) * LD + c0 + (lr & 3) * 4;
+    const v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+    union { v4s_t v; uint2 u; } cv;
+    cv.v = r;
+    return cv.u;
+}
+
+// score epilogue for one Sᵀ tile element
+struct ScoreCtx {
+    const float* bias_row;   // bias + (h*N + q)*bias_ld or nullptr
+    const int* rid_s;        // LDS region ids or nullptr
+    const float* km_s;       // LDS additive key mask or nullptr
+    int rid_q;
+    float scale;
+    int N, bias_ld;
+};
+
+// ------------------------------------------------------------------------- forward
+template <int HD, int NKT>
+__global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
+    const int* __restrict__ rid, const float* __restrict__ kmask, Geom G) {
+    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + NK * LDR;
+    float* aux = reinterpret_cast<float*>(Vs + NK * LDR);   // NK floats: kmask (mode 0) / rid as int (mode 1)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int N = G.g.N;
+
+    stage<HD, NK>(G, k, G.g.ldk, grp, h, Ks, tid);
+    stage<HD, NK>(G, v, G.g.ldv, grp, h, Vs, tid);
+    int* rid_s = reinterpret_cast<int*>(aux);
+    const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    for (int n = tid; n < NK; n += THREADS) {
+        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+    }
+    __syncthreads();
+
+    const int nqt = (N + 15) >> 4;
+    const int lg = lane >> 4, lr = lane & 15;
+    for (int qt = wave; qt < nqt; qt += WAVES) {
+        const int nq = qt * 16 + lr;
+        const bool qv = nq < N;
+        const int64_t qrow = qv ? tok_row(G, grp, nq) : 0;
+        Frag8 qf[KS];
+        load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
+
+        float p[NKT][4];
+        const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        const int rq = (rid && qv) ? rid_s[nq] : 0;
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            Frag8 kf[KS];
+            lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
+            const int key0 = t * 16 + lg * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + r;
+                float s = acc[r] * G.g.scale + bb[r];
+                if (rid) s += (rid_s[key] != rq) ? -100.0f : 0.0f;
+                else if (kmask) s += aux[key];
+                s = (key < N) ? s : -INFINITY;
+                p[t][r] = s;
+                m = fmaxf(m, s);
+            }
+        }
+        m = grp4_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(p[t][r] - m);
+                p[t][r] = e;
+                sum += e;
+            }
+        sum = grp4_sum(sum);
+        if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = m + __logf(sum);
+        const float inv = 1.0f / sum;
+
+        f32x4_t oacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NKT / 2; ++s2) {
+            Frag8 pf;
+            pf.u[0] = pack2bf(p[2 * s2][0], p[2 * s2][1]);
+            pf.u[1] = pack2bf(p[2 * s2][2], p[2 * s2][3]);
+            pf.u[2] = pack2bf(p[2 * s2 + 1][0], p[2 * s2 + 1][1]);
+            pf.u[3] = pack2bf(p[2 * s2 + 1][2], p[2 * s2 + 1][3]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                Frag8 vf;   // A[hd c*16+lr][kappa] = V[key(kappa)][hd]
+                vf.u2[0] = tr4(Vs, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
+                vf.u2[1] = tr4(Vs, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
+                oacc[c] = mfma16(vf, pf, oacc[c]);
+            }
+        }
+        if (qv) {
+            bf16_t* orow = o + qrow * G.g.ldo + h * HD + lg * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint2 w;
+                w.x = pack2bf(oacc[c][0] * inv, oacc[c][1] * inv);
+                w.y = pack2bf(oacc[c][2] * inv, oacc[c][3] * inv);
+                *reinterpret_cast<uint2*>(orow + c * 16) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- backward A: dQ, dbias, D
+template <int HD, int NKT>
+__global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
+    bf16_t* __restrict__ dq, float* __restrict__ dbias, float* __restrict__ dsum, Geom G) {
+    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + NK * LDR;
+    float* aux = reinterpret_cast<float*>(Vs + NK * LDR);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int N = G.g.N;
+
+    stage<HD, NK>(G, k, G.g.ldk, grp, h, Ks, tid);
+    stage<HD, NK>(G, v, G.g.ldv, grp, h, Vs, tid);
+    int* rid_s = reinterpret_cast<int*>(aux);
+    const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    for (int n = tid; n < NK; n += THREADS) {
+        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+    }
+    __syncthreads();
+
+    const int nqt = (N + 15) >> 4;
+    const int lg = lane >> 4, lr = lane & 15;
+    for (int qt = wave; qt < nqt; qt += WAVES) {
+        const int nq = qt * 16 + lr;
+        const bool qv = nq < N;
+        const int64_t qrow = qv ? tok_row(G, grp, nq) : 0;
+        Frag8 qf[KS], dof[KS], of[KS];
+        load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
+        load_frags<HD>(dof, dout + qrow * G.g.ldo + h * HD, qv, lane);
+        load_frags<HD>(of, o + qrow * G.g.ldo + h * HD, qv, lane);
+        float dsm = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsm += bf2f(dof[s].h[e]) * bf2f(of[s].h[e]);
+        dsm = grp4_sum(dsm);
+        const int64_t li = ((int64_t)grp * G.g.nH + h) * N + nq;
+        if (qv && lg == 0) dsum[li] = dsm;
+        const float L = qv ? lse[li] : 0.f;
+        const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        float* dbrow = (dbias && qv) ? dbias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        const int rq = (rid && qv) ? rid_s[nq] : 0;
+
+        Frag8 dsf[NKT / 2];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+            Frag8 kf[KS], vf[KS];
+            lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
+            lds_frags<HD>(vf, Vs + (t * 16 + lr) * LDR, lane);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                sacc = mfma16(kf[s], qf[s], sacc);
+                pacc = mfma16(vf[s], dof[s], pacc);
+            }
+            const int key0 = t * 16 + lg * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + r;
+                float s = sacc[r] * G.g.scale + bb[r];
+                if (rid) s += (rid_s[key] != rq) ? -100.0f : 0.0f;
+                else if (kmask) s += aux[key];
+                const float pr = (key < N && qv) ? __expf(s - L) : 0.f;
+                ds[r] = pr * (pacc[r] - dsm);
+                if (dbrow && key < N) atomicAdd(dbrow + key, ds[r]);
+            }
+            dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
+            dsf[t >> 1].u[(t & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
+        }
+        f32x4_t qacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NKT / 2; ++s2)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                Frag8 kf;   // A[hd c*16+lr][kappa] = K[key(kappa)][hd]
+                kf.u2[0] = tr4(Ks, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
+                kf.u2[1] = tr4(Ks, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
+                qacc[c] = mfma16(kf, dsf[s2], qacc[c]);
+            }
+        if (qv) {
+            bf16_t* drow = dq + qrow * G.g.ldq + h * HD + lg * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint2 w;
+                w.x = pack2bf(qacc[c][0] * G.g.scale, qacc[c][1] * G.g.scale);
+                w.y = pack2bf(qacc[c][2] * G.g.scale, qacc[c][3] * G.g.scale);
+                *reinterpret_cast<uint2*>(drow + c * 16) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- backward B: dK, dV
+template <int HD, int NKT>
+__global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
+    const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, Geom G) {
+    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dOs = Qs + NK * LDR;
+    float* L_s = reinterpret_cast<float*>(dOs + NK * LDR);
+    float* D_s = L_s + NK;
+    float* aux = D_s + NK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int N = G.g.N;
+
+    stage<HD, NK>(G, q, G.g.ldq, grp, h, Qs, tid);
+    stage<HD, NK>(G, dout, G.g.ldo, grp, h, dOs, tid);
+    int* rid_s = reinterpret_cast<int*>(aux);
+    const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    for (int n = tid; n < NK; n += THREADS) {
+        const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
+        L_s[n] = (n < N) ? lse[li] : 0.f;
+        D_s[n] = (n < N) ? dsum[li] : 0.f;
+        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+    }
+    __syncthreads();
+
+    const int nkt = (N + 15) >> 4;
+    const int lg = lane >> 4, lr = lane & 15;
+    for (int kt = wave; kt < nkt; kt += WAVES) {
+        const int nk = kt * 16 + lr;
+        const bool kv = nk < N;
+        const int64_t krow = kv ? tok_row(G, grp, nk) : 0;
+        Frag8 kf[KS], vf[KS];
+        load_frags<HD>(kf, k + krow * G.g.ldk + h * HD, kv, lane);
+        load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
+        const int rk = (rid && kv) ? rid_s[nk] : 0;
+        const float kmv = (!rid && kmask && kv) ? aux[nk] : 0.f;
+
+        f32x4_t dvacc[NC], dkacc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            dvacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dkacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int qp = 0; qp < NKT / 2; ++qp) {
+            Frag8 pf, dsf;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = qp * 2 + half;
+                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+                Frag8 qf[KS], dof[KS];
+                lds_frags<HD>(qf, Qs + (qt * 16 + lr) * LDR, lane);
+                lds_frags<HD>(dof, dOs + (qt * 16 + lr) * LDR, lane);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    sacc = mfma16(qf[s], kf[s], sacc);     // S[query (lg*4+r)][key lr]
+                    pacc = mfma16(dof[s], vf[s], pacc);    // dP same layout
+                }
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qn = qt * 16 + lg * 4 + r;
+                    float s = sacc[r] * G.g.scale;
+                    if (bias && kv && qn < N) s += bias[((int64_t)h * N + qn) * G.g.bias_ld + nk];
+                    if (rid) s += (rid_s[qn] != rk) ? -100.0f : 0.0f;
+                    else s += kmv;
+                    const float pr = (kv && qn < N) ? __expf(s - L_s[qn]) : 0.f;
+                    pv[r] = pr;
+                    dsv[r] = pr * (pacc[r] - D_s[qn]);
+                }
+                pf.u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
+                pf.u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
+                dsf.u[half * 2 + 0] = pack2bf(dsv[0], dsv[1]);
+                dsf.u[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                Frag8 a;   // A[hd c*16+lr][kappa] = dO[query(kappa)][hd]
+                a.u2[0] = tr4(dOs, LDR, (2 * qp) * 16 + lg * 4, c * 16, lr);
+                a.u2[1] = tr4(dOs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
+                dvacc[c] = mfma16(a, pf, dvacc[c]);        // dVᵀ[hd (lg*4+r)][key lr]
+                a.u2[0] = tr4(Qs, LDR, (2 * qp) * 16 + lg * 4, c * 16, lr);
+                a.u2[1] = tr4(Qs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
+                dkacc[c] = mfma16(a, dsf, dkacc[c]);
+            }
+        }
+        if (kv) {
+            bf16_t* dvrow = dv + krow * G.g.ldv + h * HD + lg * 4;
+            bf16_t* dkrow = dk + krow * G.g.ldk + h * HD + lg * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint2 w;
+                w.x = pack2bf(dvacc[c][0], dvacc[c][1]);
+                w.y = pack2bf(dvacc[c][2], dvacc[c][3]);
+                *reinterpret_cast<uint2*>(dvrow + c * 16) = w;
+                w.x = pack2bf(dkacc[c][0] * G.g.scale, dkacc[c][1] * G.g.scale);
+                w.y = pack2bf(dkacc[c][2] * G.g.scale, dkacc[c][3] * G.g.scale);
+                *reinterpret_cast<uint2*>(dkrow + c * 16) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- host side
+bool make_geom(const ClvAttnGeom* g, Geom& G) {
+    if (!g) return false;
+    G.g = *g;
+    G.nWh = G.nWw = G.nW = 1;
+    if (g->N <= 0 || g->nH <= 0 || g->groups <= 0) return false;
+    if (g->hd != 16 && g->hd != 32 && g->hd != 64) return false;
+    if ((g->ldq | g->ldk | g->ldv | g->ldo) & 7) return false;   // 16-byte row alignment
+    if (g->bias_ld & 15) return false;
+    if (g->mode == 1) {
+        if (g->wd <= 0 || g->wh <= 0 || g->ww <= 0) return false;
+        if (g->D % g->wd || g->H % g->wh || g->W % g->ww) return false;
+        if (g->N != g->wd * g->wh * g->ww) return false;
+        G.nWh = g->H / g->wh;
+        G.nWw = g->W / g->ww;
+        G.nW = (g->D / g->wd) * G.nWh * G.nWw;
+        if (g->groups % G.nW) return false;
+        if (g->sd < 0 || g->sd >= g->D || g->sh < 0 || g->sh >= g->H || g->sw < 0 || g->sw >= g->W) return false;
+    } else if (g->mode != 0) {
+        return false;
+    }
+    return true;
+}
+
+constexpr size_t MAX_LDS = 160 * 1024;
+
+template <int HD, int NKT>
+size_t fwd_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (size_t)NKT * 16 * 4; }
+template <int HD, int NKT>
+size_t dq_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (size_t)NKT * 16 * 4; }
+template <int HD, int NKT>
+size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
+
+template <int HD, int NKT>
+int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+               const int32_t* rid, const float* kmask, const Geom& G, hipStream_t st) {
+    const size_t lds = fwd_lds<HD, NKT>();
+    if (lds > MAX_LDS) return CLV_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int nblk = G.g.groups * G.g.nH;
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds, st,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, G);
+    return clv_check_launch();
+}
+
+template <int HD, int NKT>
+int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+               const float* lse, const float* bias, const int32_t* rid, const float* kmask, void* dq,
+               void* dk, void* dv, float* dbias, float* dsum, const Geom& G, hipStream_t st) {
+    const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
+    if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        attr = true;
+    }
+    const int nblk = G.g.groups * G.g.nH;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_a, st,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
+                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dbias, dsum, G);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_b, st,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse,
+                       dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, G);
+    return clv_check_launch();
+}
+
+// smallest instantiated key-tile count >= need
+int pick_nkt(int N) {
+    const int need = (N + 15) / 16;
+    const int opts[] = {2, 8, 14, 16, 28};
+    for (int o : opts) if (o >= need) return o;
+    return -1;
+}
+
+#define DISPATCH_NKT(HDV, FN, ...)                                   \
+    switch (nkt) {                                                   \
+        case 2: return FN<HDV, 2>(__VA_ARGS__);                      \
+        case 8: return FN<HDV, 8>(__VA_ARGS__);                      \
+        case 14: return FN<HDV, 14>(__VA_ARGS__);                    \
+        case 16: return FN<HDV, 16>(__VA_ARGS__);                    \
+        case 28: return FN<HDV, 28>(__VA_ARGS__);                    \
+        default: return CLV_ERR_UNSUPPORTED;                         \
+    }
+
+}  // namespace
+
+extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                            const float* bias, const int32_t* rid, const float* kmask,
+                            const ClvAttnGeom* geom, void* stream) {
+    Geom G;
+    if (!q || !k || !v || !o || !lse || !make_geom(geom, G)) return CLV_ERR_ARG;
+    if (bias && G.g.bias_ld < ((G.g.N + 15) / 16) * 16) return CLV_ERR_ARG;
+    if (rid && G.g.mode != 1) return CLV_ERR_ARG;
+    const int nkt = pick_nkt(G.g.N);
+    hipStream_t st = (hipStream_t)stream;
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st) }
+    DISPATCH_NKT(64, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st)
+}
+
+extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                            const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                            void* dq, void* dk, void* dv, float* dbias, float* dsum,
+                            const ClvAttnGeom* geom, void* stream) {
+    Geom G;
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
+    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias)) return CLV_ERR_ARG;
+    if (rid && G.g.mode != 1) return CLV_ERR_ARG;
+    const int nkt = pick_nkt(G.g.N);
+    hipStream_t st = (hipStream_t)stream;
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st)
+}

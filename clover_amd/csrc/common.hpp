@@ -1,0 +1,85 @@
+// Shared device helpers for the Clover HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CLV_OK 0
+#define CLV_ERR_ARG (-1)
+#define CLV_ERR_UNSUPPORTED (-2)
+#define CLV_ERR_LAUNCH (-3)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;  // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;     // 16x16 MFMA accumulator
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;   // 32x32 MFMA accumulator
+
+struct __attribute__((aligned(16))) u16x8 { uint16_t v[8]; };
+struct __attribute__((aligned(8))) u16x4 { uint16_t v[4]; };
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+union Frag8 {  // 8 bf16 = one MFMA 16x16x32 A/B operand
+    bf16x8_t v;
+    uint4 u4;
+    uint2 u2[2];
+    uint32_t u[4];
+    uint16_t h[8];
+};
+
+// D = A(16x32) * B(32x16) + C.  Lane l supplies A[row l&15][k (l>>4)*8..+8] and
+// B[k (l>>4)*8..+8][col l&15]; receives D[row (l>>4)*4+r][col l&15], r = 0..3.
+__device__ __forceinline__ f32x4_t mfma16(const Frag8& a, const Frag8& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over the 4 lane groups that share l&15 (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float grp4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float grp4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+// reduce over the 16 lanes that share l>>4
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+static inline int clv_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CLV_OK : CLV_ERR_LAUNCH;
+}

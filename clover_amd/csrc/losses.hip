@@ -1,0 +1,359 @@
+// Fused losses of the Clover pre-training step (fp32 math, as the reference's @force_fp32):
+//   * focal masked-LM cross entropy over the vocabulary (one pass over the logits);
+//   * exclusive tri-modal InfoNCE + margin ranking on the all-gathered embeddings
+//     (normalise -> f32-MFMA similarity GEMMs -> one-block loss -> analytic backward).
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+// =========================================================================== focal CE
+constexpr int FC_THREADS = 256;
+
+template <bool BF16>
+__device__ __forceinline__ float ld_logit(const void* p, int64_t i) {
+    if (BF16) return bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+    return reinterpret_cast<const float*>(p)[i];
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+    return r;
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(FC_THREADS) focal_fwd_kernel(
+    const void* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ row_ce,
+    float* __restrict__ row_lse, float* __restrict__ sum_acc, float* __restrict__ cnt_acc, int V, float gamma) {
+    __shared__ float sh[8];
+    const int64_t row = blockIdx.x;
+    const int64_t lab = labels[row];
+    if (lab < 0) {                       // label == -100: not a masked position
+        if (threadIdx.x == 0) { row_ce[row] = 0.f; row_lse[row] = 0.f; }
+        return;
+    }
+    const int64_t base = row * V;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += FC_THREADS) m = fmaxf(m, ld_logit<BF16>(logits, base + j));
+    m = block_reduce(m, sh, true);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < V; j += FC_THREADS) s += __expf(ld_logit<BF16>(logits, base + j) - m);
+    s = block_reduce(s, sh, false);
+    if (threadIdx.x == 0) {
+        const float lse = m + __logf(s);
+        const float ce = lse - ld_logit<BF16>(logits, base + lab);
+        const float pt = __expf(-ce);
+        row_ce[row] = ce;
+        row_lse[row] = lse;
+        atomicAdd(sum_acc, powf(1.f - pt, gamma) * ce);
+        atomicAdd(cnt_acc, 1.0f);
+    }
+}
+
+__global__ void focal_finish_kernel(float* __restrict__ loss, const float* __restrict__ count) {
+    loss[0] = loss[0] / count[0];        // mean over the masked rows (NaN when there are none, as torch)
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(FC_THREADS) focal_bwd_kernel(
+    const void* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ row_ce,
+    const float* __restrict__ row_lse, const float* __restrict__ count, const float* __restrict__ dloss,
+    void* __restrict__ dlogits, int V, float gamma) {
+    const int64_t row = blockIdx.x;
+    const int64_t lab = labels[row];
+    const int64_t base = row * V;
+    float coef = 0.f, lse = 0.f;
+    if (lab >= 0) {
+        const float ce = row_ce[row], pt = __expf(-ce), om = 1.f - pt;
+        // d/dce [(1-pt)^g * ce] = g (1-pt)^(g-1) pt ce + (1-pt)^g
+        const float dl = (gamma == 0.f) ? 1.f : gamma * powf(om, gamma - 1.f) * pt * ce + powf(om, gamma);
+        coef = dloss[0] * dl / count[0];
+        lse = row_lse[row];
+    }
+    for (int j = threadIdx.x; j < V; j += FC_THREADS) {
+        float g = 0.f;
+        if (lab >= 0) {
+            const float p = __expf(ld_logit<BF16>(logits, base + j) - lse);
+            g = coef * (p - (j == lab ? 1.f : 0.f));
+        }
+        if (BF16) reinterpret_cast<bf16_t*>(dlogits)[base + j] = f2bf(g);
+        else reinterpret_cast<float*>(dlogits)[base + j] = g;
+    }
+}
+
+// =========================================================================== InfoNCE
+// work layout (floats):
+//   en   [4][G][Dm]   normalised embeddings
+//   enT  [Dm][4][G]   their transpose (contraction index (k, j) contiguous)
+//   invn [4][G]       1/max(|e|, eps)
+//   sim  [3][G][G]    en0 . en_{k+1}^T / temperature
+//   lser [3][G]       row log-sum-exp of the three exclusive [G,3G] rows
+//   lsec [3][G]       column log-sum-exp (t2v)
+//   dsim [G][3][G]    d loss / d sim, row-major in (i, k, j)
+//   dsimT[3][G][G]    transposed per block: [k][j][i]
+//   den  [4][G][Dm]   d loss / d normalised embeddings
+//   acc  [2]
+struct NceWork {
+    float *en, *enT, *invn, *sim, *lser, *lsec, *dsim, *dsimT, *den, *acc;
+};
+__host__ __device__ inline int64_t nce_work_floats(int G, int Dm) {
+    return (int64_t)4 * G * Dm * 3 + (int64_t)4 * G + (int64_t)3 * G * G * 3 + (int64_t)6 * G + 16;
+}
+__host__ __device__ inline NceWork nce_carve(float* w, int G, int Dm) {
+    NceWork W;
+    W.en = w; w += (int64_t)4 * G * Dm;
+    W.enT = w; w += (int64_t)4 * G * Dm;
+    W.den = w; w += (int64_t)4 * G * Dm;
+    W.invn = w; w += 4 * G;
+    W.sim = w; w += (int64_t)3 * G * G;
+    W.dsim = w; w += (int64_t)3 * G * G;
+    W.dsimT = w; w += (int64_t)3 * G * G;
+    W.lser = w; w += 3 * G;
+    W.lsec = w; w += 3 * G;
+    W.acc = w;
+    return W;
+}
+
+// one wave per row: en = e / max(|e|, 1e-8)   (cos_norm, contrastive_loss.py:20-25)
+__global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, const float* e1, const float* e2,
+                                                            const float* e3, NceWork W, int G, int Dm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 4 * G) return;
+    const int k = row / G, i = row - k * G;
+    const float* e = (k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3) + (int64_t)i * Dm;
+    float s = 0.f;
+    for (int d = lane; d < Dm; d += 64) s += e[d] * e[d];
+    const float nrm = sqrtf(wave_sum(s));
+    const float inv = 1.0f / fmaxf(nrm, 1e-8f);
+    if (lane == 0) W.invn[row] = inv;
+    for (int d = lane; d < Dm; d += 64) {
+        const float v = e[d] * inv;
+        W.en[(int64_t)row * Dm + d] = v;
+        W.enT[((int64_t)d * 4 + k) * G + i] = v;
+    }
+}
+
+// C[i][j] (ldc) = alpha * sum_k A[i][k] * B[j][k]   — exact-f32 MFMA 16x16x4, one wave per
+// 16x16 tile.  K multiple of 16 is NOT required (tail guarded); rows/cols guarded.
+__global__ void __launch_bounds__(64) sgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                      int ldc, int64_t sA, int64_t sB, int64_t sC, float alpha) {
+    const int lane = threadIdx.x, lg = lane >> 4, lr = lane & 15;
+    A += sA * blockIdx.z;
+    B += sB * blockIdx.z;
+    C += sC * blockIdx.z;
+    const int i = blockIdx.y * 16 + lr, j = blockIdx.x * 16 + lr;
+    const float* ap = A + (int64_t)(i < M ? i : 0) * lda;
+    const float* bp = B + (int64_t)(j < N ? j : 0) * ldb;
+    const bool av = i < M, bv = j < N;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + lg * 4 + e;
+            a[e] = (av && k < K) ? ap[k] : 0.f;
+            b[e] = (bv && k < K) ? bp[k] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    // acc[r] = C[row blockIdx.y*16 + lg*4 + r][col blockIdx.x*16 + lr]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ci = blockIdx.y * 16 + lg * 4 + r;
+        if (ci < M && j < N) C[(int64_t)ci * ldc + j] = alpha * acc[r];
+    }
+}
+
+__device__ __forceinline__ float nce_entry(const float* sim, int G, int kx, int i, int k, int j) {
+    // value of column (k, j) in the exclusive row of variant kx for sample i
+    // (contrastive_loss.py:130-132: other blocks' diagonals become x - (x + 10000))
+    const float x = sim[((int64_t)k * G + i) * G + j];
+    if (k != kx && j == i) return x - (x + 10000.f);
+    return x;
+}
+
+// single block: all log-sum-exps, the two losses.
+__global__ void __launch_bounds__(1024) nce_loss_kernel(NceWork W, float* __restrict__ out, int G, float margin) {
+    __shared__ float sh[16];
+    const float* sim = W.sim;
+    float part_v = 0.f, part_t = 0.f, part_r = 0.f;
+    // 3G exclusive rows + 3G columns, one thread each (G <= 512 in practice: 3G*G work per thread is tiny)
+    for (int t = threadIdx.x; t < 6 * G; t += blockDim.x) {
+        if (t < 3 * G) {
+            const int kx = t / G, i = t - kx * G;
+            float m = -INFINITY;
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < G; ++j) m = fmaxf(m, nce_entry(sim, G, kx, i, k, j));
+            float s = 0.f;
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < G; ++j) s += __expf(nce_entry(sim, G, kx, i, k, j) - m);
+            const float lse = m + __logf(s);
+            W.lser[t] = lse;
+            part_v += sim[((int64_t)kx * G + i) * G + i] - lse;          // diag of the own block
+        } else {
+            const int u = t - 3 * G, k = u / G, j = u - k * G;
+            float m = -INFINITY;
+            for (int i = 0; i < G; ++i) m = fmaxf(m, sim[((int64_t)k * G + i) * G + j]);
+            float s = 0.f;
+            for (int i = 0; i < G; ++i) s += __expf(sim[((int64_t)k * G + i) * G + j] - m);
+            const float lse = m + __logf(s);
+            W.lsec[u] = lse;
+            part_t += sim[((int64_t)k * G + j) * G + j] - lse;
+        }
+    }
+    for (int i = threadIdx.x; i < G; i += blockDim.x) {
+        const float a = sim[((int64_t)0 * G + i) * G + i], b = sim[((int64_t)1 * G + i) * G + i];
+        part_r += fmaxf(0.f, -(a - b) + margin);
+    }
+    const float sv = block_reduce(part_v, sh, false);
+    const float stt = block_reduce(part_t, sh, false);
+    const float sr = block_reduce(part_r, sh, false);
+    if (threadIdx.x == 0) {
+        const float loss_v = -(sv / (float)G);
+        const float loss_t = -(stt / (float)(3 * G));
+        out[0] = loss_v + loss_t;
+        out[1] = sr / (float)G;
+    }
+}
+
+// elementwise: d loss / d sim[k][i][j]
+__global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* __restrict__ dout, int G, float margin) {
+    const int64_t total = (int64_t)3 * G * G;
+    const float gn = dout[0], gr = dout[1];
+    const float invG = 1.0f / (float)G, inv3G = 1.0f / (float)(3 * G);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / ((int64_t)G * G));
+        const int rem = (int)(idx - (int64_t)k * G * G);
+        const int i = rem / G, j = rem - i * G;
+        const float x = W.sim[idx];
+        float g = 0.f;
+        // v2t: three exclusive rows of sample i
+        for (int kx = 0; kx < 3; ++kx) {
+            if (k != kx && j == i) continue;                    // excluded entry: x-(x+1e4) has zero slope
+            const float p = __expf(x - W.lser[kx * G + i]);
+            g += -invG * gn * ((k == kx && j == i ? 1.f : 0.f) - p);
+        }
+        // t2v: column softmax over i
+        g += -inv3G * gn * ((i == j ? 1.f : 0.f) - __expf(x - W.lsec[k * G + j]));
+        // ranking: mean_i max(0, margin - (vt_ii - vtm_ii))
+        if (i == j && k < 2) {
+            const float a = W.sim[((int64_t)0 * G + i) * G + i], b = W.sim[((int64_t)1 * G + i) * G + i];
+            if (-(a - b) + margin > 0.f) g += (k == 0 ? -1.f : 1.f) * invG * gr;
+        }
+        W.dsim[((int64_t)i * 3 + k) * G + j] = g;
+        W.dsimT[((int64_t)k * G + j) * G + i] = g;
+    }
+}
+
+// d e = invn * (d en - en * <en, d en>)   (valid while |e| >= eps; below eps: d e = d en * invn)
+__global__ void __launch_bounds__(256) nce_norm_bwd_kernel(NceWork W, float* d0, float* d1, float* d2, float* d3,
+                                                           int G, int Dm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 4 * G) return;
+    const int k = row / G, i = row - k * G;
+    float* d = (k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3) + (int64_t)i * Dm;
+    const float* en = W.en + (int64_t)row * Dm;
+    const float* de = W.den + (int64_t)row * Dm;
+    float s = 0.f;
+    for (int c = lane; c < Dm; c += 64) s += en[c] * de[c];
+    s = wave_sum(s);
+    const float inv = W.invn[row];
+    const bool clamped = inv >= 1e8f;
+    for (int c = lane; c < Dm; c += 64) d[c] = clamped ? de[c] * inv : inv * (de[c] - en[c] * s);
+}
+
+}  // namespace
+
+extern "C" int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
+                                float* row_lse, float* loss, float* count, int64_t rows, int32_t V, float gamma,
+                                void* stream) {
+    if (!logits || !labels || !row_ce || !row_lse || !loss || !count || rows <= 0 || V <= 0) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // (loss, count) double as the {sum, count} accumulators; normalised in place by the finish kernel
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return CLV_ERR_LAUNCH;
+    if (hipMemsetAsync(count, 0, sizeof(float), st) != hipSuccess) return CLV_ERR_LAUNCH;
+    if (is_bf16)
+        hipLaunchKernelGGL((focal_fwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, loss, count, (int)V, gamma);
+    else
+        hipLaunchKernelGGL((focal_fwd_kernel<false>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, loss, count, (int)V, gamma);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(1), 0, st, loss, (const float*)count);
+    return clv_check_launch();
+}
+
+extern "C" int clv_focal_ce_bwd(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
+                                const float* row_lse, const float* count, const float* dloss, void* dlogits,
+                                int64_t rows, int32_t V, float gamma, void* stream) {
+    if (!logits || !labels || !row_ce || !row_lse || !count || !dloss || !dlogits || rows <= 0 || V <= 0)
+        return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16)
+        hipLaunchKernelGGL((focal_bwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, count, dloss, dlogits, (int)V, gamma);
+    else
+        hipLaunchKernelGGL((focal_bwd_kernel<false>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, count, dloss, dlogits, (int)V, gamma);
+    return clv_check_launch();
+}
+
+extern "C" int64_t clv_infonce_work_floats(int32_t G, int32_t Dm) { return nce_work_floats(G, Dm); }
+
+static int nce_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st) {
+    hipLaunchKernelGGL(sgemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16, batch), dim3(64), 0, st, A, B, C, M, N, K,
+                       lda, ldb, ldc, sA, sB, sC, alpha);
+    return clv_check_launch();
+}
+
+extern "C" int clv_infonce_fwd(const float* e0, const float* e1, const float* e2, const float* e3, float* out,
+                               float* work, int32_t G, int32_t Dm, float temperature, float margin, void* stream) {
+    if (!e0 || !e1 || !e2 || !e3 || !out || !work || G <= 0 || Dm <= 0 || temperature <= 0.f) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NceWork W = nce_carve(work, G, Dm);
+    hipLaunchKernelGGL(nce_normalize_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, e0, e1, e2, e3, W, (int)G, (int)Dm);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    // sim[k] = en0 . en_{k+1}^T / temperature
+    rc = nce_gemm(W.en, W.en + (int64_t)G * Dm, W.sim, G, G, Dm, Dm, Dm, G, 3, 0, (int64_t)G * Dm, (int64_t)G * G,
+                  1.0f / temperature, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(1024), 0, st, W, out, (int)G, margin);
+    return clv_check_launch();
+}
+
+extern "C" int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const float* e3, const float* dout,
+                               const float* work, float* d0, float* d1, float* d2, float* d3, int32_t G, int32_t Dm,
+                               float temperature, float margin, void* stream) {
+    if (!e0 || !e1 || !e2 || !e3 || !dout || !work || !d0 || !d1 || !d2 || !d3 || G <= 0 || Dm <= 0) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NceWork W = nce_carve(const_cast<float*>(work), G, Dm);
+    int64_t total = (int64_t)3 * G * G;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(nce_dsim_kernel, dim3(grid), dim3(256), 0, st, W, dout, (int)G, margin);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    const float it = 1.0f / temperature;
+    // d en0[i][d] = sum_{k,j} dsim[i][(k,j)] * en_{k+1}[j][d] / T :  A = dsim [G][3G], B = enT[d][(k+1, j)]
+    rc = nce_gemm(W.dsim, W.enT + G, W.den, G, Dm, 3 * G, 3 * G, 4 * G, Dm, 1, 0, 0, 0, it, st);
+    if (rc) return rc;
+    // d en_{k+1}[j][d] = sum_i dsimT[k][j][i] * en0[i][d] / T   :  A = dsimT[k] [G][G], B = enT[d][(0, i)]
+    rc = nce_gemm(W.dsimT, W.enT, W.den + (int64_t)G * Dm, G, Dm, G, G, 4 * G, Dm, 3, (int64_t)G * G, 0,
+                  (int64_t)G * Dm, it, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_norm_bwd_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, W, d0, d1, d2, d3, (int)G, (int)Dm);
+    return clv_check_launch();
+}

@@ -1,0 +1,355 @@
+// LayerNorm (fwd/bwd, optional fused residual input) and erf-GELU (fwd/bwd), bf16 I/O,
+// fp32 statistics.  HBM-bound: one wave per row, 4-byte (bf16x2) lane accesses, the row
+// lives in registers between the two statistics passes.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / 64;
+
+// element pair load/store for the two I/O types (bf16 storage or fp32 storage)
+template <typename T> struct IO;
+template <> struct IO<bf16_t> {
+    static __device__ __forceinline__ void ld2(const bf16_t* p, float& a, float& b) {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+        a = bf2f((bf16_t)(u & 0xffff));
+        b = bf2f((bf16_t)(u >> 16));
+    }
+    static __device__ __forceinline__ void st2(bf16_t* p, float a, float b) {
+        *reinterpret_cast<uint32_t*>(p) = pack2bf(a, b);
+    }
+};
+template <> struct IO<float> {
+    static __device__ __forceinline__ void ld2(const float* p, float& a, float& b) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        a = v.x;
+        b = v.y;
+    }
+    static __device__ __forceinline__ void st2(float* p, float a, float b) {
+        *reinterpret_cast<float2*>(p) = make_float2(a, b);
+    }
+};
+
+template <int ITERS, typename T>
+__device__ __forceinline__ void ln_load_row(float (&xv)[ITERS * 2], const T* x, const T* res, int C, int lane) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = i * 128 + lane * 2;
+        float a = 0.f, b = 0.f;
+        if (c < C) {
+            IO<T>::ld2(x + c, a, b);
+            if (res) {
+                float ra, rb;
+                IO<T>::ld2(res + c, ra, rb);
+                a += ra;
+                b += rb;
+            }
+        }
+        xv[2 * i] = a;
+        xv[2 * i + 1] = b;
+    }
+}
+
+template <int ITERS, typename T>
+__global__ void __launch_bounds__(LN_THREADS) ln_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+    const float invC = 1.0f / (float)C;
+    float g[ITERS * 2], b[ITERS * 2];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = i * 128 + lane * 2;
+        const bool ok = c < C;
+        g[2 * i] = ok ? gamma[c] : 0.f;
+        g[2 * i + 1] = ok ? gamma[c + 1] : 0.f;
+        b[2 * i] = ok ? beta[c] : 0.f;
+        b[2 * i + 1] = ok ? beta[c + 1] : 0.f;
+    }
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        float xv[ITERS * 2];
+        ln_load_row<ITERS, T>(xv, x + row * C, res ? res + row * C : nullptr, C, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS * 2; ++i) s += xv[i];
+        const float mu = wave_sum(s) * invC;
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = i * 128 + lane * 2;
+            if (c < C) {
+                const float d0 = xv[2 * i] - mu, d1 = xv[2 * i + 1] - mu;
+                vs += d0 * d0 + d1 * d1;
+            }
+        }
+        const float rs = rsqrtf(wave_sum(vs) * invC + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = i * 128 + lane * 2;
+            if (c < C) {
+                const float o0 = (xv[2 * i] - mu) * rs * g[2 * i] + b[2 * i];
+                const float o1 = (xv[2 * i + 1] - mu) * rs * g[2 * i + 1] + b[2 * i + 1];
+                IO<T>::st2(y + row * C + c, o0, o1);
+            }
+        }
+    }
+}
+
+template <int ITERS, typename T>
+__global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
+    __shared__ float red[ITERS * 128 * 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+    const float invC = 1.0f / (float)C;
+    float g[ITERS * 2], dg[ITERS * 2], db[ITERS * 2];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = i * 128 + lane * 2;
+        const bool ok = c < C;
+        g[2 * i] = ok ? gamma[c] : 0.f;
+        g[2 * i + 1] = ok ? gamma[c + 1] : 0.f;
+        dg[2 * i] = dg[2 * i + 1] = db[2 * i] = db[2 * i + 1] = 0.f;
+    }
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        float xv[ITERS * 2], dv[ITERS * 2];
+        ln_load_row<ITERS, T>(xv, x + row * C, res ? res + row * C : nullptr, C, lane);
+        ln_load_row<ITERS, T>(dv, dy + row * C, (const T*)nullptr, C, lane);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS * 2; ++i) {
+            const int c = (i >> 1) * 128 + lane * 2;
+            const float xh = (c < C) ? (xv[i] - mu) * rs : 0.f;
+            xv[i] = xh;
+            const float gd = g[i] * dv[i];
+            s1 += gd;
+            s2 += gd * xh;
+            dg[i] += dv[i] * xh;
+            db[i] += dv[i];
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = i * 128 + lane * 2;
+            if (c < C) {
+                const float o0 = rs * (g[2 * i] * dv[2 * i] - s1 - xv[2 * i] * s2);
+                const float o1 = rs * (g[2 * i + 1] * dv[2 * i + 1] - s1 - xv[2 * i + 1] * s2);
+                IO<T>::st2(dx + row * C + c, o0, o1);
+            }
+        }
+    }
+    // block reduce dgamma/dbeta over the 4 waves (one shared row, waves take turns), then
+    // write one partial row per block
+    for (int w = 0; w < LN_WAVES; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int c = i * 128 + lane * 2;
+                if (w == 0) {
+                    red[c] = dg[2 * i];
+                    red[c + 1] = dg[2 * i + 1];
+                    red[ITERS * 128 + c] = db[2 * i];
+                    red[ITERS * 128 + c + 1] = db[2 * i + 1];
+                } else {
+                    red[c] += dg[2 * i];
+                    red[c + 1] += dg[2 * i + 1];
+                    red[ITERS * 128 + c] += db[2 * i];
+                    red[ITERS * 128 + c + 1] += db[2 * i + 1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int nblk = gridDim.x;
+    for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+        partial[(int64_t)blockIdx.x * C + c] = red[c];
+        partial[((int64_t)nblk + blockIdx.x) * C + c] = red[ITERS * 128 + c];
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nblk; ++i) {
+        a += partial[(int64_t)i * C + c];
+        b += partial[((int64_t)nblk + i) * C + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+int ln_iters(int C) {
+    const int need = (C + 127) / 128;
+    const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int o : opts) if (o >= need) return o;
+    return -1;
+}
+
+int ln_fwd_blocks(int64_t rows) {
+    int64_t b = (rows + LN_WAVES - 1) / LN_WAVES;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define LN_CASE(N, KERNEL, TY, GRID, ...) \
+    case N: hipLaunchKernelGGL((KERNEL<N, TY>), dim3(GRID), dim3(LN_THREADS), 0, st, __VA_ARGS__); break;
+#define LN_DISPATCH(IT, KERNEL, TY, GRID, ...)                                          \
+    switch (IT) {                                                                        \
+        LN_CASE(1, KERNEL, TY, GRID, __VA_ARGS__) LN_CASE(2, KERNEL, TY, GRID, __VA_ARGS__) \
+        LN_CASE(3, KERNEL, TY, GRID, __VA_ARGS__) LN_CASE(4, KERNEL, TY, GRID, __VA_ARGS__) \
+        LN_CASE(6, KERNEL, TY, GRID, __VA_ARGS__) LN_CASE(8, KERNEL, TY, GRID, __VA_ARGS__) \
+        LN_CASE(12, KERNEL, TY, GRID, __VA_ARGS__) LN_CASE(16, KERNEL, TY, GRID, __VA_ARGS__) \
+        LN_CASE(24, KERNEL, TY, GRID, __VA_ARGS__) LN_CASE(32, KERNEL, TY, GRID, __VA_ARGS__) \
+        default: return CLV_ERR_UNSUPPORTED;                                             \
+    }
+
+// --------------------------------------------------------------------------- GELU
+__global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        Frag8 a, o;
+        a.u4 = *reinterpret_cast<const uint4*>(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o.u[e] = pack2bf(gelu_erf(bf2f(a.h[2 * e])), gelu_erf(bf2f(a.h[2 * e + 1])));
+        *reinterpret_cast<uint4*>(y + i * 8) = o.u4;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) {
+        const int64_t i = n8 * 8 + threadIdx.x;
+        y[i] = f2bf(gelu_erf(bf2f(x[i])));
+    }
+}
+
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                bf16_t* __restrict__ dx, int64_t n8, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        Frag8 a, d, o;
+        a.u4 = *reinterpret_cast<const uint4*>(x + i * 8);
+        d.u4 = *reinterpret_cast<const uint4*>(dy + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o.u[e] = pack2bf(bf2f(d.h[2 * e]) * gelu_erf_grad(bf2f(a.h[2 * e])),
+                             bf2f(d.h[2 * e + 1]) * gelu_erf_grad(bf2f(a.h[2 * e + 1])));
+        *reinterpret_cast<uint4*>(dx + i * 8) = o.u4;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) {
+        const int64_t i = n8 * 8 + threadIdx.x;
+        dx[i] = f2bf(bf2f(dy[i]) * gelu_erf_grad(bf2f(x[i])));
+    }
+}
+
+__global__ void gelu_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = gelu_erf(x[i]);
+}
+__global__ void gelu_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                    float* __restrict__ dx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dx[i] = dy[i] * gelu_erf_grad(x[i]);
+}
+
+int ew_blocks(int64_t n8) {
+    int64_t b = (n8 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                                 void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                                 int32_t is_f32, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || C <= 0 || (C & 1)) return CLV_ERR_ARG;
+    if (rows == 0) return CLV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int it = ln_iters(C);
+    const int grid = ln_fwd_blocks(rows);
+    if (is_f32) {
+        LN_DISPATCH(it, ln_fwd_kernel, float, grid, (const float*)x, (const float*)res, gamma, beta, (float*)y,
+                    mean, rstd, rows, (int)C, eps)
+    } else {
+        LN_DISPATCH(it, ln_fwd_kernel, bf16_t, grid, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
+                    (bf16_t*)y, mean, rstd, rows, (int)C, eps)
+    }
+    return clv_check_launch();
+}
+
+extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
+    (void)C;
+    int64_t b = (rows + LN_WAVES * 4 - 1) / (LN_WAVES * 4);
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
+                                 const float* mean, const float* rstd, void* dx, float* dgamma,
+                                 float* dbeta, float* partial, int64_t rows, int32_t C, int32_t is_f32,
+                                 void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows <= 0 || C <= 0 ||
+        (C & 1))
+        return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int it = ln_iters(C);
+    const int grid = clv_layernorm_bwd_blocks(rows, C);
+    if (is_f32) {
+        LN_DISPATCH(it, ln_bwd_kernel, float, grid, (const float*)dy, (const float*)x, (const float*)res, gamma,
+                    mean, rstd, (float*)dx, partial, rows, (int)C)
+    } else {
+        LN_DISPATCH(it, ln_bwd_kernel, bf16_t, grid, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)res,
+                    gamma, mean, rstd, (bf16_t*)dx, partial, rows, (int)C)
+    }
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, dgamma, dbeta,
+                       grid, (int)C);
+    return clv_check_launch();
+}
+
+extern "C" int clv_gelu_fwd(const void* x, void* y, int64_t n, int32_t is_f32, void* stream) {
+    if (!x || !y || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if (is_f32) {
+        hipLaunchKernelGGL(gelu_fwd_f32_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, n);
+        return clv_check_launch();
+    }
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, n8, n);
+    return clv_check_launch();
+}
+
+extern "C" int clv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t is_f32, void* stream) {
+    if (!dy || !x || !dx || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if (is_f32) {
+        hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dy, (const float*)x, (float*)dx, n);
+        return clv_check_launch();
+    }
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n8, n);
+    return clv_check_launch();
+}

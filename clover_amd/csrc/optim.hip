@@ -1,0 +1,115 @@
+// Optimizer step on flat fp32 buffers: global grad-norm (sum of squares) and a fused
+// clip + AdamW update that also refreshes the bf16 compute copy of the weights.
+// Pure HBM streaming: 16 B per lane, grid-stride.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
+    __shared__ float sh[4];
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+        const float v = g[n4 * 4 + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+struct AdamArgs {
+    float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, max_norm, grad_scale;
+};
+
+__device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
+    g *= coef;
+    p *= (1.f - a.lr * a.wd);
+    m = a.beta1 * m + (1.f - a.beta1) * g;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p -= (a.lr / a.bc1) * (m / denom);
+    return p;
+}
+
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ shadow, const float* __restrict__ sumsq,
+                                                    int64_t n, AdamArgs a) {
+    float coef = a.grad_scale;
+    if (sumsq) {
+        const float ss = sumsq[0] * a.grad_scale * a.grad_scale;
+        if (!(ss == ss) || ss > 3.0e38f) return;               // non-finite grad norm: skip the step
+        if (a.max_norm > 0.f) {
+            const float c = a.max_norm / (sqrtf(ss) + 1e-6f);  // clip_grad_norm_
+            coef *= fminf(c, 1.0f);
+        }
+    }
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pv.x, gv.x, mv.x, vv.x, a, coef);
+        adam_one(pv.y, gv.y, mv.y, vv.y, a, coef);
+        adam_one(pv.z, gv.z, mv.z, vv.z, a, coef);
+        adam_one(pv.w, gv.w, mv.w, vv.w, a, coef);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (shadow) {
+            uint2 o;
+            o.x = pack2bf(pv.x, pv.y);
+            o.y = pack2bf(pv.z, pv.w);
+            reinterpret_cast<uint2*>(shadow)[i] = o;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float pv = p[i], mv = m[i], vv = v[i];
+        adam_one(pv, g[i], mv, vv, a, coef);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+        if (shadow) shadow[i] = f2bf(pv);
+    }
+}
+
+int grid_for(int64_t n4) {
+    int64_t b = (n4 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int clv_abi_version(void) { return CLV_ABI_VERSION; }
+
+extern "C" int clv_sumsq(const float* g, float* acc, int64_t n, void* stream) {
+    if (!g || !acc || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if (((uintptr_t)g) & 15) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, acc, n);
+    return clv_check_launch();
+}
+
+extern "C" int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const float* sumsq,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float bias_c1, float bias_c2, float max_norm, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || bias_c1 <= 0.f || bias_c2 <= 0.f) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CLV_ERR_ARG;
+    if (shadow && (((uintptr_t)shadow) & 7)) return CLV_ERR_ARG;
+    AdamArgs a{lr, beta1, beta2, eps, weight_decay, bias_c1, sqrtf(bias_c2), max_norm, grad_scale};
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (bf16_t*)shadow, sumsq, n, a);
+    return clv_check_launch();
+}

@@ -1,0 +1,195 @@
+"""Data-parallel training engine for the Clover pre-training step on MI355X.
+
+What the reference spreads over MMDistributedDataParallel (tools/train.py:146-154), mmcv's
+DefaultOptimizerConstructor + AdamW (pretrain_webvid_cc3m.py:129-137), Fp16OptimizerHook
+(mmcv_Fp16OptimizerHook.py:96-149) and the CosineAnnealing LR hook (:139-140) is one object:
+
+* one process per GPU; parameters, gradients and Adam moments live in FLAT fp32 buffers
+  (decay / no-decay segments), so the gradient exchange is a handful of large RCCL
+  all-reduces over xGMI instead of per-tensor traffic, launched from autograd hooks as soon
+  as a bucket is complete (overlapping the rest of backward), and exactly once per step —
+  the reference all-reduces twice (DDP reducer + allreduce_grads);
+* gradient averaging (the 1/W that gives the reference's R6 behaviour), global-norm clipping
+  (max_norm 15) and AdamW run as two HIP kernels per segment (clv_sumsq, clv_adamw_step) with
+  no host synchronisation — the reference syncs the host once per parameter for its overflow
+  check (fp16_utils.py:328-349); bf16 needs no loss scaling, non-finite norms skip the step;
+* statically unused parameters (BERT pooler, the fusion model's own embeddings — the reason
+  the reference needs find_unused_parameters=True) are detected on a dry run and excluded.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+
+def paramwise_weight_decay(model, base_wd, norm_decay_mult=0.0, bias_decay_mult=0.0, custom_keys=None):
+    """mmcv DefaultOptimizerConstructor rules: custom_keys by substring
+    (longest first) > norm layers > bias > default.  Returns {param_name: weight_decay}."""
+    custom_keys = custom_keys or {}
+    sorted_keys = sorted(sorted(custom_keys.keys()), key=len, reverse=True)
+    norm_types = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.GroupNorm, nn.LayerNorm)
+    out = {}
+    for mod_name, mod in model.named_modules():
+        for pname, p in mod.named_parameters(recurse=False):
+            full = f'{mod_name}.{pname}' if mod_name else pname
+            wd = base_wd
+            hit = False
+            for key in sorted_keys:
+                if key in full:
+                    wd = base_wd * custom_keys[key].get('decay_mult', 1.0)
+                    hit = True
+                    break
+            if not hit:
+                if isinstance(mod, norm_types):
+                    wd = base_wd * norm_decay_mult
+                elif pname == 'bias':
+                    wd = base_wd * bias_decay_mult
+            out[full] = wd
+    return out
+
+
+def cosine_lr(base_lr, it, max_iters, min_lr_ratio=1e-3, warmup_iters=0, warmup_ratio=1e-3):
+    """mmcv CosineAnnealing (by_epoch=False) with linear warm-up."""
+    end = base_lr * min_lr_ratio
+    lr = end + 0.5 * (base_lr - end) * (1 + math.cos(math.pi * min(it, max_iters) / max(1, max_iters)))
+    if it < warmup_iters:
+        k = (1 - it / warmup_iters) * (1 - warmup_ratio)
+        lr = lr * (1 - k)
+    return lr
+
+
+class _Segment:
+    """A flat fp32 slab: params / grads / exp_avg / exp_avg_sq of one weight-decay class."""
+
+    def __init__(self, named_params, weight_decay, device):
+        self.weight_decay = weight_decay
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]          # 16-byte aligned slots
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.flat_p = torch.zeros(n, device=device, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=device, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=device, dtype=torch.float32)
+        for p, off in zip(self.params, self.offsets):
+            view = self.flat_p[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+
+
+class CloverEngine:
+    def __init__(self, model, sample_batch, lr=5e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.005,
+                 paramwise_cfg=None, grad_clip=15.0, max_iters=100000, warmup_iters=0, min_lr_ratio=1e-3,
+                 warmup_ratio=1e-3, bucket_mb=64):
+        self.model = model
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.base_lr, self.betas, self.eps = lr, betas, eps
+        self.grad_clip = grad_clip
+        self.max_iters, self.warmup_iters = max_iters, warmup_iters
+        self.min_lr_ratio, self.warmup_ratio = min_lr_ratio, warmup_ratio
+        self.step_count = 0
+        device = next(model.parameters()).device
+        pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
+                                   custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
+                                                'relative_position_bias_table': dict(decay_mult=0.)})
+        wd_map = paramwise_weight_decay(model, weight_decay, pw.get('norm_decay_mult', 1.0),
+                                        pw.get('bias_decay_mult', 1.0), pw.get('custom_keys'))
+
+        # ---- dry run: which parameters does the step graph actually reach?
+        model.zero_grad(set_to_none=True)
+        out = model.train_step(sample_batch, None)
+        out['loss'].backward()
+        used = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+        self.unused_names = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+        model.zero_grad(set_to_none=True)
+
+        # reverse registration order ~ order in which backward produces the gradients
+        used = list(reversed(used))
+        decay = [(n, p) for n, p in used if wd_map[n] > 0]
+        no_decay = [(n, p) for n, p in used if wd_map[n] == 0]
+        self.segments = [s for s in (_Segment(decay, weight_decay, device) if decay else None,
+                                     _Segment(no_decay, 0.0, device) if no_decay else None) if s is not None]
+        self.sumsq = torch.zeros(1, device=device, dtype=torch.float32)
+        self.num_params = sum(p.numel() for _, p in used)
+
+        # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
+        self._buckets = []          # (segment, start, end, n_params)
+        self._pending = []
+        self._handles = []
+        if self.world > 1:
+            cap = bucket_mb * 1024 * 1024 // 4
+            for seg in self.segments:
+                start, count = 0, 0
+                for i, p in enumerate(seg.params):
+                    count += 1
+                    end = seg.offsets[i + 1]
+                    if end - start >= cap or i == len(seg.params) - 1:
+                        self._buckets.append([seg, start, end, count])
+                        b = len(self._buckets) - 1
+                        for q in seg.params[i + 1 - count:i + 1]:
+                            q.register_post_accumulate_grad_hook(self._make_hook(b))
+                        start, count = end, 0
+            self._reset_pending()
+            self.comm_stream = torch.cuda.Stream(device=device)
+
+    # ------------------------------------------------------------------ gradient exchange
+    def _reset_pending(self):
+        self._pending = [b[3] for b in self._buckets]
+        self._handles = []
+
+    def _make_hook(self, b):
+        def hook(param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                seg, s, e, _ = self._buckets[b]
+                # side stream: the all-reduce overlaps the remaining backward kernels
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self._handles.append(dist.all_reduce(seg.flat_g[s:e], async_op=True))
+        return hook
+
+    def _finish_allreduce(self):
+        for h in self._handles:
+            h.wait()
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._reset_pending()
+
+    # ------------------------------------------------------------------ one step
+    def current_lr(self):
+        return cosine_lr(self.base_lr, self.step_count, self.max_iters, self.min_lr_ratio, self.warmup_iters,
+                         self.warmup_ratio)
+
+    def step(self, batch):
+        """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
+        out = self.model.train_step(batch, None)
+        out['loss'].backward()
+        if self.world > 1:
+            self._finish_allreduce()
+        self.optimizer_step()
+        return out
+
+    def optimizer_step(self):
+        self.step_count += 1
+        lr = self.current_lr()
+        gscale = 1.0 / self.world                       # DDP averages the summed gradients
+        self.sumsq.zero_()
+        for seg in self.segments:
+            ops.sumsq_accumulate(seg.flat_g, self.sumsq)
+        for seg in self.segments:
+            ops.adamw_step(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, None, self.sumsq, lr,
+                           self.betas[0], self.betas[1], self.eps, seg.weight_decay, self.step_count,
+                           self.grad_clip if self.grad_clip else 0.0, gscale)
+        for seg in self.segments:
+            seg.flat_g.zero_()
+
+    def grad_norm(self):
+        """Global gradient norm of the last step's (averaged) gradients — host sync, logging only."""
+        return float(self.sumsq.sqrt().item()) / self.world

@@ -1,0 +1,146 @@
+"""Contrastive projection heads, registered under the reference's names/kwargs
+(mmaction/models/heads/ssl_head.py:9-297).  [B, D]-sized GEMMs kept in fp32 (see
+nn.LinearFP32) + the HIP LayerNorm/GELU kernels in their fp32-storage form; outputs fp32
+(the loss is @force_fp32)."""
+import torch
+import torch.nn as nn
+
+from ..builder import HEADS
+from ..nn import GELU, LayerNorm
+from ..nn import LinearFP32 as Linear
+
+
+def _init_head(module):
+    for _, m in module.named_modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            nn.init.xavier_uniform_(m.weight)
+        elif isinstance(m, (nn.BatchNorm1d, nn.LayerNorm)):
+            m.bias.data.zero_()
+            m.weight.data.fill_(1.0)
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            m.bias.data.zero_()
+
+
+def _no_bn(flag, what):
+    if flag:
+        raise NotImplementedError(f'{what}: BatchNorm variants are outside the pre-training path '
+                                  '(configs use ln=True / text_bn=False)')
+
+
+@HEADS.register_module()
+class NCEHeadForMM(nn.Module):
+    def __init__(self, visual_in_channels, text_in_channels, img_hidden_dim, vts_embed_dim, spatial_type='avg',
+                 text_agg_type='avg', ln=False, text_bn=False, dropout_ratio=0.1, init_std=0.01, **kwargs):
+        super().__init__()
+        _no_bn(not ln, 'NCEHeadForMM(ln=False)')
+        _no_bn(text_bn, 'NCEHeadForMM(text_bn=True)')
+        self.vis_in_channels = visual_in_channels
+        self.text_in_channels = text_in_channels
+        self.spatial_type = spatial_type
+        self.dropout_ratio = dropout_ratio
+        self.init_std = init_std
+        self.img_hidden_dim = img_hidden_dim
+        self.vts_embed_dim = vts_embed_dim
+        self.fp16_enabled = False
+        self.ln = ln
+        self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
+        self.img_projector = nn.Sequential(
+            Linear(visual_in_channels, img_hidden_dim), LayerNorm(img_hidden_dim), GELU(),
+            Linear(img_hidden_dim, vts_embed_dim), LayerNorm(vts_embed_dim))
+        self.text_projector = nn.Sequential(
+            Linear(text_in_channels, text_in_channels), GELU(), Linear(text_in_channels, vts_embed_dim))
+        self.init_weights()
+        self.text_agg_type = text_agg_type
+
+    def init_weights(self):
+        _init_head(self)
+
+    def forward(self, img, text, text_mask=None, token_ids=None):
+        return self.forward_vision(img), self.forward_text(text, text_mask, token_ids)
+
+    def forward_vision(self, img, channels_last=False):
+        """img [N,C,T,h,w] (reference layout) or [N,T,h,w,C] with channels_last=True -> [N,vts] fp32."""
+        if self.spatial_type == 'avg':
+            img = img.float().mean(dim=(1, 2, 3) if channels_last else (2, 3, 4))
+        else:
+            raise NotImplementedError('spatial_type other than avg')
+        if self.dropout is not None:
+            img = self.dropout(img)
+        return self.img_projector(img).float()
+
+    def forward_text(self, text, text_mask=None, token_ids=None):
+        if self.text_agg_type == 'avg':
+            text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
+            text = text[:, 1:].float()
+            text_mask = text_mask[:, 1:]
+            text = (text * text_mask.unsqueeze(-1)).sum(1) / text_mask.sum(1, keepdim=True)
+        elif self.text_agg_type == 'cls':
+            text = text[:, 0]
+        elif self.text_agg_type == 'max':
+            text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
+            text = (text[:, 1:].float() * text_mask[:, 1:].unsqueeze(-1)).max(dim=1)[0]
+        return self.text_projector(text).float()
+
+
+@HEADS.register_module()
+class NCEHeadForVision(nn.Module):
+    def __init__(self, cross_in_channels=768, visual_in_channels=1024, hidden_dim=768, vts_embed_dim=768,
+                 dropout_ratio=0.1, ln=False, init_std=0.01, **kwargs):
+        super().__init__()
+        _no_bn(not ln, 'NCEHeadForVision(ln=False)')
+        self.cross_in_channels = cross_in_channels
+        self.visual_in_channels = visual_in_channels
+        self.vts_embed_dim = vts_embed_dim
+        self.hidden_dim = hidden_dim
+        self.dropout_ratio = dropout_ratio
+        self.ln = ln
+        self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
+        self.img_fc1 = Linear(visual_in_channels, hidden_dim * 2)
+        self.img_bn1 = LayerNorm(hidden_dim * 2)
+        self.img_act = GELU()
+        self.img_fc2 = Linear(hidden_dim * 2, vts_embed_dim)
+        self.img_bn2 = LayerNorm(vts_embed_dim)
+        self.init_weights()
+
+    def init_weights(self):
+        _init_head(self)
+
+    def forward(self, img):
+        """img [b, tokens, C] -> mean over tokens; a 2-D CLS row [b, C] is taken as-is.
+
+        Deviation D1: the reference calls ``img.mean(dim=1)`` on the 2-D row
+        ``t_last_hidden_state[:, 0]`` (multimodal_transformer_pretrain.py:148-149), which
+        collapses it to [b] and crashes in ``img_fc1``.  The only shape-consistent reading —
+        also what the symmetric NCEHeadForText does — is to treat the row as [b,1,C]."""
+        if img.dim() == 3:
+            img = img.float().mean(dim=1)
+        if self.dropout is not None:
+            img = self.dropout(img)
+        return self.img_bn2(self.img_fc2(self.img_act(self.img_bn1(self.img_fc1(img))))).float()
+
+
+@HEADS.register_module()
+class NCEHeadForText(nn.Module):
+    def __init__(self, cross_in_channels=768, vts_embed_dim=768, dropout_ratio=0.1, text_bn=False, **kwargs):
+        super().__init__()
+        _no_bn(text_bn, 'NCEHeadForText(text_bn=True)')
+        self.cross_in_channels = cross_in_channels
+        self.vts_embed_dim = vts_embed_dim
+        self.dropout_ratio = dropout_ratio
+        self.fp16_enabled = False
+        self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
+        self.text_bn = text_bn
+        self.fc1 = Linear(cross_in_channels, cross_in_channels)
+        self.bn = None
+        self.act = GELU()
+        self.fc2 = Linear(cross_in_channels, vts_embed_dim)
+        self.init_weights()
+
+    def init_weights(self):
+        _init_head(self)
+
+    def forward(self, mask_word_feat):
+        x = self.act(self.fc1(mask_word_feat))
+        if self.dropout is not None:
+            x = self.dropout(x)
+        return self.fc2(x).float()

@@ -1,0 +1,42 @@
+"""``ExclusiveNCEwithRankingLoss`` (mmaction/models/losses/contrastive_loss.py:72-161):
+all-gather the four embeddings, then the fused HIP loss (``clv_infonce_fwd/bwd``)."""
+import torch.nn as nn
+
+from .. import ops
+from ..builder import LOSSES
+from ..utils.dist import get_dist_info
+from ..utils.gather_loss import packed_all_gather
+
+
+@LOSSES.register_module()
+class ExclusiveNCEwithRankingLoss(nn.Module):
+    def __init__(self, temperature=0.05, use_rank=False, use_rank_ttm=True, use_rank_trtm=True, margin_ttm=5.,
+                 margin_trtm=10.):
+        super().__init__()
+        self.t = temperature
+        self.margin_ttm = margin_ttm
+        self.margin_trtm = margin_trtm          # constructed but never used by the reference forward (R3)
+        self.use_rank = use_rank
+        self.use_rank_ttm = use_rank_ttm
+        self.use_rank_trtm = use_rank_trtm
+        self.fp16_enabled = False
+        self.equal_batch = True                  # per-rank batches equal (the trainer's sampler); False -> size exchange
+
+    @property
+    def rank(self):
+        return get_dist_info()[0]
+
+    @property
+    def world_size(self):
+        return get_dist_info()[1]
+
+    def forward(self, video_embd=None, text_embd=None, text_mask_embd=None, text_recon_embd=None, **kwargs):
+        if any(e is None for e in (video_embd, text_embd, text_mask_embd, text_recon_embd)):
+            raise NotImplementedError('the fused loss needs all four embeddings (use_Cmask=True path)')
+        v, t, tm, tr = packed_all_gather([video_embd, text_embd, text_mask_embd, text_recon_embd],
+                                         equal_sizes=self.equal_batch)
+        nce, rank = ops.exclusive_infonce_rank(v, t, tm, tr, self.t, self.margin_ttm)
+        losses = {'nce_loss': nce}
+        if self.use_rank and self.use_rank_ttm:
+            losses['rank_t_tm_loss'] = rank
+        return losses

@@ -1,0 +1,65 @@
+"""Building blocks shared by the registered modules: nn.Linear / nn.LayerNorm subclasses
+(so mmcv-style param-group rules that test ``isinstance(m, nn.LayerNorm)`` keep working and
+state_dict keys stay ``weight``/``bias``) whose forward runs the bf16 HIP/hipBLASLt path.
+
+Precision policy (maps the reference's fp16 policy, fp16_utils.py:215-259, to bf16):
+parameters are fp32 masters; GEMM operands are bf16 (fp32 accumulate in MFMA); LayerNorm
+parameters/statistics, softmax, and every loss are fp32.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def to_bf16(t):
+    return t if t.dtype == BF16 else t.to(BF16)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return F.linear(to_bf16(x), to_bf16(self.weight), to_bf16(self.bias) if self.bias is not None else None)
+
+
+class LinearFP32(nn.Linear):
+    """fp32 GEMM for the [B, D] projection heads: the contrastive logits are cos/0.05, so a bf16
+    rounding of an embedding (2^-9 relative) would already move the loss by ~1e-2; these GEMMs are
+    O(B*D^2) and cost nothing (the reference forces fp32 here too, contrastive_loss.py:102)."""
+
+    def forward(self, x):
+        return F.linear(x.float(), self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x, residual=None):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual)
+
+
+class GELU(nn.Module):
+    def forward(self, x):
+        return ops.gelu(x)
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm DropPath; swin_transformer_3d.py:441,498,503)."""
+
+    def __init__(self, drop_prob=0.):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
+        return x * (mask / keep)
+
+    def extra_repr(self):
+        return f'drop_prob={self.drop_prob}'
+
+
+def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)

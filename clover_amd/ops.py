@@ -1,0 +1,413 @@
+"""torch.autograd.Function wrappers over the C ABI (include/clover_hip.h).
+
+These own every tensor, pass ``data_ptr()`` + the current HIP stream through ctypes, and
+are what the registered nn.Modules call.  No CPU path exists: a non-HIP tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ClvAttnGeom, check
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('clover_amd ops run only on a HIP device (MI355X); there is no CPU fallback — '
+                               'got a tensor on %s' % t.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- in-process kernel timing
+# bench.py sets PROF = {} for the timed region: every attention launch is then bracketed by HIP
+# events recorded on the launch stream (no synchronisation), and the elapsed times are read after
+# the final sync.  key -> dict(events=[(start, end)], flops=.., bytes=..) per launch.
+PROF = None
+
+
+class _Timed:
+    def __init__(self, key, flops, nbytes):
+        self.key, self.flops, self.nbytes = key, flops, nbytes
+
+    def __enter__(self):
+        if PROF is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROF is not None:
+            self.e.record()
+            rec = PROF.setdefault(self.key, dict(events=[], flops=self.flops, bytes=self.nbytes))
+            rec['events'].append((self.s, self.e))
+
+
+def _attn_work(g, backward):
+    """Algorithmic work of one attention launch: 2 flops/MAC over the
+    N x N x hd products (2 matmuls forward, 5 backward); bytes = q,k,v read + o written
+    (forward) or q,k,v,o,do read + dq,dk,dv written (backward), bf16."""
+    per = g.groups * g.nH * g.N * g.N * g.hd
+    flops = (10 if backward else 4) * per
+    tok = g.groups * g.N * g.nH * g.hd * 2
+    nbytes = (8 if backward else 4) * tok
+    return flops, nbytes
+
+
+def roofline_from_prof(prof, steps):
+    """-> (roofline dict of the dominant instrumented kernel, per-kernel table)."""
+    rows = []
+    for key, rec in prof.items():
+        ms = [s.elapsed_time(e) for s, e in rec['events']]
+        rows.append(dict(kernel=key, launches_per_step=len(ms) / steps, avg_us=1e3 * sum(ms) / len(ms),
+                         total_ms_per_step=sum(ms) / steps, flops=rec['flops'], bytes=rec['bytes']))
+    rows.sort(key=lambda r: -r['total_ms_per_step'])
+    top = rows[0]
+    t = top['avg_us'] * 1e-6
+    t_hbm, t_mfma = top['bytes'] / 8.0e12, top['flops'] / 2.5e15
+    if t_hbm >= t_mfma:
+        roof = dict(bound='hbm', achieved=round(top['bytes'] / t / 1e9, 1), peak=8000.0, unit='GB/s',
+                    frac=round(top['bytes'] / t / 8.0e12, 4), traffic=None)
+    else:
+        roof = dict(bound='mfma', achieved=round(top['flops'] / t / 1e12, 2), peak=2500.0, unit='TFLOP/s',
+                    frac=round(top['flops'] / t / 2.5e15, 4), traffic=None)
+    roof['kernel'] = top['kernel']
+    roof['avg_us'] = round(top['avg_us'], 2)
+    roof['algorithmic_bytes'] = top['bytes']
+    roof['algorithmic_flops'] = top['flops']
+    table = [dict(kernel=r['kernel'], launches_per_step=round(r['launches_per_step'], 2),
+                  avg_us=round(r['avg_us'], 2), ms_per_step=round(r['total_ms_per_step'], 3)) for r in rows[:12]]
+    return roof, table
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        _need_gpu(x, gamma)
+        C_ = x.shape[-1]
+        x2 = _c(x).view(-1, C_)
+        r2 = _c(res).view(-1, C_) if res is not None else None
+        f32 = x2.dtype == torch.float32            # fp32 storage (projection heads) or bf16 storage
+        if not f32 and x2.dtype != BF16:
+            x2 = x2.to(BF16)
+        if r2 is not None and r2.dtype != x2.dtype:
+            r2 = r2.to(x2.dtype)
+        g = _c(gamma.float())
+        b = _c(beta.float())
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd),
+                                           rows, C_, float(eps), int(f32), _stream()), 'clv_layernorm_fwd')
+        ctx.save_for_backward(x2, r2, g, mean, rstd)
+        ctx.has_res = res is not None
+        ctx.xshape = x.shape
+        ctx.gdtype = gamma.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, g, mean, rstd = ctx.saved_tensors
+        rows, C_ = x2.shape
+        dy2 = _c(dy).view(rows, C_)
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        L = _lib.lib()
+        nblk = L.clv_layernorm_bwd_blocks(rows, C_)
+        partial = torch.empty(2 * nblk * C_, device=x2.device, dtype=torch.float32)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C_, device=x2.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                  _ptr(dg), _ptr(db), _ptr(partial), rows, C_, int(x2.dtype == torch.float32),
+                                  _stream()), 'clv_layernorm_bwd')
+        dxv = dx.view(ctx.xshape)
+        return dxv, (dxv if ctx.has_res else None), dg.to(ctx.gdtype), db.to(ctx.gdtype), None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, residual=None):
+    """y = LayerNorm(x [+ residual]) over the last dim; bf16 (or fp32) in/out, fp32 statistics."""
+    return _LayerNorm.apply(x, residual, weight, bias, eps)
+
+
+# --------------------------------------------------------------------------- GELU
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        xc = _c(x)
+        if xc.dtype not in (BF16, torch.float32):
+            xc = xc.to(BF16)
+        y = torch.empty_like(xc)
+        check(_lib.lib().clv_gelu_fwd(_ptr(xc), _ptr(y), xc.numel(), int(xc.dtype == torch.float32), _stream()),
+              'clv_gelu_fwd')
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dyc = _c(dy)
+        if dyc.dtype != xc.dtype:
+            dyc = dyc.to(xc.dtype)
+        dx = torch.empty_like(xc)
+        check(_lib.lib().clv_gelu_bwd(_ptr(dyc), _ptr(xc), _ptr(dx), xc.numel(), int(xc.dtype == torch.float32),
+                                      _stream()), 'clv_gelu_bwd')
+        return dx
+
+
+def gelu(x):
+    """erf GELU (nn.GELU / HF 'gelu'), bf16 or fp32 storage."""
+    return _Gelu.apply(x)
+
+
+# --------------------------------------------------------------------------- attention
+class _Attention(torch.autograd.Function):
+    """qkv: bf16 [..tokens.., 3*nH*hd] with q|k|v packed along the last dim."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, rid, kmask, geom_kw):
+        _need_gpu(qkv)
+        assert qkv.dtype == BF16 and qkv.is_contiguous()
+        g = ClvAttnGeom(**geom_kw)
+        Cdim = g.nH * g.hd
+        assert qkv.shape[-1] == 3 * Cdim
+        g.ldq = g.ldk = g.ldv = 3 * Cdim
+        g.ldo = Cdim
+        g.bias_ld = bias.shape[-1] if bias is not None else 0
+        o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=BF16)
+        lse = torch.empty(g.groups * g.nH * g.N, device=qkv.device, dtype=torch.float32)
+        base = qkv.data_ptr()
+        with _Timed(f'attn_fwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, False)):
+            check(_lib.lib().clv_attn_fwd(C.c_void_p(base), C.c_void_p(base + 2 * Cdim),
+                                          C.c_void_p(base + 4 * Cdim), _ptr(o), _ptr(lse), _ptr(bias), _ptr(rid),
+                                          _ptr(kmask), C.byref(g), _stream()), 'clv_attn_fwd')
+        ctx.save_for_backward(qkv, o, lse, bias, rid, kmask)
+        ctx.geom = g
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, bias, rid, kmask = ctx.saved_tensors
+        g = ctx.geom
+        Cdim = g.nH * g.hd
+        doc = _c(do)
+        if doc.dtype != BF16:
+            doc = doc.to(BF16)
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias) if bias is not None else None
+        dsum = torch.empty_like(lse)
+        b, d = qkv.data_ptr(), dqkv.data_ptr()
+        with _Timed(f'attn_bwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, True)):
+            check(_lib.lib().clv_attn_bwd(C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim),
+                                          _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(rid), _ptr(kmask),
+                                          C.c_void_p(d), C.c_void_p(d + 2 * Cdim), C.c_void_p(d + 4 * Cdim),
+                                          _ptr(dbias), _ptr(dsum), C.byref(g), _stream()), 'clv_attn_bwd')
+        return dqkv, dbias, None, None, None
+
+
+def window_attention(qkv, bias, rid, window, shift, num_heads):
+    """3-D shifted-window MHA on the natural token layout.
+
+    qkv bf16 [B,D,H,W,3C]; bias fp32 [nH,N,Npad] (Npad multiple of 16) — the gathered
+    relative-position bias; rid int32 [nW,N] region ids (None = no shift mask).
+    Returns o bf16 [B,D,H,W,C] already window-reversed and un-rolled.
+    """
+    B, D, H, W, C3 = qkv.shape
+    Cdim = C3 // 3
+    hd = Cdim // num_heads
+    N = window[0] * window[1] * window[2]
+    nW = (D // window[0]) * (H // window[1]) * (W // window[2])
+    kw = dict(mode=1, groups=B * nW, N=N, nH=num_heads, hd=hd, D=D, H=H, W=W, wd=window[0], wh=window[1],
+              ww=window[2], sd=shift[0], sh=shift[1], sw=shift[2], scale=float(hd) ** -0.5)
+    return _Attention.apply(qkv, bias, rid, None, kw)
+
+
+def seq_attention(qkv, kmask, num_heads):
+    """BERT self-attention. qkv bf16 [B,S,3H]; kmask fp32 [B,S] additive ((1-m)*-10000) or None."""
+    B, S, C3 = qkv.shape
+    hd = C3 // 3 // num_heads
+    kw = dict(mode=0, groups=B, N=S, nH=num_heads, hd=hd, scale=float(hd) ** -0.5)
+    return _Attention.apply(qkv, None, None, kmask, kw)
+
+
+# --------------------------------------------------------------------------- patch embed
+class _PatchEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps):
+        _need_gpu(x, weight)
+        B, Cin, T, H, W = x.shape
+        Cout = weight.shape[0]
+        assert Cin == 3 and tuple(weight.shape[1:]) == (3, 2, 4, 4), 'kernel covers patch (2,4,4), 3 input channels'
+        xc = _c(x.float())
+        w2 = _c(weight.reshape(Cout, 96).to(BF16))
+        bf = _c(bias.float())
+        gf = _c(gamma.float()) if gamma is not None else None
+        bef = _c(beta.float()) if beta is not None else None
+        want_masked = vmask is not None
+        mt = _c(mask_token.reshape(-1).float()) if want_masked else None
+        vm = _c(vmask.reshape(B, vmask.shape[-2], vmask.shape[-1]).long()) if want_masked else None
+        Tp, Hp, Wp = T // 2, H // 4, W // 4
+        M = B * Tp * Hp * Wp
+        dev = x.device
+        need_grad = any(t is not None and t.requires_grad for t in (weight, bias, gamma, beta, mask_token))
+        clean = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_clean else None
+        masked = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_masked else None
+        z = torch.empty(M, Cout, device=dev, dtype=BF16) if need_grad else None
+        mean = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
+        rstd = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
+        mh, mw = (vm.shape[1], vm.shape[2]) if want_masked else (1, 1)
+        check(_lib.lib().clv_patch_embed_fwd(_ptr(xc), _ptr(w2), _ptr(bf), _ptr(gf), _ptr(bef), _ptr(mt), _ptr(vm),
+                                             _ptr(clean), _ptr(masked), _ptr(z), _ptr(mean), _ptr(rstd), B, T, H, W,
+                                             Cout, mh, mw, float(eps), _stream()), 'clv_patch_embed_fwd')
+        ctx.save_for_backward(xc, z, mean, rstd, gf, vm)
+        ctx.meta = (B, T, H, W, Cout, want_clean, want_masked, weight.shape,
+                    mask_token.shape if mask_token is not None else None)
+        outs = (clean if want_clean else x.new_empty(0), masked if want_masked else x.new_empty(0))
+        return outs
+
+    @staticmethod
+    def backward(ctx, dclean, dmasked):
+        xc, z, mean, rstd, gf, vm = ctx.saved_tensors
+        B, T, H, W, Cout, want_clean, want_masked, wshape, mtshape = ctx.meta
+        Tp, Hp, Wp = T // 2, H // 4, W // 4
+        M = B * Tp * Hp * Wp
+        dy = None
+        dmt = None
+        if want_clean and dclean is not None:
+            dy = dclean.reshape(M, Cout).float()
+        if want_masked and dmasked is not None:
+            mh, mw = vm.shape[1], vm.shape[2]
+            wt = vm.to(torch.float32).repeat_interleave(Hp // mh, 1).repeat_interleave(Wp // mw, 2)   # [B,Hp,Wp]
+            wt = wt[:, None].expand(B, Tp, Hp, Wp).reshape(M, 1)
+            dm = dmasked.reshape(M, Cout).float()
+            dmt = (dm * wt).sum(0).reshape(mtshape)
+            dm = dm * (1.0 - wt)
+            dy = dm if dy is None else dy + dm
+        L = _lib.lib()
+        dyb = dy.to(BF16).contiguous()
+        if gf is not None:
+            nblk = L.clv_layernorm_bwd_blocks(M, Cout)
+            partial = torch.empty(2 * nblk * Cout, device=xc.device, dtype=torch.float32)
+            dz = torch.empty_like(z)
+            dg = torch.empty(Cout, device=xc.device, dtype=torch.float32)
+            db = torch.empty_like(dg)
+            check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(dz),
+                                      _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, _stream()), 'clv_layernorm_bwd')
+        else:
+            dz, dg, db = dyb, None, None
+        patches = torch.empty(M, 96, device=xc.device, dtype=BF16)
+        check(L.clv_im2col_patches(_ptr(xc), _ptr(patches), B, T, H, W, _stream()), 'clv_im2col_patches')
+        dw = torch.mm(dz.t(), patches).float().reshape(wshape)
+        dbias = dz.float().sum(0)
+        return None, dw, dbias, dg, db, dmt, None, None, None
+
+
+def patch_embed(x, weight, bias, gamma, beta, mask_token=None, vmask=None, want_clean=True, eps=1e-5):
+    """PatchEmbed3D + LN + mask-token blend. x fp32 [B,3,T,H,W] (already padded).
+    Returns (clean, masked) bf16 [B,T/2,H/4,W/4,C] channels-last (masked None without vmask)."""
+    clean, masked = _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps)
+    return (clean if want_clean else None), (masked if vmask is not None else None)
+
+
+# --------------------------------------------------------------------------- focal MLM loss
+class _FocalCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, gamma):
+        _need_gpu(logits, labels)
+        lg = _c(logits)
+        assert lg.dim() == 2 and lg.dtype in (BF16, torch.float32)
+        lab = _c(labels.long())
+        rows, V = lg.shape
+        dev = lg.device
+        row_ce = torch.empty(rows, device=dev, dtype=torch.float32)
+        row_lse = torch.empty_like(row_ce)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        count = torch.empty(1, device=dev, dtype=torch.float32)
+        check(_lib.lib().clv_focal_ce_fwd(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
+                                          _ptr(loss), _ptr(count), rows, V, float(gamma), _stream()),
+              'clv_focal_ce_fwd')
+        ctx.save_for_backward(lg, lab, row_ce, row_lse, count)
+        ctx.gamma = float(gamma)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, lab, row_ce, row_lse, count = ctx.saved_tensors
+        rows, V = lg.shape
+        dl = _c(dloss.float().reshape(1))
+        dlogits = torch.empty_like(lg)
+        check(_lib.lib().clv_focal_ce_bwd(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
+                                          _ptr(count), _ptr(dl), _ptr(dlogits), rows, V, ctx.gamma, _stream()),
+              'clv_focal_ce_bwd')
+        return dlogits, None, None
+
+
+def focal_ce_masked(logits, labels, gamma=2.0):
+    """mean over rows with label != -100 of (1-pt)^gamma * CE(logits, label)."""
+    return _FocalCE.apply(logits, labels, gamma)
+
+
+# --------------------------------------------------------------------------- InfoNCE + rank
+class _InfoNCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e0, e1, e2, e3, temperature, margin):
+        _need_gpu(e0)
+        es = [_c(e.float()) for e in (e0, e1, e2, e3)]
+        G, Dm = es[0].shape
+        L = _lib.lib()
+        work = torch.empty(L.clv_infonce_work_floats(G, Dm), device=e0.device, dtype=torch.float32)
+        out = torch.empty(2, device=e0.device, dtype=torch.float32)
+        check(L.clv_infonce_fwd(_ptr(es[0]), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]), _ptr(out), _ptr(work), G, Dm,
+                                float(temperature), float(margin), _stream()), 'clv_infonce_fwd')
+        ctx.save_for_backward(*es, work)
+        ctx.cfg = (G, Dm, float(temperature), float(margin), [e.dtype for e in (e0, e1, e2, e3)])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, dnce, drank):
+        e0, e1, e2, e3, work = ctx.saved_tensors
+        G, Dm, temp, margin, dts = ctx.cfg
+        dout = torch.stack([dnce.float().reshape(()), drank.float().reshape(())]).contiguous()
+        ds = [torch.empty_like(e0) for _ in range(4)]
+        check(_lib.lib().clv_infonce_bwd(_ptr(e0), _ptr(e1), _ptr(e2), _ptr(e3), _ptr(dout), _ptr(work), _ptr(ds[0]),
+                                         _ptr(ds[1]), _ptr(ds[2]), _ptr(ds[3]), G, Dm, temp, margin, _stream()),
+              'clv_infonce_bwd')
+        return ds[0].to(dts[0]), ds[1].to(dts[1]), ds[2].to(dts[2]), ds[3].to(dts[3]), None, None
+
+
+def exclusive_infonce_rank(video, text, text_mask, text_recon, temperature=0.05, margin=5.0):
+    """(nce_loss, rank_t_tm_loss) of ExclusiveNCEwithRankingLoss on already-gathered [G,Dm] embeddings."""
+    return _InfoNCE.apply(video, text, text_mask, text_recon, temperature, margin)
+
+
+# --------------------------------------------------------------------------- optimizer primitives
+def sumsq_accumulate(flat_grad, acc):
+    _need_gpu(flat_grad, acc)
+    check(_lib.lib().clv_sumsq(_ptr(flat_grad), _ptr(acc), flat_grad.numel(), _stream()), 'clv_sumsq')
+
+
+def adamw_step(p, g, m, v, shadow, sumsq, lr, beta1, beta2, eps, weight_decay, step, max_norm, grad_scale=1.0):
+    _need_gpu(p, g, m, v)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.lib().clv_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(sumsq), p.numel(),
+                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                    float(bc1), float(bc2), float(max_norm), float(grad_scale), _stream()),
+          'clv_adamw_step')

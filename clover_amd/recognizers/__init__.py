@@ -1,0 +1,4 @@
+from .base import BaseRecognizer
+from .multimodal_transformer_pretrain import CloverPretrain
+
+__all__ = ['BaseRecognizer', 'CloverPretrain']

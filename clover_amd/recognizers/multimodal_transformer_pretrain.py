@@ -1,0 +1,131 @@
+"""``CloverPretrain`` — the video-text pre-training step graph of
+mmaction/models/recognizers/multimodal_transformer_pretrain.py:11-173, same constructor
+kwargs, same ``losses`` keys.
+
+MI355X-first scheduling of the SAME arithmetic (every encoder is sample-independent —
+LayerNorm only — so batching passes along dim 0 changes no value):
+  * clean + masked video passes (:91,114)  -> one 2B-clip Swin pass (``forward_pair``)
+  * un-masked + masked caption passes (:99,110) -> one 2B BERT pass
+  * v_fusion + t_fusion (:117,119)          -> one 2B fusion pass
+  * MLM head only on the t_fusion half; all B*L rows go through the decoder and the fused
+    focal kernel skips label == -100 rows (:134-139) — no data-dependent shapes, no host sync.
+"""
+import torch
+
+from ..builder import RECOGNIZERS, build_backbone, build_head, build_loss
+from .base import BaseRecognizer
+
+
+@RECOGNIZERS.register_module()
+class CloverPretrain(BaseRecognizer):
+    def __init__(self, mm_backbone, text_backbone=None, freeze_text_backbone=None, freeze_dvae_backbone=None,
+                 loss_type=None, ssl_loss=None, ssl_head=None, mlm_head=None, mlm_loss=None, mlm_ssl_head=None,
+                 symmetry_rank=False, separate_test=False, from_scratch=False, use_Cmask=True,
+                 text_vocab_size=30522, **kwargs):
+        super().__init__(**kwargs)
+        self.multimodal_backbone = build_backbone(mm_backbone)
+        self.text_backbone = build_backbone(text_backbone)
+        self.text_vocab_size = text_vocab_size
+        self.loss_func = build_loss(loss_type) if loss_type is not None else None
+        self.use_Cmask = use_Cmask
+        self.mlm_head = build_head(mlm_head) if mlm_head is not None else None
+        if mlm_ssl_head is not None:
+            self.mlm_ssl_V_head = build_head(mlm_ssl_head['V']) if mlm_ssl_head.get('V') else None
+            self.mlm_ssl_T_head = build_head(mlm_ssl_head['T']) if mlm_ssl_head.get('T') else None
+        else:
+            self.mlm_ssl_V_head = None
+            self.mlm_ssl_T_head = None
+        self.mlm_loss_func = build_loss(mlm_loss) if mlm_loss is not None else None
+        self.symmetry_rank = symmetry_rank
+        self.from_scratch = from_scratch
+        self.separate_test = separate_test
+        if ssl_head is not None:
+            self.ssl_head_name = ssl_head['type']
+            self.ssl_head = build_head(ssl_head)
+            self.ssl_loss = build_loss(ssl_loss)
+        self.fp16_enabled = False
+        if freeze_dvae_backbone is not None:
+            self._freeze(freeze_stage=freeze_dvae_backbone, freeze_except=[])
+        if freeze_text_backbone is not None:
+            self._freeze(freeze_stage=freeze_text_backbone, freeze_except=[])
+
+    def extract_visual_feat(self, imgs, mask=None):
+        return self.backbone(imgs, mask)
+
+    def forward_train(self, imgs, label, token_ids=None, segment_ids=None, input_mask=None, mlm_label=None,
+                      dvae_imgs=None, v_token_mask=None, hog_features=None, img_metas=None, **kwargs):
+        if not hasattr(self, 'ssl_head') or self.mlm_ssl_V_head is None or not self.use_Cmask \
+                or mlm_label is None or v_token_mask is None:
+            raise NotImplementedError('the MI355X path implements the full pre-training recipe '
+                                      '(ssl_head + mlm_ssl_head + use_Cmask + mlm_label + v_token_mask)')
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])                                   # :81
+        if self.from_scratch:
+            imgs = imgs / 255.0
+        token_ids = token_ids.reshape((-1,) + token_ids.shape[2:])                    # :85
+        text_input_mask = input_mask.reshape((-1,) + input_mask.shape[2:])
+        mlm_label = mlm_label.reshape((-1,) + mlm_label.shape[2:])
+        B = imgs.shape[0]
+
+        # ---- video encoder: clean (:91) + masked (:114) pass, channels-last [B,T',h,w,Cf]
+        vis_clean, vis_masked = self.backbone.forward_pair(imgs, v_token_mask)
+        _, T, h, w, D = vis_clean.shape
+
+        # ---- text encoder: un-masked caption (:97-101) + masked caption (:110-111)
+        input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
+        text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
+                                      torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+        text_out_no_mask, text_out_with_mask = text_out[:B], text_out[B:]
+
+        # ---- contrastive projections (:102, :150, :159)
+        vis_emb_both = self.ssl_head.forward_vision(torch.cat([vis_clean, vis_masked], 0), channels_last=True)
+        visual_emb, mask_visual_emb = vis_emb_both[:B], vis_emb_both[B:]
+        txt_emb_both = self.ssl_head.forward_text(text_out)
+        text_emb, mask_word_emb = txt_emb_both[:B], txt_emb_both[B:]
+
+        # ---- fusion: v_fusion = (masked video, clean text) (:117); t_fusion = (clean video, masked text) (:119)
+        fusion_vis = torch.cat([vis_masked, vis_clean], 0).reshape(2 * B, T, h * w, D)
+        fusion_txt = torch.cat([text_out_no_mask, text_out_with_mask], 0)
+        fusion = self.multimodal_backbone(visual_token=fusion_vis,
+                                          text_input_mask=torch.cat([text_input_mask, text_input_mask], 0),
+                                          text_input_embeds=fusion_txt)
+        t_all = fusion['t_last_hidden_state']
+        v_fusion_t, t_last_hidden_state = t_all[:B], t_all[B:]
+
+        losses = dict()
+        # ---- MLM (:129-143)
+        if self.mlm_head is not None:
+            score = self.mlm_head(t_last_hidden_state)
+            fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
+            losses['mlm_loss'] = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
+
+        # ---- tri-modal alignment with masked samples + ranking (:147-152)
+        mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])
+        losses.update(self.ssl_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb))
+
+        if self.symmetry_rank:                                                         # :155-169
+            mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])
+            l2 = self.ssl_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon_emb)
+            l2['v_nce_loss'] = l2.pop('nce_loss')
+            if self.ssl_loss.use_rank:
+                l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')
+            losses.update(l2)
+        return losses
+
+    def forward_test(self, imgs, token_ids=None, segment_ids=None, input_mask=None, **kwargs):
+        """``separate_test`` inference (:194-218): one Swin pass + one BERT pass -> (visual_emb, text_emb)."""
+        if not self.separate_test:
+            raise NotImplementedError('only separate_test=True inference exists in the reference (R4)')
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])
+        if self.from_scratch:
+            imgs = imgs / 255.0
+        vis = self.backbone.forward_tokens(imgs)
+        B_text = token_ids.shape[0]
+        if B_text != vis.shape[0]:
+            vis = vis.reshape((B_text, -1) + vis.shape[1:]).float().mean(dim=1)
+        token_ids = token_ids.reshape((-1,) + token_ids.shape[2:])
+        input_mask = input_mask.reshape((-1,) + input_mask.shape[2:])
+        text = self.text_backbone(token_ids, input_mask)['last_hidden_state']
+        return self.ssl_head.forward_vision(vis, channels_last=True), self.ssl_head.forward_text(text, input_mask, token_ids)
+
+    def forward_gradcam(self, imgs, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,159 @@
+/* clover_hip.h — C ABI of libclover_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Clover video-text pre-training hot path.  The
+ * reference (LeeYN-43/Clover) is 100 % Python over torch/cuDNN/cuBLAS and has no
+ * native FFI of its own; each entry point below replaces the torch op group that
+ * the cited reference lines execute (paths relative to /root/reference/).  A
+ * reference maintainer binds them with ctypes from the registered nn.Modules —
+ * see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch / C++ types cross the ABI;
+ *   - every pointer is DEVICE memory unless its name ends in _host;
+ *   - bf16 tensors are `void*` (uint16 storage), row-major, innermost contiguous;
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on it,
+ *     allocate nothing, and are capturable into a hipGraph;
+ *   - return 0 on success, negative CLV_ERR_* otherwise; no exceptions.
+ */
+#ifndef CLOVER_HIP_H
+#define CLOVER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLV_ABI_VERSION 1
+#define CLV_ERR_ARG (-1)
+#define CLV_ERR_UNSUPPORTED (-2)
+#define CLV_ERR_LAUNCH (-3)
+
+int clv_abi_version(void);
+
+/* ------------------------------------------------------------------ attention
+ * One kernel family serves both attention flavours of the path:
+ *   mode 1: 3-D shifted-window MHA — WindowAttention3D.forward
+ *           (mmaction/models/backbones/swin_transformer_3d.py:375-400) fused with
+ *           the cyclic roll + window_partition before it (:459-466) and the
+ *           window_reverse + un-roll after it (:470-476): q/k/v are read from, and
+ *           o is written to, the natural [B,D,H,W,*] token layout;
+ *   mode 0: full self-attention over [video ‖ text] / text with an additive key
+ *           mask — transformers 4.6.1 BertSelfAttention as called from
+ *           bert_from_hugface.py:30 and cross_transformer.py:109-110.
+ * softmax( q·kᵀ·scale + bias[h] + (rid[i]!=rid[j] ? -100 : 0) + kmask[b][j] ) · v
+ */
+typedef struct ClvAttnGeom {
+    int32_t mode;           /* 0 sequence, 1 shifted 3-D window */
+    int32_t groups;         /* B (mode 0) or B*nW (mode 1) */
+    int32_t N;              /* tokens per group: S or wd*wh*ww */
+    int32_t nH;             /* heads */
+    int32_t hd;             /* head dim: 16, 32 or 64 */
+    int32_t D, H, W;        /* mode 1: (padded) feature dims */
+    int32_t wd, wh, ww;     /* mode 1: effective window (get_window_size, :302-315) */
+    int32_t sd, sh, sw;     /* mode 1: effective shift */
+    int32_t ldq, ldk, ldv, ldo; /* row strides (elements) of q,k,v and o/do/dq.. */
+    int32_t bias_ld;        /* row stride of bias/dbias [nH][N][bias_ld] (multiple of 16), 0 = none */
+    float scale;            /* head_dim^-0.5 */
+} ClvAttnGeom;
+
+/* lse: float [groups][nH][N].  bias: float or NULL.  rid: int32 [nW][N] region ids of
+ * compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL. */
+int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                 const float* bias, const int32_t* rid, const float* kmask,
+                 const ClvAttnGeom* geom_host, void* stream);
+
+/* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float, same shape as bias)
+ * is ACCUMULATED into (caller zeroes).  dsum: float scratch [groups][nH][N]. */
+int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                 const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                 void* dq, void* dk, void* dv, float* dbias, float* dsum,
+                 const ClvAttnGeom* geom_host, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * nn.LayerNorm over the last dim (every norm site: swin_transformer_3d.py:450,483,
+ * 541,685,238; HF BERT LayerNorm eps 1e-12; cross_transformer.py:97).
+ * x,y [rows][C] bf16 (is_f32 = 0) or float (is_f32 = 1: the fp32 projection heads and
+ * losses, ssl_head.py:50-56, contrastive_loss.py:102); gamma,beta float [C]; mean,rstd
+ * float [rows].  res (same type as x, may be NULL): y = LN(x + res) (BERT post-LN residual). */
+int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                      void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                      int32_t is_f32, void* stream);
+/* dx [rows][C] (gradient wrt x and, identically, wrt res); dgamma,dbeta float [C]
+ * (overwritten); partial: float scratch [2][nblk][C] with nblk = clv_layernorm_bwd_blocks(). */
+int clv_layernorm_bwd_blocks(int64_t rows, int32_t C);
+int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                      float* partial, int64_t rows, int32_t C, int32_t is_f32, void* stream);
+
+/* ------------------------------------------------------------------ GELU (erf)
+ * nn.GELU / HF 'gelu' (swin_transformer_3d.py:264; BertIntermediate; ssl_head.py:53). */
+int clv_gelu_fwd(const void* x, void* y, int64_t n, int32_t is_f32, void* stream);
+int clv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t is_f32, void* stream);
+
+/* ------------------------------------------------------------------ patch embed
+ * PatchEmbed3D.forward (swin_transformer_3d.py:671-688: conv3d k=s=(2,4,4) as a GEMM
+ * over non-overlapping patches + bias + LayerNorm(C)) fused with the mask-token blend
+ * of SwinTransformer3D.forward (:222-230).  x float [B][3][T][H][W] (T even, H,W
+ * multiples of 4 — the caller pads, :675-680); w bf16 [C][96] (= proj.weight.flatten(1));
+ * out_clean / out_masked bf16 [B][T/2][H/4][W/4][C] channels-last; either may be NULL.
+ * vmask int64 [B][mh][mw] (the v_token_mask) and mask_token float [C] — required iff
+ * out_masked != NULL.  gamma/beta float [C] or both NULL (patch_norm=False).
+ * z_out (bf16 [M][C] pre-norm conv output), mean, rstd (float [M]): saved for backward,
+ * may be NULL.  C in {48, 96, 128}. */
+int clv_patch_embed_fwd(const float* x, const void* w, const float* bias, const float* gamma,
+                        const float* beta, const float* mask_token, const int64_t* vmask,
+                        void* out_clean, void* out_masked, void* z_out, float* mean, float* rstd,
+                        int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t mh,
+                        int32_t mw, float eps, void* stream);
+/* im2col of the clip into bf16 patches [M][96] (k = c*32 + dt*16 + dy*4 + dx): the operand
+ * of the weight-gradient GEMM dW = dZ^T * patches (the conv3d weight grad of :681). */
+int clv_im2col_patches(const float* x, void* patches, int32_t B, int32_t T, int32_t H, int32_t W,
+                       void* stream);
+
+/* ------------------------------------------------------------------ focal MLM loss
+ * SoftmaxFocalLossMultiClass.forward (mmaction/models/losses/focal_loss.py:61-72) on the
+ * masked rows selected by multimodal_transformer_pretrain.py:137-139, fused:
+ * rows with label == -100 are skipped; loss = mean over the others of (1-pt)^gamma * ce.
+ * logits bf16 or float [rows][V] (is_bf16); labels int64 [rows]; row_ce,row_lse float
+ * [rows] saved for backward; loss float [1]; count float [1] (number of masked rows). */
+int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
+                     float* row_lse, float* loss, float* count, int64_t rows, int32_t V,
+                     float gamma, void* stream);
+/* dlogits (same dtype as logits) = dloss * d loss / d logits (zero for skipped rows). */
+int clv_focal_ce_bwd(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
+                     const float* row_lse, const float* count, const float* dloss, void* dlogits,
+                     int64_t rows, int32_t V, float gamma, void* stream);
+
+/* ------------------------------------------------------------------ exclusive InfoNCE + rank
+ * ExclusiveNCEwithRankingLoss.forward after the all-gather
+ * (mmaction/models/losses/contrastive_loss.py:112-161): cos_norm of the four gathered
+ * embeddings, three G×G similarity matmuls / temperature, the three exclusive [G,3G] row
+ * log-softmaxes, the [3G,G] column log-softmax, diagonals, MarginRankingLoss(margin).
+ * e0..e3 float [G][Dm] (video, text, text_mask, text_recon).  out float [2] =
+ * {nce_loss, rank_t_tm_loss}.  work: float scratch, >= clv_infonce_work_floats(G, Dm). */
+int64_t clv_infonce_work_floats(int32_t G, int32_t Dm);
+int clv_infonce_fwd(const float* e0, const float* e1, const float* e2, const float* e3, float* out,
+                    float* work, int32_t G, int32_t Dm, float temperature, float margin, void* stream);
+/* dout float [2] = upstream grads of {nce, rank}; d0..d3 float [G][Dm].  `work` must be the
+ * buffer the matching forward filled. */
+int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const float* e3,
+                    const float* dout, const float* work, float* d0, float* d1, float* d2, float* d3,
+                    int32_t G, int32_t Dm, float temperature, float margin, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * Grad-norm (clip_grad_norm_, mmcv_Fp16OptimizerHook.py:127-137) + AdamW step on flat
+ * buffers (optimizer cfg pretrain_webvid_cc3m.py:129-137).
+ * clv_sumsq: acc[0] += sum(g^2) over n floats (caller zeroes acc). */
+int clv_sumsq(const float* g, float* acc, int64_t n, void* stream);
+/* One fused AdamW step over a flat fp32 segment.  sumsq: float[1] device = total grad norm²
+ * (all segments); the clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) is applied on
+ * device, and the step is skipped when sumsq is not finite.  shadow (bf16, may be NULL)
+ * receives the updated weights for the bf16 compute path.  grad_scale multiplies g first. */
+int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const float* sumsq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_c1, float bias_c2, float max_norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOVER_HIP_H */

@@ -1,0 +1,265 @@
+"""GPU parity of each HIP kernel (through the C ABI) against the oracle / a plain fp32
+PyTorch restatement of the same op, on the same seeded inputs.  `-m gpu` only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import indexing as ix          # noqa: E402
+from oracle import model as om             # noqa: E402
+
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def ops():
+    from clover_amd import ops as o
+    return o
+
+
+# ----------------------------------------------------------------------------- LayerNorm / GELU
+@pytest.mark.parametrize('C', [48, 96, 128, 192, 384, 768, 1024, 1536, 3072])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_layernorm(C, with_res):
+    rows = 777
+    x = rnd(rows, C, seed=1).to(BF)
+    r = rnd(rows, C, seed=2).to(BF) if with_res else None
+    g = (1 + 0.1 * rnd(C, seed=3))
+    b = 0.1 * rnd(C, seed=4)
+    dy = rnd(rows, C, seed=5).to(BF)
+    xr = x.float().requires_grad_()
+    rr = r.float().requires_grad_() if with_res else None
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.layer_norm(xr + rr if with_res else xr, (C,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    xg = x.to(DEV).requires_grad_()
+    rg = r.to(DEV).requires_grad_() if with_res else None
+    gg, bg = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops().layer_norm(xg, gg, bg, 1e-5, residual=rg)
+    y.backward(dy.to(DEV))
+    assert rel(y, yr) < 1e-2
+    assert rel(xg.grad, xr.grad) < 2e-2
+    if with_res:
+        assert rel(rg.grad, rr.grad) < 2e-2
+    assert rel(gg.grad, gr.grad) < 1e-2
+    assert rel(bg.grad, br.grad) < 1e-2
+
+
+def test_layernorm_eps_1e12_matches_oracle():
+    P = {'n.weight': 1 + 0.1 * rnd(128, seed=1), 'n.bias': 0.1 * rnd(128, seed=2)}
+    x = rnd(5, 16, 128, seed=3).to(BF)
+    yr = om.layer_norm(P, 'n', x.float(), 1e-12)
+    y = ops().layer_norm(x.to(DEV), P['n.weight'].to(DEV), P['n.bias'].to(DEV), 1e-12)
+    assert rel(y, yr) < 1e-2
+
+
+def test_gelu():
+    x = rnd(1000, 771, scale=2.0, seed=1).to(BF)
+    dy = rnd(1000, 771, seed=2).to(BF)
+    xr = x.float().requires_grad_()
+    yr = om.gelu(xr)
+    yr.backward(dy.float())
+    xg = x.to(DEV).requires_grad_()
+    y = ops().gelu(xg)
+    y.backward(dy.to(DEV))
+    assert rel(y, yr) < 1e-2
+    assert rel(xg.grad, xr.grad) < 1e-2
+
+
+# ----------------------------------------------------------------------------- window attention
+def ref_window_attention(qkv, table, rel_index_full, cfg_ws, cfg_ss, nH):
+    """fp32 restatement of roll + partition + WindowAttention3D core + reverse + unroll on a qkv
+    tensor in the natural layout (swin_transformer_3d.py:375-397, 459-476), via the oracle's index helpers."""
+    B, D, H, W, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // nH
+    ws, ss = ix.get_window_size((D, H, W), cfg_ws, cfg_ss)
+    N = ws[0] * ws[1] * ws[2]
+    sh = torch.roll(qkv, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3)) if any(ss) else qkv
+    xw = om._t_window_partition(sh, ws)                                   # [B_, N, 3C]
+    B_ = xw.shape[0]
+    q, k, v = xw.reshape(B_, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    idx = torch.from_numpy(rel_index_full[:N, :N].reshape(-1).copy())
+    bias = table[idx].reshape(N, N, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if any(ss):
+        mask = torch.from_numpy(ix.compute_mask(D, H, W, ws, ss))
+        nW = mask.shape[0]
+        attn = attn.view(B_ // nW, nW, nH, N, N) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, nH, N, N)
+    attn = attn.softmax(-1)
+    o = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    o = om._t_window_reverse(o.view(-1, *(ws + (C,))), ws, B, D, H, W)
+    if any(ss):
+        o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
+    return o
+
+
+WIN_CASES = [
+    # (B, D, H, W, C, nH, block shift on?)
+    (2, 4, 14, 14, 96, 3, False),
+    (2, 4, 14, 14, 96, 3, True),
+    (1, 2, 14, 14, 48, 3, True),      # hd 16, N = 98
+    (2, 4, 7, 7, 64, 2, True),        # clamped window, shift zeroed on every axis -> no mask
+    (1, 16, 14, 14, 64, 2, True),     # (8,7,7) window, temporal shift 4, N = 392
+    (1, 4, 14, 14, 128, 2, True),     # hd 64
+]
+
+
+@pytest.mark.parametrize('case', WIN_CASES)
+def test_window_attention(case):
+    from clover_amd.backbones.swin_transformer_3d import window_geometry, gathered_bias
+    B, D, H, W, C, nH, shifted = case
+    cfg_ws, cfg_ss = (8, 7, 7), ((4, 3, 3) if shifted else (0, 0, 0))
+    qkv = rnd(B, D, H, W, 3 * C, seed=11).to(BF)
+    table = rnd((2 * 8 - 1) * 13 * 13, nH, scale=0.5, seed=12)
+    do = rnd(B, D, H, W, C, seed=13).to(BF)
+    rpi = ix.relative_position_index(cfg_ws)
+    qr = qkv.float().requires_grad_()
+    tr = table.clone().requires_grad_()
+    o_ref = ref_window_attention(qr, tr, rpi, cfg_ws, cfg_ss, nH)
+    o_ref.backward(do.float())
+
+    ws, ss, rid = window_geometry((D, H, W), cfg_ws, cfg_ss, DEV)
+    qg = qkv.to(DEV).requires_grad_()
+    tg = table.to(DEV).requires_grad_()
+    rpi_t = torch.from_numpy(rpi).to(DEV)
+    bias = gathered_bias(tg, rpi_t, ws[0] * ws[1] * ws[2])
+    o = ops().window_attention(qg, bias, rid, ws, ss, nH)
+    o.backward(do.to(DEV))
+    assert rel(o, o_ref) < 2e-2, rel(o, o_ref)
+    assert rel(qg.grad, qr.grad) < 3e-2, rel(qg.grad, qr.grad)
+    assert rel(tg.grad, tr.grad) < 3e-2, rel(tg.grad, tr.grad)
+
+
+# ----------------------------------------------------------------------------- sequence attention
+@pytest.mark.parametrize('B,S,nH,hd', [(3, 16, 2, 64), (2, 32, 12, 64), (2, 228, 12, 64), (2, 40, 4, 32), (1, 408, 2, 64)])
+def test_seq_attention(B, S, nH, hd):
+    Hd = nH * hd
+    qkv = rnd(B, S, 3 * Hd, seed=21).to(BF)
+    do = rnd(B, S, Hd, seed=22).to(BF)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[0, S - 5:] = 0
+    ext = om.extended_mask(mask)                                           # [B,1,1,S]
+    qr = qkv.float().requires_grad_()
+    q, k, v = qr.view(B, S, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    p = (q @ k.transpose(-1, -2) / hd ** 0.5 + ext).softmax(-1)
+    o_ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, Hd)
+    o_ref.backward(do.float())
+    qg = qkv.to(DEV).requires_grad_()
+    o = ops().seq_attention(qg, ext.reshape(B, S).to(DEV).contiguous(), nH)
+    o.backward(do.to(DEV))
+    assert rel(o, o_ref) < 2e-2, rel(o, o_ref)
+    assert rel(qg.grad, qr.grad) < 3e-2, rel(qg.grad, qr.grad)
+
+
+# ----------------------------------------------------------------------------- patch embed
+@pytest.mark.parametrize('C,B,T,HW', [(48, 2, 4, 112), (96, 2, 8, 56), (128, 1, 4, 56)])
+def test_patch_embed(C, B, T, HW):
+    x = rnd(B, 3, T, HW, HW, seed=31)
+    P = {'proj.weight': rnd(C, 3, 2, 4, 4, scale=0.1, seed=32), 'proj.bias': 0.1 * rnd(C, seed=33),
+         'norm.weight': 1 + 0.1 * rnd(C, seed=34), 'norm.bias': 0.1 * rnd(C, seed=35)}
+    mt = rnd(1, C, 1, 1, 1, scale=0.3, seed=36)
+    vm = (rnd(B, 1, 7, 7, seed=37) > 0.5).long()
+    Pr = {k: v.clone().requires_grad_() for k, v in P.items()}
+    mtr = mt.clone().requires_grad_()
+    cfg = dict(patch_size=(2, 4, 4), embed_dim=C, patch_norm=True)
+    y = om.patch_embed(Pr, '', x, cfg)                                      # [B,C,T',H',W']
+    Tp, Hp = y.shape[2], y.shape[3]
+    w = torch.from_numpy(ix.mask_blend_weight(vm.numpy(), Tp, Hp, Hp)).float()
+    ym = y * (1. - w) + mtr.expand(B, -1, Tp, Hp, Hp) * w
+    g1 = rnd(*y.shape, seed=38).to(BF).float()
+    g2 = rnd(*y.shape, seed=39).to(BF).float()
+    ((y * g1).sum() + (ym * g2).sum()).backward()
+
+    Pg = {k: v.to(DEV).requires_grad_() for k, v in P.items()}
+    mtg = mt.to(DEV).requires_grad_()
+    clean, masked = ops().patch_embed(x.to(DEV), Pg['proj.weight'], Pg['proj.bias'], Pg['norm.weight'],
+                                      Pg['norm.bias'], mtg, vm.to(DEV))
+    assert rel(clean.permute(0, 4, 1, 2, 3), y) < 2e-2
+    assert rel(masked.permute(0, 4, 1, 2, 3), ym) < 2e-2
+    ((clean.float() * g1.to(DEV).permute(0, 2, 3, 4, 1)).sum() + (masked.float() * g2.to(DEV).permute(0, 2, 3, 4, 1)).sum()).backward()
+    for k in P:
+        assert rel(Pg[k].grad, Pr[k].grad) < 3e-2, (k, rel(Pg[k].grad, Pr[k].grad))
+    assert rel(mtg.grad, mtr.grad) < 2e-2
+
+
+# ----------------------------------------------------------------------------- losses
+@pytest.mark.parametrize('dtype', [torch.float32, BF])
+def test_focal_ce(dtype):
+    R, V = 37, 30522
+    logits = rnd(R, V, scale=2.0, seed=41).to(dtype).clone()
+    labels = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(42))
+    labels[::3] = -100
+    rows = torch.where(labels != -100)[0]
+    lr = logits.detach().float().clone().requires_grad_()
+    loss_ref = om.focal_loss_multiclass(lr[rows], labels[rows], 2.0)
+    loss_ref.backward()
+    lg = logits.detach().to(DEV).requires_grad_()
+    loss = ops().focal_ce_masked(lg, labels.to(DEV), 2.0)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1, abs(loss_ref.item()))
+    assert rel(lg.grad, lr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('G', [1, 2, 8, 64, 200])
+def test_infonce(G):
+    Dm = 768 if G > 2 else 128
+    es = [rnd(G, Dm, seed=50 + k) for k in range(4)]
+    # make positives close so that the ranking hinge is active for some rows and not others
+    es[1] = es[0] * 0.7 + es[1] * 0.5
+    es[2] = es[0] * 0.6 + es[2] * 0.6
+    er = [e.clone().requires_grad_() for e in es]
+    l = om.exclusive_nce_rank_loss(*er, temperature=0.05, margin=5.0, gather=False)
+    (l['nce_loss'] * 1.3 + l['rank_t_tm_loss'] * 0.7).backward()
+    eg = [e.to(DEV).requires_grad_() for e in es]
+    nce, rank = ops().exclusive_infonce_rank(*eg, 0.05, 5.0)
+    (nce * 1.3 + rank * 0.7).backward()
+    assert abs(nce.item() - l['nce_loss'].item()) < 2e-4 * max(1, abs(l['nce_loss'].item())), (nce.item(), l['nce_loss'].item())
+    assert abs(rank.item() - l['rank_t_tm_loss'].item()) < 2e-4 * max(1, abs(l['rank_t_tm_loss'].item()))
+    for k in range(4):
+        if er[k].grad.abs().max() > 0:
+            assert rel(eg[k].grad, er[k].grad) < 2e-3, (k, rel(eg[k].grad, er[k].grad))
+
+
+# ----------------------------------------------------------------------------- optimizer
+def test_adamw_and_clip():
+    n = 100003
+    p0 = rnd(n, seed=61)
+    grads = [rnd(n, scale=s, seed=62 + i) for i, s in enumerate([1.0, 30.0, 0.1])]
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.005)
+    pg = p0.clone().to(DEV)
+    pad = (-n) % 4
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    sh = torch.zeros(n + pad, device=DEV, dtype=BF)
+    for step, g in enumerate(grads, 1):
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 15.0)
+        opt.step()
+        gg = g.to(DEV)
+        acc = torch.zeros(1, device=DEV)
+        ops().sumsq_accumulate(gg, acc)
+        assert abs(acc.item() - (g.double() ** 2).sum().item()) < 1e-3 * (g.double() ** 2).sum().item()
+        ops().adamw_step(pg, gg, m, v, sh, acc, 1e-2, 0.9, 0.98, 1e-8, 0.005, step, 15.0)
+    assert rel(pg, pr.data) < 1e-5
+    assert rel(sh[:n].float(), pr.data) < 1e-2
+    # non-finite grad norm -> step skipped
+    before = pg.clone()
+    acc = torch.full((1,), float('inf'), device=DEV)
+    ops().adamw_step(pg, grads[0].to(DEV), m, v, sh, acc, 1e-2, 0.9, 0.98, 1e-8, 0.005, 4, 15.0)
+    assert torch.equal(before, pg)
