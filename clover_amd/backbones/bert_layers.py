@@ -106,7 +106,7 @@ class BertSelfAttention(nn.Module):
     def forward(self, x, kmask):
         w = torch.cat([self.query.weight, self.key.weight, self.value.weight], dim=0)
         b = torch.cat([self.query.bias, self.key.bias, self.value.bias], dim=0)
-        qkv = F.linear(to_bf16(x), to_bf16(w), to_bf16(b))
+        qkv = ops.linear(x, w, b)
         return ops.seq_attention(qkv.contiguous(), kmask, self.num_attention_heads)
 
 

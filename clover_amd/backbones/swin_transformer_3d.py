@@ -92,15 +92,33 @@ def window_geometry(x_size, cfg_ws, cfg_ss, device):
     return ws, ss, rid
 
 
+class _GatherBias(torch.autograd.Function):
+    """table[idx] -> [nH, N, Npad]; backward = index_add_ (atomics) of the kernel's dbias into the
+    2535-row table — torch's generic advanced-indexing backward sorts the 38 416 indices every call."""
+
+    @staticmethod
+    def forward(ctx, table, idx_flat, N):
+        nH = table.shape[1]
+        npad = (N + 15) // 16 * 16
+        b = table.float().index_select(0, idx_flat).view(N, N, nH).permute(2, 0, 1)
+        out = table.new_zeros((nH, N, npad), dtype=torch.float32)
+        out[:, :, :N] = b
+        ctx.save_for_backward(idx_flat)
+        ctx.meta = (table.shape, table.dtype, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dbias):
+        (idx_flat,) = ctx.saved_tensors
+        shape, dtype, N = ctx.meta
+        d = dbias[:, :, :N].permute(1, 2, 0).reshape(N * N, shape[1])
+        dtable = torch.zeros(shape, device=dbias.device, dtype=torch.float32).index_add_(0, idx_flat, d)
+        return dtable.to(dtype), None, None
+
+
 def gathered_bias(table, rel_index, N):
-    """table[index[:N,:N]] -> fp32 [nH, N, Npad] (Npad = N rounded up to 16), reference :382-384.
-    Plain torch gather: autograd scatters the kernel's dbias back into the 2535-row table."""
-    nH = table.shape[1]
-    b = table.float()[rel_index[:N, :N].reshape(-1)].reshape(N, N, nH).permute(2, 0, 1)
-    npad = (N + 15) // 16 * 16
-    if npad != N:
-        b = F.pad(b, (0, npad - N))
-    return b.contiguous()
+    """table[index[:N,:N]] -> fp32 [nH, N, Npad] (Npad = N rounded up to 16), reference :382-384."""
+    return _GatherBias.apply(table, rel_index[:N, :N].reshape(-1).contiguous(), N)
 
 
 def mask_blend_weight(mask, T, H, W):

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
-    bf16_t* __restrict__ dq, float* __restrict__ dbias, float* __restrict__ dsum, Geom G) {
+    bf16_t* __restrict__ dq, bf16_t* __restrict__ ds_out, float* __restrict__ dsum, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         if (qv && lg == 0) dsum[li] = dsm;
         const float L = qv ? lse[li] : 0.f;
         const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
-        float* dbrow = (dbias && qv) ? dbias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        bf16_t* dsrow = (ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
         const int rq = (rid && qv) ? rid_s[nq] : 0;
 
         Frag8 dsf[NKT / 2];
@@ -291,10 +291,14 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
                 else if (kmask) s += aux[key];
                 const float pr = (key < N && qv) ? __expf(s - L) : 0.f;
                 ds[r] = pr * (pacc[r] - dsm);
-                if (dbrow && key < N) atomicAdd(dbrow + key, ds[r]);
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
             dsf[t >> 1].u[(t & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
+            // per-(window, head) dS goes to a bf16 scratch; dbias = sum over windows is a separate
+            // streaming reduction (dbias_reduce_kernel) instead of N*N atomics per block
+            if (dsrow && key0 < G.g.bias_ld)
+                *reinterpret_cast<uint2*>(dsrow + key0) =
+                    make_uint2(dsf[t >> 1].u[(t & 1) * 2 + 0], dsf[t >> 1].u[(t & 1) * 2 + 1]);
         }
         f32x4_t qacc[NC];
 #pragma unroll
@@ -432,6 +436,24 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     }
 }
 
+// dbias[e] += sum_g ds[g][e]   (e over nH*N*bias_ld, 8 elements per thread, groups split over y)
+__global__ void __launch_bounds__(256) dbias_reduce_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbias,
+                                                           int64_t E8, int groups) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= E8) return;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int g = blockIdx.y; g < groups; g += gridDim.y) {
+        Frag8 v;
+        v.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)g * E8 + c) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v.h[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dbias + c * 8 + e, acc[e]);
+}
+
 // ------------------------------------------------------------------------- host side
 bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (!g) return false;
@@ -485,7 +507,7 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                const float* lse, const float* bias, const int32_t* rid, const float* kmask, void* dq,
-               void* dk, void* dv, float* dbias, float* dsum, const Geom& G, hipStream_t st) {
+               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const Geom& G, hipStream_t st) {
     const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     static bool attr = false;
@@ -499,9 +521,20 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const int nblk = G.g.groups * G.g.nH;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_a, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
-                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dbias, dsum, G);
+                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, (bf16_t*)(bias ? ds_scratch : nullptr), dsum, G);
     int rc = clv_check_launch();
     if (rc) return rc;
+    if (bias) {
+        const int64_t E8 = (int64_t)G.g.nH * G.g.N * G.g.bias_ld / 8;
+        const int xb = (int)((E8 + 255) / 256);
+        int splits = 1024 / (xb > 0 ? xb : 1);
+        if (splits < 1) splits = 1;
+        if (splits > G.g.groups) splits = G.g.groups;
+        hipLaunchKernelGGL(dbias_reduce_kernel, dim3(xb, splits), dim3(256), 0, st, (const bf16_t*)ds_scratch, dbias,
+                           E8, G.g.groups);
+        rc = clv_check_launch();
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_b, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse,
                        dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, G);
@@ -544,15 +577,15 @@ extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o
 
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                             const float* lse, const float* bias, const int32_t* rid, const float* kmask,
-                            void* dq, void* dk, void* dv, float* dbias, float* dsum,
+                            void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
                             const ClvAttnGeom* geom, void* stream) {
     Geom G;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
-    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias)) return CLV_ERR_ARG;
+    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st) }
-    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st)
 }

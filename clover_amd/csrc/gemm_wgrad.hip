@@ -1,0 +1,157 @@
+// Weight / bias gradient of a Linear layer for the token-parallel (huge-M, small N x K) shapes of
+// the Swin stages and the patch embedding:
+//       dW[n][k] += sum_m dY[m][n] * X[m][k]        db[n] += sum_m dY[m][n]
+// A library GEMM tiles the N x K OUTPUT (e.g. 288 x 96 -> ~10 workgroups on 256 CUs) and walks
+// M = 200 704 serially.  Here the contraction dimension is split over the whole chip: every
+// workgroup owns a 128 x 128 output tile for one M-slice, streams dY and X once (16-B coalesced
+// rows into LDS), feeds both MFMA operands with LDS transpose reads (the contraction index m runs
+// along the ROWS of both tiles), and writes an fp32 partial; a second streaming kernel folds the
+// partials into dW/db.  HBM-bound: algorithmic bytes = M (N + K) * 2.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int TN = 128, TK = 128, TM = 32, LD = 128 + 8;
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr4(const bf16_t* base, int row0, int c0, int lr) {
+    const bf16_t* p = base + (row0 + (lr >> 2)) * LD + c0 + (lr & 3) * 4;
+    const v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+    union { v4s_t v; uint2 u; } cv;
+    cv.v = r;
+    return cv.u;
+}
+
+__device__ __forceinline__ void load_tile(bf16_t* dst, const bf16_t* __restrict__ src, int64_t m0, int64_t m_end,
+                                          int c0, int ncols, int ld, int tid) {
+    // 32 rows x 128 cols, 16-B chunks; rows >= m_end and cols >= ncols are zero
+    for (int idx = tid; idx < TM * (128 / 8); idx += WG_THREADS) {
+        const int r = idx >> 4, c8 = idx & 15;
+        const int64_t m = m0 + r;
+        const int c = c0 + c8 * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < m_end && c < ncols) v = *reinterpret_cast<const uint4*>(src + m * ld + c);   // ncols % 8 == 0
+        *reinterpret_cast<uint4*>(dst + r * LD + c8 * 8) = v;
+    }
+}
+
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           float* __restrict__ partial, float* __restrict__ pbias,
+                                                           int64_t M, int N, int K, int ldy, int ldx, int tilesK,
+                                                           int64_t rows_per_split) {
+    __shared__ __attribute__((aligned(16))) bf16_t dYs[TM * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[TM * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tn = tile / tilesK, tk = tile - tn * tilesK;
+    const int n0 = tn * TN, k0 = tk * TK;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;            // this wave's 64 x 64 sub-tile
+    const int64_t m_begin = (int64_t)split * rows_per_split;
+    int64_t m_end = m_begin + rows_per_split;
+    if (m_end > M) m_end = M;
+    const bool do_bias = pbias && tk == 0 && wk == 0;
+
+    f32x4_t acc[4][4];
+    f32x4_t bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    Frag8 ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;      // bf16 1.0 pairs
+
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += TM) {
+        __syncthreads();
+        load_tile(dYs, dy, m0, m_end, n0, N, ldy, tid);
+        load_tile(Xs, x, m0, m_end, k0, K, ldx, tid);
+        __syncthreads();
+        Frag8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i].u2[0] = tr4(dYs, lg * 4, wn + i * 16, lr);            // A[n][kappa] = dY[m(kappa)][n]
+            a[i].u2[1] = tr4(dYs, 16 + lg * 4, wn + i * 16, lr);
+            b[i].u2[0] = tr4(Xs, lg * 4, wk + i * 16, lr);             // B[kappa][k] = X[m(kappa)][k]
+            b[i].u2[1] = tr4(Xs, 16 + lg * 4, wk + i * 16, lr);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            if (do_bias) bacc[i] = mfma16(a[i], ones, bacc[i]);
+        }
+    }
+    // acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]
+    float* pw = partial + (int64_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn + i * 16 + lg * 4 + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + j * 16 + lr;
+                if (k < K) pw[(int64_t)n * K + k] = acc[i][j][r];
+            }
+            if (do_bias && lr == 0) pbias[(int64_t)split * N + n] = bacc[i][r];
+        }
+}
+
+// out[e] += sum_s partial[s][e]
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int64_t E, int splits) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += partial[(int64_t)s * E + e];
+    out[e] += a;
+}
+
+int pick_splits(int64_t M, int tiles) {
+    int64_t s = (768 + tiles - 1) / tiles;             // ~3 workgroups per CU
+    const int64_t max_by_rows = (M + 255) / 256;        // >= 256 rows per slice
+    if (s > max_by_rows) s = max_by_rows;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K) {
+    const int tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
+    const int splits = pick_splits(M, tiles);
+    return (int64_t)splits * ((int64_t)N * K + N);
+}
+
+extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
+                                int32_t N, int32_t K, int32_t ldy, int32_t ldx, void* stream) {
+    if (!dy || !x || !dw || !work || M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (ldy & 7) || (ldx & 7))
+        return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int tilesN = (N + TN - 1) / TN, tilesK = (K + TK - 1) / TK;
+    const int tiles = tilesN * tilesK;
+    const int splits = pick_splits(M, tiles);
+    int64_t rows = (M + splits - 1) / splits;
+    rows = (rows + TM - 1) / TM * TM;
+    float* partial = work;
+    float* pbias = db ? work + (int64_t)splits * N * K : nullptr;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(WG_THREADS), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)x, partial, pbias, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    const int64_t E = (int64_t)N * K;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, partial, dw, E, splits);
+    rc = clv_check_launch();
+    if (rc) return rc;
+    if (db) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pbias, db,
+                           (int64_t)N, splits);
+        rc = clv_check_launch();
+    }
+    return rc;
+}

@@ -181,17 +181,33 @@ __global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dgamma[c] = sum_i partial[0][i][c], dbeta[c] = sum_i partial[1][i][c].  Block = 64 channels x 16
+// row-splits (1024 threads): coalesced 256-B row reads, 16-way split of the nblk loop, LDS tree.
+__global__ void __launch_bounds__(1024) ln_bwd_reduce_kernel(const float* __restrict__ partial,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int nblk, int C) {
+    __shared__ float sa[16][64], sb[16][64];
+    const int cl = threadIdx.x & 63, sp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblk; ++i) {
-        a += partial[(int64_t)i * C + c];
-        b += partial[((int64_t)nblk + i) * C + c];
+    if (c < C) {
+        for (int i = sp; i < nblk; i += 16) {
+            a += partial[(int64_t)i * C + c];
+            b += partial[((int64_t)nblk + i) * C + c];
+        }
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    sa[sp][cl] = a;
+    sb[sp][cl] = b;
+    __syncthreads();
+    if (sp == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            a += sa[k][cl];
+            b += sb[k][cl];
+        }
+        dgamma[c] = a;
+        dbeta[c] = b;
+    }
 }
 
 int ln_iters(int C) {
@@ -321,7 +337,7 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
     }
     int rc = clv_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, dgamma, dbeta,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, dgamma, dbeta,
                        grid, (int)C);
     return clv_check_launch();
 }

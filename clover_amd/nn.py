@@ -21,7 +21,7 @@ def to_bf16(t):
 
 class Linear(nn.Linear):
     def forward(self, x):
-        return F.linear(to_bf16(x), to_bf16(self.weight), to_bf16(self.bias) if self.bias is not None else None)
+        return ops.linear(x, self.weight, self.bias)
 
 
 class LinearFP32(nn.Linear):

@@ -94,6 +94,69 @@ def roofline_from_prof(prof, steps):
     return roof, table
 
 
+# --------------------------------------------------------------------------- Linear
+def _wgrad_custom(M, N, K):
+    """Token-parallel shapes (huge M, small N x K): the library GEMM under-fills the chip."""
+    return M >= 2048 and N * K <= (1 << 20) and N % 8 == 0 and K % 8 == 0
+
+
+def linear_wgrad(dy2, x2, want_bias):
+    """(dW fp32 [N,K], db fp32 [N] | None) of y = x W^T + b for bf16 dy2 [M,N], x2 [M,K]."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if _wgrad_custom(M, N, K):
+        L = _lib.lib()
+        dw = torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
+        db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if want_bias else None
+        work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
+        check(L.clv_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0),
+                                 x2.stride(0), _stream()), 'clv_linear_wgrad')
+        return dw, db
+    dw = torch.mm(dy2.t(), x2).float()
+    db = dy2.sum(0, dtype=torch.float32) if want_bias else None
+    return dw, db
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b with fp32 master parameters and bf16 MFMA operands.  The forward and the
+    input-gradient GEMMs are plain library GEMMs (hipBLASLt through torch); the weight/bias
+    gradient of the token-parallel layers is the split-M HIP kernel (clv_linear_wgrad) and comes
+    back in fp32 directly (no bf16 rounding of dW, no separate bias-reduction kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight)
+        xb = x if x.dtype == BF16 else x.to(BF16)
+        wb = weight.to(BF16)
+        bb = bias.to(BF16) if bias is not None else None
+        y = torch.nn.functional.linear(xb, wb, bb)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = bias is not None
+        ctx.wdtype = weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        N, K = wb.shape
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dy2 = _c(dy2)
+        x2 = _c(xb.reshape(-1, K))
+        dx = torch.mm(dy2, wb).view(xb.shape) if ctx.needs_input_grad[0] else None
+        dw, db = (None, None)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = linear_wgrad(dy2, x2, ctx.has_bias)
+            dw = dw.to(ctx.wdtype)
+            db = db.to(ctx.wdtype) if db is not None else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
 # --------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
@@ -213,12 +276,15 @@ class _Attention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias) if bias is not None else None
         dsum = torch.empty_like(lse)
+        ds_scratch = (torch.empty(g.groups * g.nH * g.N * g.bias_ld, device=qkv.device, dtype=BF16)
+                      if bias is not None else None)
         b, d = qkv.data_ptr(), dqkv.data_ptr()
         with _Timed(f'attn_bwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, True)):
             check(_lib.lib().clv_attn_bwd(C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim),
                                           _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(rid), _ptr(kmask),
                                           C.c_void_p(d), C.c_void_p(d + 2 * Cdim), C.c_void_p(d + 4 * Cdim),
-                                          _ptr(dbias), _ptr(dsum), C.byref(g), _stream()), 'clv_attn_bwd')
+                                          _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), C.byref(g), _stream()),
+                  'clv_attn_bwd')
         return dqkv, dbias, None, None, None
 
 
@@ -314,8 +380,8 @@ class _PatchEmbed(torch.autograd.Function):
             dz, dg, db = dyb, None, None
         patches = torch.empty(M, 96, device=xc.device, dtype=BF16)
         check(L.clv_im2col_patches(_ptr(xc), _ptr(patches), B, T, H, W, _stream()), 'clv_im2col_patches')
-        dw = torch.mm(dz.t(), patches).float().reshape(wshape)
-        dbias = dz.float().sum(0)
+        dw, dbias = linear_wgrad(dz, patches, True)
+        dw = dw.reshape(wshape)
         return None, dw, dbias, dg, db, dmt, None, None, None
 
 

@@ -63,10 +63,12 @@ int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  const ClvAttnGeom* geom_host, void* stream);
 
 /* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float, same shape as bias)
- * is ACCUMULATED into (caller zeroes).  dsum: float scratch [groups][nH][N]. */
+ * is ACCUMULATED into (caller zeroes).  dsum: float scratch [groups][nH][N].
+ * ds_scratch: bf16 scratch [groups][nH][N][bias_ld] (per-window dS, reduced over windows
+ * into dbias by a streaming kernel); required iff bias != NULL. */
 int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                  const float* lse, const float* bias, const int32_t* rid, const float* kmask,
-                 void* dq, void* dk, void* dv, float* dbias, float* dsum,
+                 void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
                  const ClvAttnGeom* geom_host, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm
@@ -109,6 +111,17 @@ int clv_patch_embed_fwd(const float* x, const void* w, const float* bias, const 
  * of the weight-gradient GEMM dW = dZ^T * patches (the conv3d weight grad of :681). */
 int clv_im2col_patches(const float* x, void* patches, int32_t B, int32_t T, int32_t H, int32_t W,
                        void* stream);
+
+/* ------------------------------------------------------------------ Linear weight/bias gradient
+ * dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] — the weight gradient of every
+ * token-parallel nn.Linear on the path (qkv/proj/fc1/fc2/reduction, swin_transformer_3d.py:257-259,
+ * 361-363,518; the conv3d weight of :665 through clv_im2col_patches) for huge M and small N x K,
+ * where the contraction (token) dimension is split over the whole chip.  dy bf16 [M][N] (row stride
+ * ldy), x bf16 [M][K] (row stride ldx); dw float [N][K], db float [N] or NULL — both ACCUMULATED
+ * into.  N, K, ldy, ldx multiples of 8.  work: float scratch, clv_linear_wgrad_work_floats(). */
+int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K);
+int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
+                     int32_t N, int32_t K, int32_t ldy, int32_t ldx, void* stream);
 
 /* ------------------------------------------------------------------ focal MLM loss
  * SoftmaxFocalLossMultiClass.forward (mmaction/models/losses/focal_loss.py:61-72) on the

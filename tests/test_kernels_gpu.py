@@ -263,3 +263,22 @@ def test_adamw_and_clip():
     acc = torch.full((1,), float('inf'), device=DEV)
     ops().adamw_step(pg, grads[0].to(DEV), m, v, sh, acc, 1e-2, 0.9, 0.98, 1e-8, 0.005, 4, 15.0)
     assert torch.equal(before, pg)
+
+
+# ----------------------------------------------------------------------------- linear weight grad
+@pytest.mark.parametrize('M,N,K', [(50176, 288, 96), (12544, 96, 384), (4096, 1152, 384), (3000, 96, 96), (777, 3072, 768)])
+def test_linear_and_wgrad(M, N, K):
+    x = rnd(M, K, seed=71).to(BF)
+    w = rnd(N, K, scale=0.05, seed=72)
+    b = rnd(N, scale=0.1, seed=73)
+    dy = rnd(M, N, seed=74).to(BF)
+    xr, wr, br = x.float().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.linear(xr, wr.to(BF).float(), br.to(BF).float())
+    yr.backward(dy.float())
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops().linear(xg, wg, bg)
+    y.backward(dy.to(DEV))
+    assert rel(y, yr) < 1e-2
+    assert rel(xg.grad, xr.grad) < 1e-2
+    assert rel(wg.grad, wr.grad) < 5e-3, rel(wg.grad, wr.grad)
+    assert rel(bg.grad, br.grad) < 5e-3, rel(bg.grad, br.grad)
