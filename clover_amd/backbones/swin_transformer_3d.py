@@ -224,7 +224,9 @@ class PatchMerging(nn.Module):
         self.reduction = Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
-    def forward(self, x):
+    @staticmethod
+    def merge_gather(x):
+        """[B,D,H,W,C] -> [B,D,H/2,W/2,4C] in the reference's concat order (:531-539)."""
         B, D, H, W, C = x.shape
         if (H % 2 == 1) or (W % 2 == 1):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
@@ -232,8 +234,10 @@ class PatchMerging(nn.Module):
         x1 = x[:, :, 1::2, 0::2, :]
         x2 = x[:, :, 0::2, 1::2, :]
         x3 = x[:, :, 1::2, 1::2, :]
-        x = torch.cat([x0, x1, x2, x3], -1)
-        return self.reduction(self.norm(x))
+        return torch.cat([x0, x1, x2, x3], -1)
+
+    def forward(self, x):
+        return self.reduction(self.norm(self.merge_gather(x)))
 
 
 class BasicLayer(nn.Module):

@@ -101,14 +101,23 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
         }
 }
 
-// out[e] += sum_s partial[s][e]
-__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int64_t E, int splits) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+// out[e] += sum_s partial[s][e].  Block = 64 consecutive e x 16 split-lanes (1024 threads):
+// coalesced 256-B reads, the splits loop is 16-way parallel, LDS tree at the end.
+__global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int64_t E, int splits) {
+    __shared__ float sh[16][64];
+    const int el = threadIdx.x & 63, sp = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
     float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += partial[(int64_t)s * E + e];
-    out[e] += a;
+    if (e < E)
+        for (int s = sp; s < splits; s += 16) a += partial[(int64_t)s * E + e];
+    sh[sp][el] = a;
+    __syncthreads();
+    if (sp == 0 && e < E) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) a += sh[k][el];
+        out[e] += a;
+    }
 }
 
 int pick_splits(int64_t M, int tiles) {
@@ -145,11 +154,11 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     int rc = clv_check_launch();
     if (rc) return rc;
     const int64_t E = (int64_t)N * K;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, partial, dw, E, splits);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, partial, dw, E, splits);
     rc = clv_check_launch();
     if (rc) return rc;
     if (db) {
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pbias, db,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, pbias, db,
                            (int64_t)N, splits);
         rc = clv_check_launch();
     }

@@ -23,6 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
+from .utils.grad_reducer import BucketedGradReducer
 
 
 def paramwise_weight_decay(model, base_wd, norm_decay_mult=0.0, bias_decay_mult=0.0, custom_keys=None):
@@ -121,46 +122,8 @@ class CloverEngine:
         self.num_params = sum(p.numel() for _, p in used)
 
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
-        self._buckets = []          # (segment, start, end, n_params)
-        self._pending = []
-        self._handles = []
-        if self.world > 1:
-            cap = bucket_mb * 1024 * 1024 // 4
-            for seg in self.segments:
-                start, count = 0, 0
-                for i, p in enumerate(seg.params):
-                    count += 1
-                    end = seg.offsets[i + 1]
-                    if end - start >= cap or i == len(seg.params) - 1:
-                        self._buckets.append([seg, start, end, count])
-                        b = len(self._buckets) - 1
-                        for q in seg.params[i + 1 - count:i + 1]:
-                            q.register_post_accumulate_grad_hook(self._make_hook(b))
-                        start, count = end, 0
-            self._reset_pending()
-            self.comm_stream = torch.cuda.Stream(device=device)
-
-    # ------------------------------------------------------------------ gradient exchange
-    def _reset_pending(self):
-        self._pending = [b[3] for b in self._buckets]
-        self._handles = []
-
-    def _make_hook(self, b):
-        def hook(param):
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                seg, s, e, _ = self._buckets[b]
-                # side stream: the all-reduce overlaps the remaining backward kernels
-                self.comm_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.comm_stream):
-                    self._handles.append(dist.all_reduce(seg.flat_g[s:e], async_op=True))
-        return hook
-
-    def _finish_allreduce(self):
-        for h in self._handles:
-            h.wait()
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self._reset_pending()
+        self.reducer = BucketedGradReducer([(seg.flat_g, seg.params, seg.offsets) for seg in self.segments],
+                                           bucket_bytes=bucket_mb << 20)
 
     # ------------------------------------------------------------------ one step
     def current_lr(self):
@@ -171,8 +134,7 @@ class CloverEngine:
         """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
         out = self.model.train_step(batch, None)
         out['loss'].backward()
-        if self.world > 1:
-            self._finish_allreduce()
+        self.reducer.finish()
         self.optimizer_step()
         return out
 

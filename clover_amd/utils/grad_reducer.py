@@ -1,0 +1,71 @@
+"""Bucketed gradient all-reduce over flat buffers, launched from autograd hooks.
+
+The data-parallel exchange of the step: gradients live in a few flat fp32 slabs;
+a bucket is a contiguous slice; when the last gradient of a bucket has been accumulated its
+all-reduce (SUM — the 1/W average is folded into the optimizer kernel) is issued at once, on a
+side HIP stream so RCCL traffic over xGMI overlaps the rest of backward.  Works on CPU tensors
+with gloo as well (no streams), which is how the N>1 path is tested without GPUs."""
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradReducer:
+    def __init__(self, slabs, bucket_bytes=64 << 20):
+        """slabs: list of (flat_grad, params, offsets) with params[i].grad a view of
+        flat_grad[offsets[i]:offsets[i+1]] (in the order backward is expected to fill them)."""
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.buckets = []           # [flat_grad, start, end, n_params]
+        self.handles = []
+        self.pending = []
+        self.comm_stream = None
+        if self.world == 1:
+            return
+        cap = max(1, bucket_bytes // 4)
+        for flat, params, offsets in slabs:
+            start, count = 0, 0
+            for i, p in enumerate(params):
+                count += 1
+                end = offsets[i + 1]
+                if end - start >= cap or i == len(params) - 1:
+                    self.buckets.append([flat, start, end, count])
+                    b = len(self.buckets) - 1
+                    for q in params[i + 1 - count:i + 1]:
+                        q.register_post_accumulate_grad_hook(self._make_hook(b))
+                    start, count = end, 0
+            if flat.is_cuda and self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=flat.device)
+        self.reset()
+
+    def reset(self):
+        self.pending = [b[3] for b in self.buckets]
+        self.handles = []
+
+    def _launch(self, b):
+        flat, s, e, _ = self.buckets[b]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(dist.all_reduce(flat[s:e], async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(flat[s:e], async_op=True))
+
+    def _make_hook(self, b):
+        def hook(param):
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def finish(self):
+        """Wait for every bucket (launching any whose hooks did not all fire, e.g. a parameter that
+        received no gradient this step), then make the compute stream wait for the comm stream."""
+        if self.world == 1:
+            return
+        for b, left in enumerate(self.pending):
+            if left > 0:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()

@@ -1,9 +1,11 @@
 """Closed-form (RNG-free) weights and inputs shared by the golden generator and the
 parity tests, so fixtures only need to hold OUTPUTS (SURVEY.md §8c G-swin note).
 
-Every tensor is a deterministic function of (name, shape): float values are
-scale*sin(golden-ratio*i + phase(name)) computed in float64; integer values come
-from a splitmix64 hash.  Nothing here depends on torch's RNG or on the reference.
+Every tensor is a deterministic function of (name, shape): a splitmix64 hash of
+(crc32(name), flat index) mapped to uniform [-1, 1) (floats, full-rank, RNG-free) or to an
+integer range.  Magnitudes follow real initialisations (weights ~ 1/sqrt(fan_in), embeddings
+0.1, LayerNorm gains 1 +- 0.1) so that attention logits stay O(1-10) as in a trained model.
+Nothing here depends on torch's RNG or on the reference.
 """
 import zlib
 
@@ -66,17 +68,6 @@ def oracle_cfg_from(model_cfg, bert_cfg=TINY_BERT):
         gamma=model_cfg['mlm_loss']['gamma'], vocab=model_cfg['text_vocab_size'])
 
 
-def _phase(name):
-    return (zlib.crc32(name.encode()) % 100003) * 0.01
-
-
-def cf_float(name, shape, scale=1.0, offset=0.0):
-    n = int(np.prod(shape)) if len(shape) else 1
-    i = np.arange(n, dtype=np.float64)
-    v = offset + scale * np.sin(0.6180339887498949 * i * 7.0 + _phase(name))
-    return torch.from_numpy(v.astype(np.float32).reshape(shape))
-
-
 def _splitmix(x):
     x = (x + np.uint64(0x9E3779B97F4A7C15))
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
@@ -84,10 +75,22 @@ def _splitmix(x):
     return x ^ (x >> np.uint64(31))
 
 
+def _hash_u64(name, n):
+    with np.errstate(over='ignore'):
+        return _splitmix(np.arange(n, dtype=np.uint64) + np.uint64(zlib.crc32(name.encode())) * np.uint64(1000003))
+
+
+def cf_float(name, shape, scale=1.0, offset=0.0):
+    """offset + scale * U[-1, 1), value i = hash(name, i)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = (_hash_u64(name, n) >> np.uint64(11)).astype(np.float64) / float(1 << 53)      # [0, 1)
+    v = offset + scale * (2.0 * u - 1.0)
+    return torch.from_numpy(v.astype(np.float32).reshape(shape))
+
+
 def cf_int(name, shape, lo, hi):
     n = int(np.prod(shape))
-    with np.errstate(over='ignore'):
-        h = _splitmix(np.arange(n, dtype=np.uint64) + np.uint64(zlib.crc32(name.encode())) * np.uint64(1000003))
+    h = _hash_u64(name + '#int', n)
     v = lo + (h % np.uint64(hi - lo)).astype(np.int64)
     return torch.from_numpy(v.reshape(shape))
 
@@ -103,11 +106,11 @@ def cf_param(name, shape):
     if 'relative_position_bias_table' in name:
         return cf_float(name, shape, 0.5)
     if 'mask_token' in name or 'vis_space_pos' in name or 'vis_tempor_pos' in name:
-        return cf_float(name, shape, 0.3)
+        return cf_float(name, shape, 0.1)
     if 'embeddings' in name:                            # embedding tables
-        return cf_float(name, shape, 0.3)
+        return cf_float(name, shape, 0.1)
     fan_in = int(np.prod(shape[1:]))
-    return cf_float(name, shape, 1.7 / np.sqrt(fan_in))
+    return cf_float(name, shape, 1.2 / np.sqrt(fan_in))
 
 
 def cf_state(manifest):
@@ -117,7 +120,7 @@ def cf_state(manifest):
 
 def cf_batch(B, frames=4, size=112, L=16, vocab=1024, tag='b', n_pad=3):
     """Synthetic batch in the reference's data_batch format."""
-    imgs = cf_float(f'{tag}.imgs', (B, 1, 3, frames, size, size), 1.0)
+    imgs = cf_float(f'{tag}.imgs', (B, 1, 3, frames, size, size), 1.7)
     ids = cf_int(f'{tag}.ids', (B, 1, L), 5, vocab)
     ids[:, :, 0] = 101
     input_mask = torch.ones(B, 1, L, dtype=torch.long)

@@ -1,0 +1,164 @@
+"""CPU-only checks of the host side: registry / plugin API, state_dict compatibility, the
+index/geometry helpers against the reference goldens (bit-exact), the C ABI surface, and the
+no-CPU-fallback rule."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+import gutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_builds_reference_config_and_state_dict_matches_reference():
+    import clover_amd
+    from clover_amd.builder import MODELS
+    for name in ['SwinTransformer3D', 'BertFromPretrained', 'CrossModalTransformerFromPretrained', 'NCEHeadForMM',
+                 'NCEHeadForVision', 'NCEHeadForText', 'MLMHead', 'ExclusiveNCEwithRankingLoss',
+                 'SoftmaxFocalLossMultiClass', 'CrossEntropyLoss', 'CloverPretrain']:
+        assert name in MODELS, name
+    m = clover_amd.build_model(cf.tiny_model_cfg())
+    sd = m.state_dict()
+    man = gutil.manifest()                     # names/shapes of the REFERENCE model's state_dict
+    assert set(sd) == set(man)
+    for k, shp in man.items():
+        assert list(sd[k].shape) == shp, k
+    assert m.aux_info == cf.AUX and m.fp16_enabled is False
+    with pytest.raises(KeyError):
+        clover_amd.build_backbone(dict(type='NoSuchBackbone'))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1), None, return_loss=True)          # 'Label should not be None.'
+
+
+FS = [(4, 56, 56), (8, 56, 56), (16, 56, 56), (2, 28, 28), (2, 14, 14), (4, 7, 7), (16, 7, 7), (16, 14, 14), (3, 10, 12)]
+
+
+@pytest.mark.parametrize('fs', FS)
+def test_window_geometry_bit_exact(fs):
+    from clover_amd.backbones import swin_transformer_3d as S
+    g = gutil.load('g_idx.npz')
+    tag = '%d_%d_%d' % fs
+    ws, ss = S.get_window_size(fs, (8, 7, 7), (4, 3, 3))
+    assert list(ws) + list(ss) == g['gws_' + tag].tolist()
+    ws2, ss2, rid = S.window_geometry(fs, (8, 7, 7), (4, 3, 3), 'cpu')
+    assert (ws2, ss2) == (ws, ss)
+    mask = g['mask_' + tag]
+    if any(ss):
+        r = rid.numpy()
+        assert r.dtype == np.int32
+        assert np.array_equal((r[:, :, None] != r[:, None, :]).astype(np.int8), mask)
+    else:
+        assert rid is None and not mask.any()
+
+
+def _tok_row(D, H, W, ws, ss, wi, n):
+    """Python transcription of the kernel's token addressing (attention.hip tok_row)."""
+    nWh, nWw = H // ws[1], W // ws[2]
+    wz, wr = divmod(wi, nWh * nWw)
+    wy, wx = divmod(wr, nWw)
+    tz, tr = divmod(n, ws[1] * ws[2])
+    ty, tx = divmod(tr, ws[2])
+    d = (wz * ws[0] + tz + ss[0]) % D
+    h = (wy * ws[1] + ty + ss[1]) % H
+    w = (wx * ws[2] + tx + ss[2]) % W
+    return (d * H + h) * W + w
+
+
+@pytest.mark.parametrize('fs', [(4, 56, 56), (16, 14, 14), (2, 28, 28), (4, 7, 7)])
+def test_kernel_token_addressing_matches_roll_partition(fs):
+    from clover_amd.backbones import swin_transformer_3d as S
+    g = gutil.load('g_idx.npz')
+    ws, ss = S.get_window_size(fs, (8, 7, 7), (4, 3, 3))
+    part = g['part_%d_%d_%d' % fs]                      # reference roll(-shift) + window_partition of arange
+    nW, N = part.shape
+    for wi in list(range(0, nW, max(1, nW // 7))) + [nW - 1]:
+        rows = [_tok_row(fs[0], fs[1], fs[2], ws, ss, wi, n) for n in range(N)]
+        assert rows == part[wi].tolist()
+
+
+def test_relative_position_index_and_blend_and_merge_order():
+    from clover_amd.backbones import swin_transformer_3d as S
+    g = gutil.load('g_idx.npz')
+    for ws in [(8, 7, 7), (4, 7, 7), (2, 7, 7)]:
+        assert np.array_equal(S.build_relative_position_index(ws).numpy(), g['rpi_%d_%d_%d' % ws])
+    w = S.mask_blend_weight(torch.from_numpy(g['blend_mask']), 2, 28, 28)
+    assert np.array_equal(w.numpy().astype(np.int8), g['blend_w'])
+    cat = S.PatchMerging.merge_gather(torch.from_numpy(g['merge_in']))
+    assert np.array_equal(cat.numpy(), g['merge_cat'])
+    tid = torch.from_numpy(g['ssl_token_ids'])[:, 0]
+    lab = torch.from_numpy(g['ssl_mlm_label'])[:, 0]
+    assert np.array_equal(torch.where(lab == -100, tid, lab).numpy(), g['ssl_ids'])
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from clover_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'clover_hip.h')).read()
+    declared = set(re.findall(r'\b(clv_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert _lib.lib().clv_abi_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.ClvAttnGeom) == 20 * 4
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from clover_amd import ops
+    x = torch.randn(4, 96)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.layer_norm(x, torch.ones(96), torch.zeros(96))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.gelu(x)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.linear(x, torch.randn(8, 96), None)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'clover_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_optimizer_param_groups_and_lr_schedule():
+    import clover_amd
+    from clover_amd.engine import cosine_lr, paramwise_weight_decay
+    m = clover_amd.build_model(cf.tiny_model_cfg())
+    wd = paramwise_weight_decay(m, 0.005, 0.0, 0.0, {'absolute_pos_embed': dict(decay_mult=0.),
+                                                    'relative_position_bias_table': dict(decay_mult=0.)})
+    assert wd['backbone.layers.0.blocks.0.attn.relative_position_bias_table'] == 0.0      # custom key
+    assert wd['backbone.layers.0.blocks.0.norm1.weight'] == 0.0                            # norm layer
+    assert wd['backbone.layers.0.blocks.0.attn.qkv.bias'] == 0.0                           # bias
+    assert wd['backbone.layers.0.blocks.0.attn.qkv.weight'] == 0.005
+    assert wd['text_backbone.bert.embeddings.word_embeddings.weight'] == 0.005
+    assert wd['multimodal_backbone.vis_space_pos'] == 0.005
+    base = 1e-3
+    assert abs(cosine_lr(base, 0, 100) - base) < 1e-12
+    assert abs(cosine_lr(base, 100, 100) - base * 1e-3) < 1e-12
+    assert abs(cosine_lr(base, 50, 100) - (base * 1e-3 + 0.5 * (base - base * 1e-3))) < 1e-12
+    lr0 = cosine_lr(base, 0, 1000, warmup_iters=10, warmup_ratio=0.001)
+    assert abs(lr0 - cosine_lr(base, 0, 1000) * 0.001) < 1e-12
+    assert cosine_lr(base, 10, 1000, warmup_iters=10) == cosine_lr(base, 10, 1000)
+
+
+def test_lazy_log_vars_and_parse_losses():
+    from clover_amd.recognizers.base import BaseRecognizer, LazyLogVars
+    lv = LazyLogVars(['a_loss', 'b'], torch.tensor([1.5, 2.0]))
+    assert list(lv.keys()) == ['a_loss', 'b'] and lv['a_loss'] == 1.5 and dict(lv.items())['b'] == 2.0
+
+    class R(BaseRecognizer):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.lazy_log_vars = False
+
+        def forward_train(self, *a, **k):
+            pass
+
+        def forward_test(self, *a, **k):
+            pass
+    loss, log_vars = R()._parse_losses({'mlm_loss': torch.tensor(1.0), 'acc': torch.tensor(0.5),
+                                        'x_loss': [torch.tensor([1.0, 3.0])]})
+    assert float(loss) == 3.0 and log_vars['loss'] == 3.0 and log_vars['acc'] == 0.5     # 'acc' not summed
