@@ -98,11 +98,23 @@ def oracle_cfg(cfg):
                 temperature=0.05, margin=5.0, gamma=2.0, vocab=30522)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
     """The oracle (fp32 CPU restatement of the reference step, parity-pinned to the reference by
     tests/golden) timed on this box's host cores: forward + losses + backward, B = 2."""
     from oracle import model as om
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     P = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
          for k, v in state.items() if 'relative_position_index' not in k}
@@ -111,6 +123,7 @@ def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
     ocfg = oracle_cfg(cfg)
     times = []
     t_start = time.time()
+    warm = None
     for it in range(4):
         t0 = time.time()
         losses = om.forward_train(P, batch, ocfg, gather=False)
@@ -119,14 +132,38 @@ def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
         dt = time.time() - t0
         if it > 0:
             times.append(dt)
+        else:
+            warm = dt
         for p in P.values():
             p.grad = None
-        if time.time() - t_start > budget_s and times:
+        if time.time() - t_start > budget_s:
             break
+    note = 'timed iters after 1 warm-up'
+    if not times:                       # slow host: the warm-up iteration is all the budget allows
+        times, note = [warm], 'iter (the warm-up itself; budget exhausted)'
     per = sum(times) / len(times)
     return dict(value=round(B / per, 4), unit='pairs/s', cores=ncores, kind='port',
                 sample=f'oracle forward_train+backward, fp32, B={B}, {frames}f x 224^2, L={L}, '
-                       f'{len(times)} timed iters after 1 warm-up ({per:.2f} s/iter)')
+                       f'{len(times)} {note} ({per:.2f} s/iter)')
+
+
+def cpu_baseline_subprocess(variant, frames, L, timeout_s=240):
+    """Run the CPU leg in a child process that never touches the GPU (own thread pool, hard
+    timeout) so it cannot stall the GPU process; same seed -> same random-init weights."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--variant', variant,
+           '--frames', str(frames), '--tokens', str(L)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(value=None, unit='pairs/s', cores=usable_cores(), kind='port',
+                    sample='cpu leg failed: ' + (out.stderr.strip().splitlines() or ['?'])[-1][:200])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='pairs/s', cores=usable_cores(), kind='port',
+                    sample=f'cpu leg exceeded {timeout_s} s and was stopped')
 
 
 def main():
@@ -140,7 +177,17 @@ def main():
     ap.add_argument('--variant', default='T', choices=['T', 'B'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:                           # child of cpu_baseline_subprocess(): CPU only
+        import clover_amd
+        torch.manual_seed(1234)
+        cfg = model_cfg(args.variant, args.frames)
+        model = clover_amd.build_model(cfg)
+        state = {k: v.detach() for k, v in model.state_dict().items()}
+        print(json.dumps(cpu_baseline(cfg, state, args.frames, args.tokens)))
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -162,9 +209,6 @@ def main():
     cfg = model_cfg(args.variant, args.frames)
     model = clover_amd.build_model(cfg).to(dev)
     model.train()                                        # dropout / DropPath active, as in training
-    state_cpu = None
-    if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
-        state_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
 
     batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.frames, args.tokens, 1000 + rank).items()}
     engine = CloverEngine(model, batch, lr=5e-5 / 1024 * args.batch * world, weight_decay=0.005, grad_clip=15.0,
@@ -212,8 +256,8 @@ def main():
         }
         if prof:
             res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, args.steps)
-        if state_cpu is not None:
-            res['cpu_baseline'] = cpu_baseline(cfg, state_cpu, args.frames, args.tokens)
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -147,6 +147,17 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
         float p[NKT][4];
         const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
         const int rq = (rid && qv) ? rid_s[nq] : 0;
+        // issue every bias load of this query row up front: one L2 latency instead of NKT serial ones
+        constexpr bool PRE = NKT <= 16;
+        float4 bpre[PRE ? NKT : 1];
+        if (PRE) {
+#pragma unroll
+            for (int t = 0; t < (PRE ? NKT : 1); ++t) {
+                const int key0 = t * 16 + lg * 4;
+                bpre[t] = (brow && key0 < G.g.bias_ld) ? *reinterpret_cast<const float4*>(brow + key0)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -157,7 +168,8 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
             for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
             const int key0 = t * 16 + lg * 4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
+            if (PRE) bv = bpre[PRE ? t : 0];
+            else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
             const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -263,6 +275,16 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         if (qv && lg == 0) dsum[li] = dsm;
         const float L = qv ? lse[li] : 0.f;
         const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        constexpr bool PRE = NKT <= 16;
+        float4 bpre[PRE ? NKT : 1];
+        if (PRE) {
+#pragma unroll
+            for (int t = 0; t < (PRE ? NKT : 1); ++t) {
+                const int key0 = t * 16 + lg * 4;
+                bpre[t] = (brow && key0 < G.g.bias_ld) ? *reinterpret_cast<const float4*>(brow + key0)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         bf16_t* dsrow = (ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
         const int rq = (rid && qv) ? rid_s[nq] : 0;
 
@@ -280,7 +302,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             }
             const int key0 = t * 16 + lg * 4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
+            if (PRE) bv = bpre[PRE ? t : 0];
+            else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
             const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
             float ds[4];
 #pragma unroll

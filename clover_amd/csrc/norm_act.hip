@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(1024) ln_bwd_reduce_kernel(const float* __rest
     const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        for (int i = sp; i < nblk; i += 16) {
+        for (int i = blockIdx.y * 16 + sp; i < nblk; i += 16 * gridDim.y) {
             a += partial[(int64_t)i * C + c];
             b += partial[((int64_t)nblk + i) * C + c];
         }
@@ -205,8 +205,13 @@ __global__ void __launch_bounds__(1024) ln_bwd_reduce_kernel(const float* __rest
             a += sa[k][cl];
             b += sb[k][cl];
         }
-        dgamma[c] = a;
-        dbeta[c] = b;
+        if (gridDim.y == 1) {
+            dgamma[c] = a;
+            dbeta[c] = b;
+        } else {                                       // outputs zeroed by the launcher
+            atomicAdd(dgamma + c, a);
+            atomicAdd(dbeta + c, b);
+        }
     }
 }
 
@@ -312,8 +317,8 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
 
 extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
     (void)C;
-    int64_t b = (rows + LN_WAVES * 4 - 1) / (LN_WAVES * 4);
-    if (b > 512) b = 512;
+    int64_t b = (rows + LN_WAVES - 1) / LN_WAVES;      // one row per wave until the chip is full
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -337,7 +342,12 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
     }
     int rc = clv_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, dgamma, dbeta,
+    const int ysplit = grid >= 256 ? 8 : 1;
+    if (ysplit > 1) {
+        if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess) return CLV_ERR_LAUNCH;
+        if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) return CLV_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64, ysplit), dim3(1024), 0, st, partial, dgamma, dbeta,
                        grid, (int)C);
     return clv_check_launch();
 }

@@ -78,11 +78,15 @@ class _Segment:
         self.flat_g = torch.zeros(n, device=device, dtype=torch.float32)
         self.exp_avg = torch.zeros(n, device=device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=device, dtype=torch.float32)
+        self.shadow = torch.zeros(n, device=device, dtype=torch.bfloat16)      # bf16 compute copy
         for p, off in zip(self.params, self.offsets):
             view = self.flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+            p._clv_grad = p.grad                                                   # sink for ops.linear
+            p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
+        self.shadow.copy_(self.flat_p)
 
 
 class CloverEngine:
@@ -146,7 +150,7 @@ class CloverEngine:
         for seg in self.segments:
             ops.sumsq_accumulate(seg.flat_g, self.sumsq)
         for seg in self.segments:
-            ops.adamw_step(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, None, self.sumsq, lr,
+            ops.adamw_step(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, seg.shadow, self.sumsq, lr,
                            self.betas[0], self.betas[1], self.eps, seg.weight_decay, self.step_count,
                            self.grad_clip if self.grad_clip else 0.0, gscale)
         for seg in self.segments:

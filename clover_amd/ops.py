@@ -100,39 +100,57 @@ def _wgrad_custom(M, N, K):
     return M >= 2048 and N * K <= (1 << 20) and N % 8 == 0 and K % 8 == 0
 
 
-def linear_wgrad(dy2, x2, want_bias):
-    """(dW fp32 [N,K], db fp32 [N] | None) of y = x W^T + b for bf16 dy2 [M,N], x2 [M,K]."""
+def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None):
+    """dW fp32 [N,K] and db fp32 [N] of y = x W^T + b for bf16 dy2 [M,N], x2 [M,K].
+    With dw_out / db_out (fp32, e.g. views of the engine's flat gradient slab) the result is
+    ACCUMULATED into them in place and (None, None) is returned."""
     M, N = dy2.shape
     K = x2.shape[1]
+    sink = dw_out is not None
     if _wgrad_custom(M, N, K):
         L = _lib.lib()
-        dw = torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
-        db = torch.zeros(N, device=dy2.device, dtype=torch.float32) if want_bias else None
+        dw = dw_out if sink else torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
+        db = (db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)) if want_bias else None
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
         check(L.clv_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0),
                                  x2.stride(0), _stream()), 'clv_linear_wgrad')
-        return dw, db
-    dw = torch.mm(dy2.t(), x2).float()
-    db = dy2.sum(0, dtype=torch.float32) if want_bias else None
-    return dw, db
+        return (None, None) if sink else (dw, db)
+    dwb = torch.mm(dy2.t(), x2)
+    if sink:
+        dw_out.add_(dwb)                                    # fp32 += bf16, one kernel
+        if want_bias:
+            db_out.add_(dy2.sum(0, dtype=torch.float32))
+        return None, None
+    return dwb.float(), (dy2.sum(0, dtype=torch.float32) if want_bias else None)
 
 
 class _Linear(torch.autograd.Function):
     """y = x W^T + b with fp32 master parameters and bf16 MFMA operands.  The forward and the
     input-gradient GEMMs are plain library GEMMs (hipBLASLt through torch); the weight/bias
-    gradient of the token-parallel layers is the split-M HIP kernel (clv_linear_wgrad) and comes
-    back in fp32 directly (no bf16 rounding of dW, no separate bias-reduction kernel)."""
+    gradient of the token-parallel layers is the split-M HIP kernel (clv_linear_wgrad), in fp32.
+
+    Engine-managed parameters carry ``_clv_shadow`` (bf16 copy kept fresh by the AdamW kernel — no
+    per-step cast), ``_clv_grad`` (fp32 view of the flat gradient slab — gradients are accumulated
+    there directly, no autograd AccumulateGrad add) and ``_clv_ready`` (bucket countdown of the
+    gradient all-reduce)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         _need_gpu(x, weight)
         xb = x if x.dtype == BF16 else x.to(BF16)
-        wb = weight.to(BF16)
-        bb = bias.to(BF16) if bias is not None else None
+        wb = getattr(weight, '_clv_shadow', None)
+        if wb is None:
+            wb = weight.to(BF16)
+        bb = None
+        if bias is not None:
+            bb = getattr(bias, '_clv_shadow', None)
+            if bb is None:
+                bb = bias.to(BF16)
         y = torch.nn.functional.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.has_bias = bias is not None
         ctx.wdtype = weight.dtype
+        ctx.wref, ctx.bref = weight, bias
         return y
 
     @staticmethod
@@ -147,9 +165,17 @@ class _Linear(torch.autograd.Function):
         dx = torch.mm(dy2, wb).view(xb.shape) if ctx.needs_input_grad[0] else None
         dw, db = (None, None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = linear_wgrad(dy2, x2, ctx.has_bias)
-            dw = dw.to(ctx.wdtype)
-            db = db.to(ctx.wdtype) if db is not None else None
+            wsink = getattr(ctx.wref, '_clv_grad', None)
+            bsink = getattr(ctx.bref, '_clv_grad', None) if ctx.has_bias else None
+            if wsink is not None and (bsink is not None or not ctx.has_bias):
+                linear_wgrad(dy2, x2, ctx.has_bias, wsink, bsink)
+                ctx.wref._clv_ready()
+                if ctx.has_bias:
+                    ctx.bref._clv_ready()
+            else:
+                dw, db = linear_wgrad(dy2, x2, ctx.has_bias)
+                dw = dw.to(ctx.wdtype)
+                db = db.to(ctx.wdtype) if db is not None else None
         return dx, dw, db
 
 

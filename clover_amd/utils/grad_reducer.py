@@ -19,6 +19,9 @@ class BucketedGradReducer:
         self.pending = []
         self.comm_stream = None
         if self.world == 1:
+            for _, params, _ in slabs:
+                for q in params:
+                    q._clv_ready = (lambda: None)
             return
         cap = max(1, bucket_bytes // 4)
         for flat, params, offsets in slabs:
@@ -30,7 +33,9 @@ class BucketedGradReducer:
                     self.buckets.append([flat, start, end, count])
                     b = len(self.buckets) - 1
                     for q in params[i + 1 - count:i + 1]:
-                        q.register_post_accumulate_grad_hook(self._make_hook(b))
+                        hook = self._make_hook(b)
+                        q.register_post_accumulate_grad_hook(hook)
+                        q._clv_ready = (lambda h=hook, t=q: h(t))       # for ops that fill .grad themselves
                     start, count = end, 0
             if flat.is_cuda and self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=flat.device)
