@@ -279,9 +279,8 @@ extern "C" int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64
                                 void* stream) {
     if (!logits || !labels || !row_ce || !row_lse || !loss || !count || rows <= 0 || V <= 0) return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // (loss, count) double as the {sum, count} accumulators; normalised in place by the finish kernel
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return CLV_ERR_LAUNCH;
-    if (hipMemsetAsync(count, 0, sizeof(float), st) != hipSuccess) return CLV_ERR_LAUNCH;
+    // (loss, count) double as the {sum, count} accumulators (caller zeroes both); normalised in place
+    // by the finish kernel
     if (is_bf16)
         hipLaunchKernelGGL((focal_fwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
                            row_ce, row_lse, loss, count, (int)V, gamma);

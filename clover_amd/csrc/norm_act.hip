@@ -205,13 +205,8 @@ __global__ void __launch_bounds__(1024) ln_bwd_reduce_kernel(const float* __rest
             a += sa[k][cl];
             b += sb[k][cl];
         }
-        if (gridDim.y == 1) {
-            dgamma[c] = a;
-            dbeta[c] = b;
-        } else {                                       // outputs zeroed by the launcher
-            atomicAdd(dgamma + c, a);
-            atomicAdd(dbeta + c, b);
-        }
+        atomicAdd(dgamma + c, a);                      // dgamma/dbeta are ACCUMULATED into (caller zeroes)
+        atomicAdd(dbeta + c, b);
     }
 }
 
@@ -342,11 +337,7 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
     }
     int rc = clv_check_launch();
     if (rc) return rc;
-    const int ysplit = grid >= 256 ? 8 : 1;
-    if (ysplit > 1) {
-        if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess) return CLV_ERR_LAUNCH;
-        if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) return CLV_ERR_LAUNCH;
-    }
+    const int ysplit = grid >= 256 ? 8 : 1;      // > 1: atomics into dgamma/dbeta (caller zeroes them)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64, ysplit), dim3(1024), 0, st, partial, dgamma, dbeta,
                        grid, (int)C);
     return clv_check_launch();

@@ -101,6 +101,7 @@ class CloverEngine:
         self.max_iters, self.warmup_iters = max_iters, warmup_iters
         self.min_lr_ratio, self.warmup_ratio = min_lr_ratio, warmup_ratio
         self.step_count = 0
+        self.graph = None
         device = next(model.parameters()).device
         pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                    custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
@@ -136,11 +137,51 @@ class CloverEngine:
 
     def step(self, batch):
         """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
-        out = self.model.train_step(batch, None)
-        out['loss'].backward()
+        if self.graph is not None:
+            for k, v in self._static_batch.items():
+                if batch[k] is not v:
+                    v.copy_(batch[k], non_blocking=True)
+            self.graph.replay()
+            out = dict(self._static_out)
+            lv = self._static_out['log_vars']
+            if hasattr(lv, 'fresh'):
+                out['log_vars'] = lv.fresh()          # re-read the replayed values on next access
+        else:
+            out = self.model.train_step(batch, None)
+            out['loss'].backward()
         self.reducer.finish()
         self.optimizer_step()
         return out
+
+    def capture(self, batch, warmup=2):
+        """Capture forward + backward of the step into one hipGraph (static shapes; the step has no
+        data-dependent shape and no host sync by construction).  ~2400 kernel launches per step
+        become one graph launch, which removes the host-side launch bound.  Single-GPU only for now:
+        with W > 1 the RCCL hooks stay on the eager path."""
+        if self.world > 1:
+            return False
+        self._static_batch = {k: v.clone() for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                out = self.model.train_step(self._static_batch, None)
+                out['loss'].backward()
+                for seg in self.segments:
+                    seg.flat_g.zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        # no autograd graph may survive into the capture: a live one pins the parameters'
+        # AccumulateGrad nodes to the warm-up stream and their accumulation escapes the hipGraph
+        del out
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.model.train_step(self._static_batch, None)
+            out['loss'].backward()
+        for seg in self.segments:
+            seg.flat_g.zero_()                     # the capture pass itself does not execute kernels
+        self.graph, self._static_out = g, out
+        return True
 
     def optimizer_step(self):
         self.step_count += 1

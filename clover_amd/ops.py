@@ -221,8 +221,8 @@ class _LayerNorm(torch.autograd.Function):
         nblk = L.clv_layernorm_bwd_blocks(rows, C_)
         partial = torch.empty(2 * nblk * C_, device=x2.device, dtype=torch.float32)
         dx = torch.empty_like(x2)
-        dg = torch.empty(C_, device=x2.device, dtype=torch.float32)
-        db = torch.empty_like(dg)
+        dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
+        db = torch.zeros_like(dg)
         check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx),
                                   _ptr(dg), _ptr(db), _ptr(partial), rows, C_, int(x2.dtype == torch.float32),
                                   _stream()), 'clv_layernorm_bwd')
@@ -398,8 +398,8 @@ class _PatchEmbed(torch.autograd.Function):
             nblk = L.clv_layernorm_bwd_blocks(M, Cout)
             partial = torch.empty(2 * nblk * Cout, device=xc.device, dtype=torch.float32)
             dz = torch.empty_like(z)
-            dg = torch.empty(Cout, device=xc.device, dtype=torch.float32)
-            db = torch.empty_like(dg)
+            dg = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
+            db = torch.zeros_like(dg)
             check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(dz),
                                       _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, _stream()), 'clv_layernorm_bwd')
         else:
@@ -430,8 +430,8 @@ class _FocalCE(torch.autograd.Function):
         dev = lg.device
         row_ce = torch.empty(rows, device=dev, dtype=torch.float32)
         row_lse = torch.empty_like(row_ce)
-        loss = torch.empty(1, device=dev, dtype=torch.float32)
-        count = torch.empty(1, device=dev, dtype=torch.float32)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        count = torch.zeros(1, device=dev, dtype=torch.float32)
         check(_lib.lib().clv_focal_ce_fwd(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
                                           _ptr(loss), _ptr(count), rows, V, float(gamma), _stream()),
               'clv_focal_ce_fwd')

@@ -27,6 +27,10 @@ class LazyLogVars(OrderedDict):
             OrderedDict.__setitem__(self, n, None)
         self._resolved = False
 
+    def fresh(self):
+        """A new unresolved view of the same device tensor (after a hipGraph replay refreshed it)."""
+        return LazyLogVars(self._names, self._packed)
+
     def _resolve(self):
         if not self._resolved:
             vals = self._packed.detach().float().cpu().tolist()

@@ -81,7 +81,7 @@ int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const 
                       void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
                       int32_t is_f32, void* stream);
 /* dx [rows][C] (gradient wrt x and, identically, wrt res); dgamma,dbeta float [C]
- * (overwritten); partial: float scratch [2][nblk][C] with nblk = clv_layernorm_bwd_blocks(). */
+ * ACCUMULATED into (caller zeroes); partial: float scratch [2][nblk][C] with nblk = clv_layernorm_bwd_blocks(). */
 int clv_layernorm_bwd_blocks(int64_t rows, int32_t C);
 int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
@@ -128,7 +128,8 @@ int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float*
  * masked rows selected by multimodal_transformer_pretrain.py:137-139, fused:
  * rows with label == -100 are skipped; loss = mean over the others of (1-pt)^gamma * ce.
  * logits bf16 or float [rows][V] (is_bf16); labels int64 [rows]; row_ce,row_lse float
- * [rows] saved for backward; loss float [1]; count float [1] (number of masked rows). */
+ * [rows] saved for backward; loss float [1]; count float [1] (number of masked rows) —
+ * both must be ZERO on entry (they double as the accumulators). */
 int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
                      float* row_lse, float* loss, float* count, int64_t rows, int32_t V,
                      float gamma, void* stream);
