@@ -28,7 +28,7 @@ _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(ClvAttnGeom), _p]),
-    'clv_attn_bwd': (C.c_int, [_p] * 15 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_bwd': (C.c_int, [_p] * 16 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_layernorm_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _p]),

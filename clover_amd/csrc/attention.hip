@@ -170,14 +170,22 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (PRE) bv = bpre[PRE ? t : 0];
             else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (rid) {                                   // wave-uniform: shifted block, region-id mask
+                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
+                bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
+                bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
+                bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
+                bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
+            } else if (kmask) {
+                const float4 km = *reinterpret_cast<const float4*>(aux + key0);
+                bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
+            }
+            const bool full = (t * 16 + 16) <= N;          // wave-uniform: every key of the tile is real
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = key0 + r;
-                float s = acc[r] * G.g.scale + bb[r];
-                if (rid) s += (rid_s[key] != rq) ? -100.0f : 0.0f;
-                else if (kmask) s += aux[key];
-                s = (key < N) ? s : -INFINITY;
+                float s = fmaf(acc[r], G.g.scale, bb[r]);
+                if (!full) s = (key0 + r < N) ? s : -INFINITY;
                 p[t][r] = s;
                 m = fmaxf(m, s);
             }
@@ -304,15 +312,24 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (PRE) bv = bpre[PRE ? t : 0];
             else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (rid) {
+                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
+                bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
+                bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
+                bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
+                bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
+            } else if (kmask) {
+                const float4 km = *reinterpret_cast<const float4*>(aux + key0);
+                bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
+            }
+            const bool full = (t * 16 + 16) <= N;
             float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = key0 + r;
-                float s = sacc[r] * G.g.scale + bb[r];
-                if (rid) s += (rid_s[key] != rq) ? -100.0f : 0.0f;
-                else if (kmask) s += aux[key];
-                const float pr = (key < N && qv) ? __expf(s - L) : 0.f;
+                const float s = fmaf(sacc[r], G.g.scale, bb[r]) - L;
+                float pr = __expf(s);
+                if (!full) pr = (key0 + r < N) ? pr : 0.f;
                 ds[r] = pr * (pacc[r] - dsm);
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
@@ -353,7 +370,7 @@ template <int HD, int NKT>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
-    const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
+    const float* __restrict__ biasT, const int* __restrict__ rid, const float* __restrict__ kmask,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -392,6 +409,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
         load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
         const int rk = (rid && kv) ? rid_s[nk] : 0;
         const float kmv = (!rid && kmask && kv) ? aux[nk] : 0.f;
+        const float* btrow = (biasT && kv) ? biasT + ((int64_t)h * N + nk) * G.g.bias_ld : nullptr;
 
         f32x4_t dvacc[NC], dkacc[NC];
 #pragma unroll
@@ -415,16 +433,28 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                     pacc = mfma16(dof[s], vf[s], pacc);    // dP same layout
                 }
                 float pv[4], dsv[4];
+                const int qn0 = qt * 16 + lg * 4;
+                float4 bv = make_float4(kmv, kmv, kmv, kmv);
+                if (btrow && qn0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(btrow + qn0);   // biasT[h][key][q..q+3]
+                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                if (rid) {
+                    const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
+                    bb[0] += (rq4.x != rk) ? -100.0f : 0.0f;
+                    bb[1] += (rq4.y != rk) ? -100.0f : 0.0f;
+                    bb[2] += (rq4.z != rk) ? -100.0f : 0.0f;
+                    bb[3] += (rq4.w != rk) ? -100.0f : 0.0f;
+                }
+                const float4 L4 = *reinterpret_cast<const float4*>(L_s + qn0);
+                const float4 D4 = *reinterpret_cast<const float4*>(D_s + qn0);
+                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                const bool full = (qt * 16 + 16) <= N;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qn = qt * 16 + lg * 4 + r;
-                    float s = sacc[r] * G.g.scale;
-                    if (bias && kv && qn < N) s += bias[((int64_t)h * N + qn) * G.g.bias_ld + nk];
-                    if (rid) s += (rid_s[qn] != rk) ? -100.0f : 0.0f;
-                    else s += kmv;
-                    const float pr = (kv && qn < N) ? __expf(s - L_s[qn]) : 0.f;
+                    float pr = __expf(fmaf(sacc[r], G.g.scale, bb[r]) - Lr[r]);
+                    if (!full) pr = (qn0 + r < N) ? pr : 0.f;
+                    pr = kv ? pr : 0.f;
                     pv[r] = pr;
-                    dsv[r] = pr * (pacc[r] - D_s[qn]);
+                    dsv[r] = pr * (pacc[r] - Dr[r]);
                 }
                 pf.u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
                 pf.u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
@@ -529,7 +559,7 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-               const float* lse, const float* bias, const int32_t* rid, const float* kmask, void* dq,
+               const float* lse, const float* bias, const float* biasT, const int32_t* rid, const float* kmask, void* dq,
                void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const Geom& G, hipStream_t st) {
     const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
@@ -560,7 +590,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_b, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse,
-                       dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, G);
+                       dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, G);
     return clv_check_launch();
 }
 
@@ -599,16 +629,17 @@ extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                            const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                            const float* lse, const float* bias, const float* biasT, const int32_t* rid,
+                            const float* kmask,
                             void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
                             const ClvAttnGeom* geom, void* stream) {
     Geom G;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
-    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch)) return CLV_ERR_ARG;
+    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch || !biasT)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
-    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st)
 }

@@ -18,17 +18,16 @@ struct __attribute__((aligned(8))) u16x4 { uint16_t v[4]; };
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, in hardware: one v_cvt_pk_bf16_f32 per PAIR (gfx950).
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_hw_t v = {lo, hi};
+    union { bf16x2_hw_t b; uint32_t u; } c;
+    c.b = __builtin_convertvector(v, bf16x2_hw_t);
+    return c.u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 union Frag8 {  // 8 bf16 = one MFMA 16x16x32 A/B operand
     bf16x8_t v;

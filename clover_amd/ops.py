@@ -302,12 +302,16 @@ class _Attention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias) if bias is not None else None
         dsum = torch.empty_like(lse)
-        ds_scratch = (torch.empty(g.groups * g.nH * g.N * g.bias_ld, device=qkv.device, dtype=BF16)
-                      if bias is not None else None)
+        ds_scratch = biasT = None
+        if bias is not None:
+            ds_scratch = torch.empty(g.groups * g.nH * g.N * g.bias_ld, device=qkv.device, dtype=BF16)
+            biasT = torch.zeros_like(bias)                 # [nH][key][query], same row stride
+            biasT[:, :, :g.N] = bias[:, :, :g.N].transpose(1, 2)
         b, d = qkv.data_ptr(), dqkv.data_ptr()
         with _Timed(f'attn_bwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, True)):
             check(_lib.lib().clv_attn_bwd(C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim),
-                                          _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(rid), _ptr(kmask),
+                                          _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(biasT), _ptr(rid),
+                                          _ptr(kmask),
                                           C.c_void_p(d), C.c_void_p(d + 2 * Cdim), C.c_void_p(d + 4 * Cdim),
                                           _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), C.byref(g), _stream()),
                   'clv_attn_bwd')

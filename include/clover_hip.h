@@ -65,9 +65,12 @@ int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 /* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float, same shape as bias)
  * is ACCUMULATED into (caller zeroes).  dsum: float scratch [groups][nH][N].
  * ds_scratch: bf16 scratch [groups][nH][N][bias_ld] (per-window dS, reduced over windows
- * into dbias by a streaming kernel); required iff bias != NULL. */
+ * into dbias by a streaming kernel); biasT: the same bias with query/key swapped,
+ * biasT[h][key][query] (row stride bias_ld) — the dK/dV kernel walks scores key-major; both
+ * required iff bias != NULL. */
 int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                 const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                 const float* lse, const float* bias, const float* biasT, const int32_t* rid,
+                 const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
                  const ClvAttnGeom* geom_host, void* stream);
 

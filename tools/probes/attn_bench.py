@@ -1,0 +1,29 @@
+"""Micro-benchmark of the window-attention kernels at the stage-0 shape of config 2 (2B = 16 clips)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from clover_amd import ops
+from clover_amd.backbones.swin_transformer_3d import window_geometry, gathered_bias, build_relative_position_index
+B, D, H, W, C, nH = 16, 4, 56, 56, 96, 3
+if len(sys.argv) > 1 and sys.argv[1] == 's2':
+    B, D, H, W, C, nH = 16, 4, 14, 14, 384, 12
+torch.manual_seed(0)
+qkv = torch.randn(B, D, H, W, 3 * C, device='cuda').to(torch.bfloat16).requires_grad_()
+table = (torch.randn(15 * 13 * 13, nH, device='cuda') * 0.5).requires_grad_()
+rpi = build_relative_position_index((8, 7, 7)).cuda()
+ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), (4, 3, 3), 'cuda')
+do = torch.randn(B, D, H, W, C, device='cuda').to(torch.bfloat16)
+for it in range(5):
+    bias = gathered_bias(table, rpi, 196)
+    o = ops.window_attention(qkv, bias, rid, ws, ss, nH)
+    o.backward(do)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+bias = gathered_bias(table, rpi, 196).detach()
+s.record()
+for _ in range(10):
+    with torch.no_grad():
+        o = ops.window_attention(qkv.detach(), bias, rid, ws, ss, nH)
+e.record(); torch.cuda.synchronize()
+print('fwd us', s.elapsed_time(e) * 100)
