@@ -138,14 +138,7 @@ class CloverEngine:
     def step(self, batch):
         """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
         if self.graph is not None:
-            for k, v in self._static_batch.items():
-                if batch[k] is not v:
-                    v.copy_(batch[k], non_blocking=True)
-            self.graph.replay()
-            out = dict(self._static_out)
-            lv = self._static_out['log_vars']
-            if hasattr(lv, 'fresh'):
-                out['log_vars'] = lv.fresh()          # re-read the replayed values on next access
+            out = self._graphed_forward_backward(batch)
         else:
             out = self.model.train_step(batch, None)
             out['loss'].backward()
@@ -153,34 +146,63 @@ class CloverEngine:
         self.optimizer_step()
         return out
 
+    # ------------------------------------------------------------------ hipGraph mode
+    def _graphed_forward_backward(self, batch):
+        """encode (hipGraph) -> gather + contrastive losses (eager: it holds the step's only forward
+        collective) -> backward of the losses (eager, a handful of kernels) -> encode backward (hipGraph)."""
+        for k, v in self._static_batch.items():
+            if batch[k] is not v:
+                v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        emb = self._static_emb.detach().requires_grad_()
+        mlm = self._static_mlm.detach().requires_grad_()
+        losses = self.model.contrastive_losses(emb, mlm)
+        loss, log_vars = self.model._parse_losses(losses)
+        loss.backward()
+        self._static_demb.copy_(emb.grad)
+        self._static_dmlm.copy_(mlm.grad)
+        self.graph_bwd.replay()
+        return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
+
     def capture(self, batch, warmup=2):
-        """Capture forward + backward of the step into one hipGraph (static shapes; the step has no
-        data-dependent shape and no host sync by construction).  ~2400 kernel launches per step
-        become one graph launch, which removes the host-side launch bound.  Single-GPU only for now:
-        with W > 1 the RCCL hooks stay on the eager path."""
-        if self.world > 1:
-            return False
+        """Capture the rank-local part of the step — CloverPretrain.encode and its backward, ~2300 of
+        the ~2400 kernel launches — as two hipGraphs sharing one memory pool (static shapes; no
+        data-dependent shape and no host sync by construction).  The cross-rank part (feature
+        all-gather, InfoNCE/rank losses, logged-scalar all-reduce) stays eager between the two
+        replays, so no RCCL call is ever captured and the same code path serves 1..8 GPUs."""
+        model = self.model
+        aux = {k: None for k in ('token_ids', 'input_mask', 'mlm_label', 'v_token_mask')}
         self._static_batch = {k: v.clone() for k, v in batch.items()}
+        sb = self._static_batch
+
+        def encode():
+            return model.encode(sb['imgs'], **{k: sb[k] for k in aux})
+        self.reducer.enabled = False           # no collective may be issued from inside a capture; in graph
+        self.reducer.reset()                   # mode finish() all-reduces every bucket after the replay
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                out = self.model.train_step(self._static_batch, None)
-                out['loss'].backward()
-                for seg in self.segments:
-                    seg.flat_g.zero_()
+                emb, mlm = encode()
+                torch.autograd.backward([emb, mlm], [torch.zeros_like(emb), torch.zeros_like(mlm)])
         torch.cuda.current_stream().wait_stream(side)
         # no autograd graph may survive into the capture: a live one pins the parameters'
         # AccumulateGrad nodes to the warm-up stream and their accumulation escapes the hipGraph
-        del out
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self.model.train_step(self._static_batch, None)
-            out['loss'].backward()
+        del emb, mlm
         for seg in self.segments:
-            seg.flat_g.zero_()                     # the capture pass itself does not execute kernels
-        self.graph, self._static_out = g, out
+            seg.flat_g.zero_()
+        torch.cuda.synchronize()
+        gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf):
+            emb, mlm = encode()
+        self._static_demb = torch.zeros_like(emb)
+        self._static_dmlm = torch.zeros_like(mlm)
+        with torch.cuda.graph(gb, pool=gf.pool()):
+            torch.autograd.backward([emb, mlm], [self._static_demb, self._static_dmlm])
+        for seg in self.segments:
+            seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit
+        self.graph, self.graph_bwd = gf, gb
+        self._static_emb, self._static_mlm = emb, mlm
         return True
 
     def optimizer_step(self):

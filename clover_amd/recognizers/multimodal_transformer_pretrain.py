@@ -52,12 +52,19 @@ class CloverPretrain(BaseRecognizer):
     def extract_visual_feat(self, imgs, mask=None):
         return self.backbone(imgs, mask)
 
-    def forward_train(self, imgs, label, token_ids=None, segment_ids=None, input_mask=None, mlm_label=None,
-                      dvae_imgs=None, v_token_mask=None, hog_features=None, img_metas=None, **kwargs):
-        if not hasattr(self, 'ssl_head') or self.mlm_ssl_V_head is None or not self.use_Cmask \
-                or mlm_label is None or v_token_mask is None:
-            raise NotImplementedError('the MI355X path implements the full pre-training recipe '
-                                      '(ssl_head + mlm_ssl_head + use_Cmask + mlm_label + v_token_mask)')
+    EMB_NAMES = ('visual_emb', 'text_emb', 'mask_word_emb', 'mask_visual_recon_emb', 'mask_visual_emb',
+                 'mask_word_recon_emb')
+
+    def encode(self, imgs, token_ids=None, input_mask=None, mlm_label=None, v_token_mask=None, **kwargs):
+        """Everything of the step that touches only THIS rank's samples: the three encoders, the heads
+        and the MLM loss.  Returns (emb fp32 [B, 6, D] in EMB_NAMES order, mlm_loss).  No collective
+        and no data-dependent shape inside — the engine captures it (and its backward) as hipGraphs."""
+        if not hasattr(self, 'ssl_head') or self.mlm_ssl_V_head is None or self.mlm_ssl_T_head is None \
+                or not self.use_Cmask or not self.symmetry_rank or mlm_label is None or v_token_mask is None \
+                or self.mlm_head is None:
+            raise NotImplementedError('the MI355X path implements the full pre-training recipe (ssl_head + '
+                                      'mlm_head + mlm_ssl_head V/T + use_Cmask + symmetry_rank + mlm_label + '
+                                      'v_token_mask), i.e. configs/exp_local/pretrain_webvid_cc3m.py')
         imgs = imgs.reshape((-1,) + imgs.shape[2:])                                   # :81
         if self.from_scratch:
             imgs = imgs / 255.0
@@ -91,25 +98,36 @@ class CloverPretrain(BaseRecognizer):
         t_all = fusion['t_last_hidden_state']
         v_fusion_t, t_last_hidden_state = t_all[:B], t_all[B:]
 
-        losses = dict()
-        # ---- MLM (:129-143)
-        if self.mlm_head is not None:
-            score = self.mlm_head(t_last_hidden_state)
-            fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
-            losses['mlm_loss'] = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
+        # ---- MLM (:129-143): all B*L rows through the decoder, the fused focal kernel skips label == -100
+        score = self.mlm_head(t_last_hidden_state)
+        fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
+        mlm_loss = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
 
-        # ---- tri-modal alignment with masked samples + ranking (:147-152)
-        mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])
-        losses.update(self.ssl_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb))
+        mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])                 # :148-149
+        mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])          # :156-157
+        emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
+                           mask_word_recon_emb], dim=1).float()
+        return emb, mlm_loss
 
-        if self.symmetry_rank:                                                         # :155-169
-            mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])
-            l2 = self.ssl_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon_emb)
-            l2['v_nce_loss'] = l2.pop('nce_loss')
-            if self.ssl_loss.use_rank:
-                l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')
-            losses.update(l2)
+    def contrastive_losses(self, emb, mlm_loss):
+        """The cross-rank part of the step (:147-169): all-gather of the embeddings + the two
+        exclusive-InfoNCE / ranking evaluations.  emb [B, 6, D] in EMB_NAMES order."""
+        visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb, mask_word_recon_emb = \
+            emb.unbind(dim=1)
+        losses = dict(mlm_loss=mlm_loss)
+        losses.update(self.ssl_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb))       # :151
+        l2 = self.ssl_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon_emb)                 # :161
+        l2['v_nce_loss'] = l2.pop('nce_loss')
+        if self.ssl_loss.use_rank:
+            l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')
+        losses.update(l2)
         return losses
+
+    def forward_train(self, imgs, label, token_ids=None, segment_ids=None, input_mask=None, mlm_label=None,
+                      dvae_imgs=None, v_token_mask=None, hog_features=None, img_metas=None, **kwargs):
+        emb, mlm_loss = self.encode(imgs, token_ids=token_ids, input_mask=input_mask, mlm_label=mlm_label,
+                                    v_token_mask=v_token_mask)
+        return self.contrastive_losses(emb, mlm_loss)
 
     def forward_test(self, imgs, token_ids=None, segment_ids=None, input_mask=None, **kwargs):
         """``separate_test`` inference (:194-218): one Swin pass + one BERT pass -> (visual_emb, text_emb)."""

@@ -14,6 +14,7 @@ class BucketedGradReducer:
         """slabs: list of (flat_grad, params, offsets) with params[i].grad a view of
         flat_grad[offsets[i]:offsets[i+1]] (in the order backward is expected to fill them)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.enabled = True         # False: hooks are inert (hipGraph capture) and finish() sends everything
         self.buckets = []           # [flat_grad, start, end, n_params]
         self.handles = []
         self.pending = []
@@ -56,6 +57,8 @@ class BucketedGradReducer:
 
     def _make_hook(self, b):
         def hook(param):
+            if not self.enabled:
+                return
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 self._launch(b)
