@@ -197,9 +197,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('CLOVER_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29555')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import clover_amd
@@ -216,7 +217,7 @@ def main():
                           max_iters=100000)
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -248,7 +249,7 @@ def main():
         prof, ops.PROF = ops.PROF, None
         engine.graph = g
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     log_vars = {k: float(v) for k, v in out['log_vars'].items()}
@@ -276,7 +277,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

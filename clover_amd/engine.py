@@ -193,11 +193,12 @@ class CloverEngine:
             seg.flat_g.zero_()
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gf):
+        # thread_local: RCCL's watchdog thread (W > 1) keeps polling events while we capture
+        with torch.cuda.graph(gf, capture_error_mode='thread_local'):
             emb, mlm = encode()
         self._static_demb = torch.zeros_like(emb)
         self._static_dmlm = torch.zeros_like(mlm)
-        with torch.cuda.graph(gb, pool=gf.pool()):
+        with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
             torch.autograd.backward([emb, mlm], [self._static_demb, self._static_dmlm])
         for seg in self.segments:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit

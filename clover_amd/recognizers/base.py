@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .. import builder
+from ..utils.dist import collectives_active
 
 
 class LazyLogVars(OrderedDict):
@@ -145,7 +146,7 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         log_vars['loss'] = loss
         names = list(log_vars.keys())
         packed = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_active():
             packed = packed / dist.get_world_size()
             dist.all_reduce(packed)
         if getattr(self, 'lazy_log_vars', True):

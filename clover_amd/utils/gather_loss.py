@@ -13,6 +13,8 @@ without a process group, defect R2); equal per-rank batches skip the size exchan
 import torch
 import torch.distributed as dist
 
+from .dist import collectives_active
+
 
 def _world():
     if dist.is_available() and dist.is_initialized():
@@ -26,7 +28,7 @@ class GatherLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tensor, rank, world_size):
         ctx.rank, ctx.batch_size = rank, tensor.shape[0]
-        if world_size == 1:
+        if not collectives_active():
             return tensor.clone()
         out = torch.empty((world_size,) + tuple(tensor.shape), dtype=tensor.dtype, device=tensor.device)
         dist.all_gather_into_tensor(out.view(-1), tensor.contiguous().view(-1))
@@ -44,7 +46,7 @@ class VariedShapeGatherLoss(torch.autograd.Function):
     def forward(ctx, q, rank, ws, equal_sizes=False):
         ctx.rank = rank
         n = q.size(0)
-        if ws == 1:
+        if not collectives_active():
             ctx.bounds = (0, n)
             return q.clone()
         if equal_sizes:
@@ -74,7 +76,7 @@ class VariedShapeGatherLoss(torch.autograd.Function):
 def packed_all_gather(tensors, equal_sizes=True):
     """Gather several [B, D] tensors with one collective: stack -> [B, k, D] -> gather -> unstack."""
     rank, ws = _world()
-    if ws == 1:
+    if not collectives_active():
         return list(tensors)
     packed = torch.stack([t.float() for t in tensors], dim=1)
     g = VariedShapeGatherLoss.apply(packed, rank, ws, equal_sizes)

@@ -8,6 +8,8 @@ with gloo as well (no streams), which is how the N>1 path is tested without GPUs
 import torch
 import torch.distributed as dist
 
+from .dist import collectives_active
+
 
 class BucketedGradReducer:
     def __init__(self, slabs, bucket_bytes=64 << 20):
@@ -19,7 +21,8 @@ class BucketedGradReducer:
         self.handles = []
         self.pending = []
         self.comm_stream = None
-        if self.world == 1:
+        self.active = collectives_active()
+        if not self.active:
             for _, params, _ in slabs:
                 for q in params:
                     q._clv_ready = (lambda: None)
@@ -67,7 +70,7 @@ class BucketedGradReducer:
     def finish(self):
         """Wait for every bucket (launching any whose hooks did not all fire, e.g. a parameter that
         received no gradient this step), then make the compute stream wait for the comm stream."""
-        if self.world == 1:
+        if not self.active:
             return
         for b, left in enumerate(self.pending):
             if left > 0:
