@@ -29,9 +29,9 @@ SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(ClvAttnGeom), _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [C.POINTER(ClvAttnGeom), _p]),
-    'clv_layernorm_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _i32, _p]),
+    'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
-    'clv_layernorm_bwd': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _p]),
+    'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _p]),
     'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
     'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),

@@ -193,10 +193,10 @@ class SwinTransformerBlock3D(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
-    def forward_part1(self, x):
+    def attn_part(self, x):
+        """Everything of forward_part1 after norm1 (x is already normalised)."""
         B, D, H, W, C = x.shape
         ws, ss, rid = window_geometry((D, H, W), self.window_size, self.shift_size, x.device)
-        x = self.norm1(x)
         pad_d1 = (ws[0] - D % ws[0]) % ws[0]
         pad_b = (ws[1] - H % ws[1]) % ws[1]
         pad_r = (ws[2] - W % ws[2]) % ws[2]
@@ -207,14 +207,29 @@ class SwinTransformerBlock3D(nn.Module):
             x = x[:, :D, :H, :W, :].contiguous()
         return x
 
+    def forward_part1(self, x):
+        return self.attn_part(self.norm1(x))
+
     def forward_part2(self, x):
         return self.drop_path(self.mlp(self.norm2(x)))
+
+    def forward_pending(self, x, branch=None):
+        """Residual stream with a PENDING addition: the block input is x (+ branch); returns
+        (stream, branch') with block output = stream + branch'.  Both residual adds of the reference
+        (:498, :503) are folded into the LayerNorm kernels that follow them (fwd: sum_out, bwd: dsum)."""
+        if branch is None:
+            y1, s0 = self.norm1(x), x
+        else:
+            y1, s0 = self.norm1(branch, residual=x, return_sum=True)
+        a = self.drop_path(self.attn_part(y1))
+        y2, s1 = self.norm2(a, residual=s0, return_sum=True)
+        return s1, self.drop_path(self.mlp(y2))
 
     def forward(self, x, mask_matrix=None):
         """x bf16 [B,D,H,W,C].  ``mask_matrix`` is accepted for signature compatibility and unused:
         the shift mask is evaluated from region ids inside the kernel."""
-        x = x + self.drop_path(self.forward_part1(x))
-        return x + self.forward_part2(x)
+        s, m = self.forward_pending(x)
+        return s + m
 
 
 class PatchMerging(nn.Module):
@@ -259,11 +274,16 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         """x bf16 channels-last [B,D,H,W,C] -> [B,D,H',W',C'] (the reference takes/returns B C D H W)."""
-        for blk in self.blocks:
-            x = blk(x)
+        s, m = self.forward_pending(x)
+        x = s + m
         if self.downsample is not None:
             x = self.downsample(x)
         return x
+
+    def forward_pending(self, x, branch=None):
+        for blk in self.blocks:
+            x, branch = blk.forward_pending(x, branch)
+        return x, branch
 
 
 class PatchEmbed3D(nn.Module):
@@ -402,9 +422,10 @@ class SwinTransformer3D(nn.Module):
     # ---- channels-last core -------------------------------------------------------------
     def _stages(self, x):
         x = self.pos_drop(x)
-        for layer in self.layers:
+        for layer in self.layers[:-1]:
             x = layer(x)
-        return self.norm(x)
+        s, m = self.layers[-1].forward_pending(x)        # last stage has no downsample:
+        return self.norm(m, residual=s)                  # its final residual add rides in the norm
 
     def forward_tokens(self, x, mask=None):
         """[B,3,T,H,W] -> channels-last features [B,T',h,w,Cf] (masked pass if `mask` given)."""

@@ -55,7 +55,7 @@ __device__ __forceinline__ void ln_load_row(float (&xv)[ITERS * 2], const T* x, 
 template <int ITERS, typename T>
 __global__ void __launch_bounds__(LN_THREADS) ln_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
-    const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+    const float* __restrict__ beta, T* __restrict__ y, T* __restrict__ sum_out, float* __restrict__ mean,
     float* __restrict__ rstd, int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(LN_THREADS) ln_fwd_kernel(
                 const float o0 = (xv[2 * i] - mu) * rs * g[2 * i] + b[2 * i];
                 const float o1 = (xv[2 * i + 1] - mu) * rs * g[2 * i + 1] + b[2 * i + 1];
                 IO<T>::st2(y + row * C + c, o0, o1);
+                if (sum_out) IO<T>::st2(sum_out + row * C + c, xv[2 * i], xv[2 * i + 1]);
             }
         }
     }
@@ -108,7 +109,7 @@ template <int ITERS, typename T>
 __global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-    T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
+    const T* __restrict__ dsum, T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
     __shared__ float red[ITERS * 128 * 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + wv;
@@ -146,8 +147,14 @@ __global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
         for (int i = 0; i < ITERS; ++i) {
             const int c = i * 128 + lane * 2;
             if (c < C) {
-                const float o0 = rs * (g[2 * i] * dv[2 * i] - s1 - xv[2 * i] * s2);
-                const float o1 = rs * (g[2 * i + 1] * dv[2 * i + 1] - s1 - xv[2 * i + 1] * s2);
+                float o0 = rs * (g[2 * i] * dv[2 * i] - s1 - xv[2 * i] * s2);
+                float o1 = rs * (g[2 * i + 1] * dv[2 * i + 1] - s1 - xv[2 * i + 1] * s2);
+                if (dsum) {                                  // gradient arriving through the residual path
+                    float a0, a1;
+                    IO<T>::ld2(dsum + row * C + c, a0, a1);
+                    o0 += a0;
+                    o1 += a1;
+                }
                 IO<T>::st2(dx + row * C + c, o0, o1);
             }
         }
@@ -293,8 +300,8 @@ int ew_blocks(int64_t n8) {
 }  // namespace
 
 extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
-                                 void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
-                                 int32_t is_f32, void* stream) {
+                                 void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,
+                                 float eps, int32_t is_f32, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || C <= 0 || (C & 1)) return CLV_ERR_ARG;
     if (rows == 0) return CLV_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -302,10 +309,10 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
     const int grid = ln_fwd_blocks(rows);
     if (is_f32) {
         LN_DISPATCH(it, ln_fwd_kernel, float, grid, (const float*)x, (const float*)res, gamma, beta, (float*)y,
-                    mean, rstd, rows, (int)C, eps)
+                    (float*)sum_out, mean, rstd, rows, (int)C, eps)
     } else {
         LN_DISPATCH(it, ln_fwd_kernel, bf16_t, grid, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
-                    (bf16_t*)y, mean, rstd, rows, (int)C, eps)
+                    (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)C, eps)
     }
     return clv_check_launch();
 }
@@ -319,7 +326,7 @@ extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
 }
 
 extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
-                                 const float* mean, const float* rstd, void* dx, float* dgamma,
+                                 const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma,
                                  float* dbeta, float* partial, int64_t rows, int32_t C, int32_t is_f32,
                                  void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows <= 0 || C <= 0 ||
@@ -330,10 +337,10 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
     const int grid = clv_layernorm_bwd_blocks(rows, C);
     if (is_f32) {
         LN_DISPATCH(it, ln_bwd_kernel, float, grid, (const float*)dy, (const float*)x, (const float*)res, gamma,
-                    mean, rstd, (float*)dx, partial, rows, (int)C)
+                    mean, rstd, (const float*)dsum, (float*)dx, partial, rows, (int)C)
     } else {
         LN_DISPATCH(it, ln_bwd_kernel, bf16_t, grid, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)res,
-                    gamma, mean, rstd, (bf16_t*)dx, partial, rows, (int)C)
+                    gamma, mean, rstd, (const bf16_t*)dsum, (bf16_t*)dx, partial, rows, (int)C)
     }
     int rc = clv_check_launch();
     if (rc) return rc;

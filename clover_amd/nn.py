@@ -34,8 +34,8 @@ class LinearFP32(nn.Linear):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual)
+    def forward(self, x, residual=None, return_sum=False):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual, return_sum=return_sum)
 
 
 class GELU(nn.Module):

@@ -185,8 +185,12 @@ def linear(x, weight, bias=None):
 
 # --------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
+    """y = LN(x [+ res]); with want_sum also returns s = x + res (the updated residual stream), and the
+    backward folds the gradient arriving on s into dx — the Swin residual adds never run as kernels.
+    Engine-managed gamma/beta receive their gradients directly in the flat slab (atomics)."""
+
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, want_sum):
         _need_gpu(x, gamma)
         C_ = x.shape[-1]
         x2 = _c(x).view(-1, C_)
@@ -200,39 +204,64 @@ class _LayerNorm(torch.autograd.Function):
         b = _c(beta.float())
         rows = x2.shape[0]
         y = torch.empty_like(x2)
+        ssum = torch.empty_like(x2) if want_sum else None
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd),
-                                           rows, C_, float(eps), int(f32), _stream()), 'clv_layernorm_fwd')
-        ctx.save_for_backward(x2, r2, g, mean, rstd)
+        check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), _ptr(ssum), _ptr(mean),
+                                           _ptr(rstd), rows, C_, float(eps), int(f32), _stream()),
+              'clv_layernorm_fwd')
+        if want_sum:
+            ctx.save_for_backward(ssum, None, g, mean, rstd)    # x + res is all the backward needs
+        else:
+            ctx.save_for_backward(x2, r2, g, mean, rstd)
         ctx.has_res = res is not None
         ctx.xshape = x.shape
         ctx.gdtype = gamma.dtype
-        return y.view(x.shape)
+        ctx.gref, ctx.bref = gamma, beta
+        if want_sum:
+            return y.view(x.shape), ssum.view(x.shape)
+        return y.view(x.shape), None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dsum):
         x2, r2, g, mean, rstd = ctx.saved_tensors
         rows, C_ = x2.shape
         dy2 = _c(dy).view(rows, C_)
         if dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype)
+        ds2 = None
+        if dsum is not None:
+            ds2 = _c(dsum).view(rows, C_)
+            if ds2.dtype != x2.dtype:
+                ds2 = ds2.to(x2.dtype)
         L = _lib.lib()
         nblk = L.clv_layernorm_bwd_blocks(rows, C_)
         partial = torch.empty(2 * nblk * C_, device=x2.device, dtype=torch.float32)
         dx = torch.empty_like(x2)
-        dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
-        db = torch.zeros_like(dg)
-        check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                  _ptr(dg), _ptr(db), _ptr(partial), rows, C_, int(x2.dtype == torch.float32),
-                                  _stream()), 'clv_layernorm_bwd')
+        gsink = getattr(ctx.gref, '_clv_grad', None)
+        bsink = getattr(ctx.bref, '_clv_grad', None)
+        sink = gsink is not None and bsink is not None and gsink.dtype == torch.float32
+        if sink:
+            dg, db = gsink, bsink
+        else:
+            dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
+            db = torch.zeros_like(dg)
+        check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(ds2),
+                                  _ptr(dx), _ptr(dg), _ptr(db), _ptr(partial), rows, C_,
+                                  int(x2.dtype == torch.float32), _stream()), 'clv_layernorm_bwd')
         dxv = dx.view(ctx.xshape)
-        return dxv, (dxv if ctx.has_res else None), dg.to(ctx.gdtype), db.to(ctx.gdtype), None
+        if sink:
+            ctx.gref._clv_ready()
+            ctx.bref._clv_ready()
+            return dxv, (dxv if ctx.has_res else None), None, None, None, None
+        return dxv, (dxv if ctx.has_res else None), dg.to(ctx.gdtype), db.to(ctx.gdtype), None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None):
-    """y = LayerNorm(x [+ residual]) over the last dim; bf16 (or fp32) in/out, fp32 statistics."""
-    return _LayerNorm.apply(x, residual, weight, bias, eps)
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
+    """y = LayerNorm(x [+ residual]) over the last dim; bf16 (or fp32) in/out, fp32 statistics.
+    return_sum=True -> (y, x + residual)."""
+    y, s = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum))
+    return (y, s) if return_sum else y
 
 
 # --------------------------------------------------------------------------- GELU
@@ -404,7 +433,7 @@ class _PatchEmbed(torch.autograd.Function):
             dz = torch.empty_like(z)
             dg = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
             db = torch.zeros_like(dg)
-            check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(dz),
+            check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(None), _ptr(dz),
                                       _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, _stream()), 'clv_layernorm_bwd')
         else:
             dz, dg, db = dyb, None, None

@@ -79,15 +79,18 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
  * 541,685,238; HF BERT LayerNorm eps 1e-12; cross_transformer.py:97).
  * x,y [rows][C] bf16 (is_f32 = 0) or float (is_f32 = 1: the fp32 projection heads and
  * losses, ssl_head.py:50-56, contrastive_loss.py:102); gamma,beta float [C]; mean,rstd
- * float [rows].  res (same type as x, may be NULL): y = LN(x + res) (BERT post-LN residual). */
+ * float [rows].  res (same type as x, may be NULL): y = LN(x + res) (BERT post-LN residual;
+ * the Swin residual adds of :498,503 fused into the following norm).  sum_out (may be NULL)
+ * receives x + res — the updated residual stream. */
 int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
-                      void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
-                      int32_t is_f32, void* stream);
-/* dx [rows][C] (gradient wrt x and, identically, wrt res); dgamma,dbeta float [C]
+                      void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,
+                      float eps, int32_t is_f32, void* stream);
+/* dx [rows][C] (gradient wrt x and, identically, wrt res) = LN backward of dy (+ dsum, the
+ * gradient arriving on sum_out, may be NULL); dgamma,dbeta float [C]
  * ACCUMULATED into (caller zeroes); partial: float scratch [2][nblk][C] with nblk = clv_layernorm_bwd_blocks(). */
 int clv_layernorm_bwd_blocks(int64_t rows, int32_t C);
 int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
-                      const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                      const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma, float* dbeta,
                       float* partial, int64_t rows, int32_t C, int32_t is_f32, void* stream);
 
 /* ------------------------------------------------------------------ GELU (erf)

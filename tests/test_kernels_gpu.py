@@ -282,3 +282,23 @@ def test_linear_and_wgrad(M, N, K):
     assert rel(xg.grad, xr.grad) < 1e-2
     assert rel(wg.grad, wr.grad) < 5e-3, rel(wg.grad, wr.grad)
     assert rel(bg.grad, br.grad) < 5e-3, rel(bg.grad, br.grad)
+
+
+def test_layernorm_fused_residual_stream():
+    """y, s = LN(x + r), x + r with the gradient on s folded into the backward (Swin residual adds)."""
+    rows, C = 1000, 96
+    x, r = rnd(rows, C, seed=81).to(BF), rnd(rows, C, seed=82).to(BF)
+    g, b = 1 + 0.1 * rnd(C, seed=83), 0.1 * rnd(C, seed=84)
+    dy, ds = rnd(rows, C, seed=85).to(BF), rnd(rows, C, seed=86).to(BF)
+    xr, rr = x.float().requires_grad_(), r.float().requires_grad_()
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    sr = xr + rr
+    yr = F.layer_norm(sr, (C,), gr, br, 1e-5)
+    torch.autograd.backward([yr, sr], [dy.float(), ds.float()])
+    xg, rg = x.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+    gg, bg = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y, s = ops().layer_norm(xg, gg, bg, 1e-5, residual=rg, return_sum=True)
+    torch.autograd.backward([y, s], [dy.to(DEV), ds.to(DEV)])
+    assert rel(y, yr) < 1e-2 and rel(s, sr) < 1e-2
+    assert rel(xg.grad, xr.grad) < 2e-2 and rel(rg.grad, rr.grad) < 2e-2
+    assert rel(gg.grad, gr.grad) < 1e-2 and rel(bg.grad, br.grad) < 1e-2
