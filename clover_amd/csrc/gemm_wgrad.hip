@@ -13,7 +13,8 @@
 namespace {
 
 constexpr int WG_THREADS = 256;
-constexpr int TN = 128, TK = 128, TM = 32, LD = 128 + 8;
+constexpr int TN = 128, TK = 128, TM = 64, LD = 128 + 8;
+constexpr int CHUNKS = TM * (128 / 8) / WG_THREADS;       // 16-B chunks per thread per tile (= 4)
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 tr4(const bf16_t* base, int row0, int c0, int lr) {
@@ -24,23 +25,32 @@ __device__ __forceinline__ uint2 tr4(const bf16_t* base, int row0, int c0, int l
     return cv.u;
 }
 
-__device__ __forceinline__ void load_tile(bf16_t* dst, const bf16_t* __restrict__ src, int64_t m0, int64_t m_end,
-                                          int c0, int ncols, int ld, int tid) {
-    // 32 rows x 128 cols, 16-B chunks; rows >= m_end and cols >= ncols are zero
-    for (int idx = tid; idx < TM * (128 / 8); idx += WG_THREADS) {
+// global -> registers: this thread's CHUNKS 16-B pieces of a 64 x 128 tile (rows >= m_end, cols >= ncols: 0)
+__device__ __forceinline__ void fetch_tile(uint4 (&v)[CHUNKS], const bf16_t* __restrict__ src, int64_t m0,
+                                           int64_t m_end, int c0, int ncols, int ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int idx = tid + i * WG_THREADS;
         const int r = idx >> 4, c8 = idx & 15;
         const int64_t m = m0 + r;
         const int c = c0 + c8 * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < m_end && c < ncols) v = *reinterpret_cast<const uint4*>(src + m * ld + c);   // ncols % 8 == 0
-        *reinterpret_cast<uint4*>(dst + r * LD + c8 * 8) = v;
+        v[i] = (m < m_end && c < ncols) ? *reinterpret_cast<const uint4*>(src + m * ld + c) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void store_tile(bf16_t* dst, const uint4 (&v)[CHUNKS], int tid) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int idx = tid + i * WG_THREADS;
+        *reinterpret_cast<uint4*>(dst + (idx >> 4) * LD + (idx & 15) * 8) = v[i];
     }
 }
 
+// Register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is
+// consumed from LDS (T14 "issue early / write late"); one LDS buffer, two barriers per 64 rows.
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                           float* __restrict__ partial, float* __restrict__ pbias,
-                                                           int64_t M, int N, int K, int ldy, int ldx, int tilesK,
-                                                           int64_t rows_per_split) {
+                                                           float* __restrict__ partial, int64_t M, int N, int K,
+                                                           int ldy, int ldx, int tilesK, int64_t rows_per_split,
+                                                           int want_bias) {
     __shared__ __attribute__((aligned(16))) bf16_t dYs[TM * LD];
     __shared__ __attribute__((aligned(16))) bf16_t Xs[TM * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
@@ -51,7 +61,7 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
     const int64_t m_begin = (int64_t)split * rows_per_split;
     int64_t m_end = m_begin + rows_per_split;
     if (m_end > M) m_end = M;
-    const bool do_bias = pbias && tk == 0 && wk == 0;
+    const bool do_bias = want_bias && tk == 0 && wk == 0;
 
     f32x4_t acc[4][4];
     f32x4_t bacc[4];
@@ -64,28 +74,39 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
     Frag8 ones;
     ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;      // bf16 1.0 pairs
 
+    uint4 ry[CHUNKS], rx[CHUNKS];
+    fetch_tile(ry, dy, m_begin, m_end, n0, N, ldy, tid);
+    fetch_tile(rx, x, m_begin, m_end, k0, K, ldx, tid);
     for (int64_t m0 = m_begin; m0 < m_end; m0 += TM) {
+        __syncthreads();                                   // previous tile fully consumed
+        store_tile(dYs, ry, tid);
+        store_tile(Xs, rx, tid);
         __syncthreads();
-        load_tile(dYs, dy, m0, m_end, n0, N, ldy, tid);
-        load_tile(Xs, x, m0, m_end, k0, K, ldx, tid);
-        __syncthreads();
-        Frag8 a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i].u2[0] = tr4(dYs, lg * 4, wn + i * 16, lr);            // A[n][kappa] = dY[m(kappa)][n]
-            a[i].u2[1] = tr4(dYs, 16 + lg * 4, wn + i * 16, lr);
-            b[i].u2[0] = tr4(Xs, lg * 4, wk + i * 16, lr);             // B[kappa][k] = X[m(kappa)][k]
-            b[i].u2[1] = tr4(Xs, 16 + lg * 4, wk + i * 16, lr);
+        if (m0 + TM < m_end) {                             // next tile's loads fly under the MFMAs below
+            fetch_tile(ry, dy, m0 + TM, m_end, n0, N, ldy, tid);
+            fetch_tile(rx, x, m0 + TM, m_end, k0, K, ldx, tid);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int h = 0; h < TM / 32; ++h) {
+            Frag8 a[4], b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-            if (do_bias) bacc[i] = mfma16(a[i], ones, bacc[i]);
+            for (int i = 0; i < 4; ++i) {
+                a[i].u2[0] = tr4(dYs, h * 32 + lg * 4, wn + i * 16, lr);        // A[n][kappa] = dY[m(kappa)][n]
+                a[i].u2[1] = tr4(dYs, h * 32 + 16 + lg * 4, wn + i * 16, lr);
+                b[i].u2[0] = tr4(Xs, h * 32 + lg * 4, wk + i * 16, lr);         // B[kappa][k] = X[m(kappa)][k]
+                b[i].u2[1] = tr4(Xs, h * 32 + 16 + lg * 4, wk + i * 16, lr);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                if (do_bias) bacc[i] = mfma16(a[i], ones, bacc[i]);
+            }
         }
     }
-    // acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]
-    float* pw = partial + (int64_t)split * N * K;
+    // partial[split] = [N*K dW | N db];  acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]
+    const int64_t E2 = (int64_t)N * K + N;
+    float* pw = partial + (int64_t)split * E2;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -97,26 +118,29 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
                 const int k = k0 + wk + j * 16 + lr;
                 if (k < K) pw[(int64_t)n * K + k] = acc[i][j][r];
             }
-            if (do_bias && lr == 0) pbias[(int64_t)split * N + n] = bacc[i][r];
+            if (do_bias && lr == 0) pw[(int64_t)N * K + n] = bacc[i][r];
         }
 }
 
-// out[e] += sum_s partial[s][e].  Block = 64 consecutive e x 16 split-lanes (1024 threads):
-// coalesced 256-B reads, the splits loop is 16-way parallel, LDS tree at the end.
-__global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                             int64_t E, int splits) {
+// dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N).  Block = 64 consecutive e x
+// 16 split-lanes (1024 threads): coalesced 256-B reads, 16-way parallel splits loop, LDS tree at the end.
+__global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                             float* __restrict__ db, int64_t NK, int64_t E2,
+                                                             int splits) {
     __shared__ float sh[16][64];
     const int el = threadIdx.x & 63, sp = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    const int64_t Eeff = db ? E2 : NK;
     float a = 0.f;
-    if (e < E)
-        for (int s = sp; s < splits; s += 16) a += partial[(int64_t)s * E + e];
+    if (e < Eeff)
+        for (int s = sp; s < splits; s += 16) a += partial[(int64_t)s * E2 + e];
     sh[sp][el] = a;
     __syncthreads();
-    if (sp == 0 && e < E) {
+    if (sp == 0 && e < Eeff) {
 #pragma unroll
         for (int k = 1; k < 16; ++k) a += sh[k][el];
-        out[e] += a;
+        if (e < NK) dw[e] += a;
+        else db[e - NK] += a;
     }
 }
 
@@ -147,20 +171,13 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     const int splits = pick_splits(M, tiles);
     int64_t rows = (M + splits - 1) / splits;
     rows = (rows + TM - 1) / TM * TM;
-    float* partial = work;
-    float* pbias = db ? work + (int64_t)splits * N * K : nullptr;
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(WG_THREADS), 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)x, partial, pbias, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows);
+                       (const bf16_t*)x, work, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows, db ? 1 : 0);
     int rc = clv_check_launch();
     if (rc) return rc;
-    const int64_t E = (int64_t)N * K;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, partial, dw, E, splits);
-    rc = clv_check_launch();
-    if (rc) return rc;
-    if (db) {
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, pbias, db,
-                           (int64_t)N, splits);
-        rc = clv_check_launch();
-    }
-    return rc;
+    const int64_t NK = (int64_t)N * K, E2 = NK + N;
+    const int64_t Eeff = db ? E2 : NK;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK, E2,
+                       splits);
+    return clv_check_launch();
 }
