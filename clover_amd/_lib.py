@@ -19,7 +19,7 @@ class ClvAttnGeom(C.Structure):
     """Mirror of ``struct ClvAttnGeom`` (include/clover_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in
                 ('mode', 'groups', 'N', 'nH', 'hd', 'D', 'H', 'W', 'wd', 'wh', 'ww', 'sd', 'sh', 'sw',
-                 'ldq', 'ldk', 'ldv', 'ldo', 'bias_ld')] + [('scale', C.c_float)]
+                 'ldq', 'ldk', 'ldv', 'ldo', 'bias_ld')] + [('scale', C.c_float), ('dropout_p', C.c_float)]
 
 
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -27,8 +27,8 @@ _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
-    'clv_attn_fwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(ClvAttnGeom), _p]),
-    'clv_attn_bwd': (C.c_int, [_p] * 16 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_bwd': (C.c_int, [_p] * 17 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _p]),

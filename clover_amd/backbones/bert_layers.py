@@ -107,7 +107,8 @@ class BertSelfAttention(nn.Module):
         w = torch.cat([self.query.weight, self.key.weight, self.value.weight], dim=0)
         b = torch.cat([self.query.bias, self.key.bias, self.value.bias], dim=0)
         qkv = ops.linear(x, w, b)
-        return ops.seq_attention(qkv.contiguous(), kmask, self.num_attention_heads)
+        return ops.seq_attention(qkv.contiguous(), kmask, self.num_attention_heads,
+                                 self.attn_dropout_p if self.training else 0.0)
 
 
 class BertSelfOutput(nn.Module):

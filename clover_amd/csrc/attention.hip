@@ -24,7 +24,20 @@ constexpr int THREADS = WAVES * 64;
 struct Geom {
     ClvAttnGeom g;
     int nWh, nWw, nW;  // windows per axis / per clip (mode 1)
+    unsigned drop_thresh;   // attention-probability dropout: P(drop) = drop_thresh / 2^32 (0 = off)
+    float inv_keep;
 };
+
+// Counter-based dropout mask: a pure function of (seed, (group, head, query) row id, key), so the
+// backward kernels regenerate exactly the forward's mask.  Returns 1/(1-p) (kept) or 0 (dropped).
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned rowid, unsigned key, unsigned thresh,
+                                            float inv_keep) {
+    unsigned x = (rowid * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (unsigned)seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += (unsigned)(seed >> 32);
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    return (x >= thresh) ? inv_keep : 0.f;
+}
 
 __device__ __forceinline__ int64_t tok_row(const Geom& G, int grp, int n) {
     if (G.g.mode == 0) return (int64_t)grp * G.g.N + n;
@@ -113,7 +126,8 @@ template <int HD, int NKT>
 __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
-    const int* __restrict__ rid, const float* __restrict__ kmask, Geom G) {
+    const int* __restrict__ rid, const float* __restrict__ kmask, const unsigned long long* __restrict__ seedp,
+    Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -203,6 +217,15 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
         sum = grp4_sum(sum);
         if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = m + __logf(sum);
         const float inv = 1.0f / sum;
+        if (G.drop_thresh) {                               // dropout on the probabilities (after softmax)
+            const unsigned long long sd = *seedp;
+            const unsigned rowid = (unsigned)((grp * G.g.nH + h) * N + nq);
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p[t][r] *= keep_scale(sd, rowid, (unsigned)(t * 16 + lg * 4 + r), G.drop_thresh, G.inv_keep);
+        }
 
         f32x4_t oacc[NC];
 #pragma unroll
@@ -241,7 +264,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
-    bf16_t* __restrict__ dq, bf16_t* __restrict__ ds_out, float* __restrict__ dsum, Geom G) {
+    bf16_t* __restrict__ dq, bf16_t* __restrict__ ds_out, float* __restrict__ dsum,
+    const unsigned long long* __restrict__ seedp, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -280,6 +304,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             for (int e = 0; e < 8; ++e) dsm += bf2f(dof[s].h[e]) * bf2f(of[s].h[e]);
         dsm = grp4_sum(dsm);
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + nq;
+        const unsigned rowid = (unsigned)li;
+        const unsigned long long sd = G.drop_thresh ? *seedp : 0ull;
         if (qv && lg == 0) dsum[li] = dsm;
         const float L = qv ? lse[li] : 0.f;
         const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
@@ -330,7 +356,9 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
                 const float s = fmaf(sacc[r], G.g.scale, bb[r]) - L;
                 float pr = __expf(s);
                 if (!full) pr = (key0 + r < N) ? pr : 0.f;
-                ds[r] = pr * (pacc[r] - dsm);
+                float dp = pacc[r];
+                if (G.drop_thresh) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
+                ds[r] = pr * (dp - dsm);
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
             dsf[t >> 1].u[(t & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
@@ -371,7 +399,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
     const float* __restrict__ biasT, const int* __restrict__ rid, const float* __restrict__ kmask,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, Geom G) {
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, const unsigned long long* __restrict__ seedp, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -400,6 +428,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
 
     const int nkt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
+    const unsigned long long sd = G.drop_thresh ? *seedp : 0ull;
     for (int kt = wave; kt < nkt; kt += WAVES) {
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
@@ -453,8 +482,12 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                     float pr = __expf(fmaf(sacc[r], G.g.scale, bb[r]) - Lr[r]);
                     if (!full) pr = (qn0 + r < N) ? pr : 0.f;
                     pr = kv ? pr : 0.f;
-                    pv[r] = pr;
-                    dsv[r] = pr * (pacc[r] - Dr[r]);
+                    float ks = 1.f;
+                    if (G.drop_thresh)
+                        ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + qn0 + r), (unsigned)nk, G.drop_thresh,
+                                        G.inv_keep);
+                    pv[r] = pr * ks;
+                    dsv[r] = pr * (pacc[r] * ks - Dr[r]);
                 }
                 pf.u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
                 pf.u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
@@ -512,6 +545,13 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (!g) return false;
     G.g = *g;
     G.nWh = G.nWw = G.nW = 1;
+    G.drop_thresh = 0;
+    G.inv_keep = 1.f;
+    if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return false;
+    if (g->dropout_p > 0.f) {
+        G.drop_thresh = (unsigned)((double)g->dropout_p * 4294967296.0);
+        G.inv_keep = 1.0f / (1.0f - g->dropout_p);
+    }
     if (g->N <= 0 || g->nH <= 0 || g->groups <= 0) return false;
     if (g->hd != 16 && g->hd != 32 && g->hd != 64) return false;
     if ((g->ldq | g->ldk | g->ldv | g->ldo) & 7) return false;   // 16-byte row alignment
@@ -542,7 +582,7 @@ size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NK
 
 template <int HD, int NKT>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
-               const int32_t* rid, const float* kmask, const Geom& G, hipStream_t st) {
+               const int32_t* rid, const float* kmask, const unsigned long long* seed, const Geom& G, hipStream_t st) {
     const size_t lds = fwd_lds<HD, NKT>();
     if (lds > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     static bool attr = false;
@@ -553,14 +593,15 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     }
     const int nblk = G.g.groups * G.g.nH;
     hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, G);
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
     return clv_check_launch();
 }
 
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                const float* lse, const float* bias, const float* biasT, const int32_t* rid, const float* kmask, void* dq,
-               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const Geom& G, hipStream_t st) {
+               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const unsigned long long* seed, const Geom& G,
+               hipStream_t st) {
     const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     static bool attr = false;
@@ -574,7 +615,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const int nblk = G.g.groups * G.g.nH;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_a, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
-                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, (bf16_t*)(bias ? ds_scratch : nullptr), dsum, G);
+                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, (bf16_t*)(bias ? ds_scratch : nullptr), dsum, seed, G);
     int rc = clv_check_launch();
     if (rc) return rc;
     if (bias) {
@@ -590,7 +631,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_b, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse,
-                       dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, G);
+                       dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G);
     return clv_check_launch();
 }
 
@@ -615,31 +656,35 @@ int pick_nkt(int N) {
 }  // namespace
 
 extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
-                            const float* bias, const int32_t* rid, const float* kmask,
+                            const float* bias, const int32_t* rid, const float* kmask, const void* seed,
                             const ClvAttnGeom* geom, void* stream) {
     Geom G;
     if (!q || !k || !v || !o || !lse || !make_geom(geom, G)) return CLV_ERR_ARG;
+    if (G.drop_thresh && !seed) return CLV_ERR_ARG;
+    const unsigned long long* sp = (const unsigned long long*)seed;
     if (bias && G.g.bias_ld < ((G.g.N + 15) / 16) * 16) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st) }
-    DISPATCH_NKT(64, launch_fwd, q, k, v, o, lse, bias, rid, kmask, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st) }
+    DISPATCH_NKT(64, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st)
 }
 
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                             const float* lse, const float* bias, const float* biasT, const int32_t* rid,
                             const float* kmask,
                             void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
-                            const ClvAttnGeom* geom, void* stream) {
+                            const void* seed, const ClvAttnGeom* geom, void* stream) {
     Geom G;
+    const unsigned long long* sp = (const unsigned long long*)seed;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
     if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch || !biasT)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
+    if (G.drop_thresh && !seed) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st) }
-    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st)
 }

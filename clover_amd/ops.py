@@ -300,10 +300,11 @@ class _Attention(torch.autograd.Function):
     """qkv: bf16 [..tokens.., 3*nH*hd] with q|k|v packed along the last dim."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, rid, kmask, geom_kw):
+    def forward(ctx, qkv, bias, rid, kmask, geom_kw, seed):
         _need_gpu(qkv)
         assert qkv.dtype == BF16 and qkv.is_contiguous()
         g = ClvAttnGeom(**geom_kw)
+        assert g.dropout_p == 0.0 or seed is not None
         Cdim = g.nH * g.hd
         assert qkv.shape[-1] == 3 * Cdim
         g.ldq = g.ldk = g.ldv = 3 * Cdim
@@ -315,14 +316,14 @@ class _Attention(torch.autograd.Function):
         with _Timed(f'attn_fwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, False)):
             check(_lib.lib().clv_attn_fwd(C.c_void_p(base), C.c_void_p(base + 2 * Cdim),
                                           C.c_void_p(base + 4 * Cdim), _ptr(o), _ptr(lse), _ptr(bias), _ptr(rid),
-                                          _ptr(kmask), C.byref(g), _stream()), 'clv_attn_fwd')
-        ctx.save_for_backward(qkv, o, lse, bias, rid, kmask)
+                                          _ptr(kmask), _ptr(seed), C.byref(g), _stream()), 'clv_attn_fwd')
+        ctx.save_for_backward(qkv, o, lse, bias, rid, kmask, seed)
         ctx.geom = g
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, bias, rid, kmask = ctx.saved_tensors
+        qkv, o, lse, bias, rid, kmask, seed = ctx.saved_tensors
         g = ctx.geom
         Cdim = g.nH * g.hd
         doc = _c(do)
@@ -342,9 +343,9 @@ class _Attention(torch.autograd.Function):
                                           _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(biasT), _ptr(rid),
                                           _ptr(kmask),
                                           C.c_void_p(d), C.c_void_p(d + 2 * Cdim), C.c_void_p(d + 4 * Cdim),
-                                          _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), C.byref(g), _stream()),
-                  'clv_attn_bwd')
-        return dqkv, dbias, None, None, None
+                                          _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), _ptr(seed), C.byref(g),
+                                          _stream()), 'clv_attn_bwd')
+        return dqkv, dbias, None, None, None, None
 
 
 def window_attention(qkv, bias, rid, window, shift, num_heads):
@@ -361,15 +362,34 @@ def window_attention(qkv, bias, rid, window, shift, num_heads):
     nW = (D // window[0]) * (H // window[1]) * (W // window[2])
     kw = dict(mode=1, groups=B * nW, N=N, nH=num_heads, hd=hd, D=D, H=H, W=W, wd=window[0], wh=window[1],
               ww=window[2], sd=shift[0], sh=shift[1], sw=shift[2], scale=float(hd) ** -0.5)
-    return _Attention.apply(qkv, bias, rid, None, kw)
+    return _Attention.apply(qkv, bias, rid, None, kw, None)
 
 
-def seq_attention(qkv, kmask, num_heads):
-    """BERT self-attention. qkv bf16 [B,S,3H]; kmask fp32 [B,S] additive ((1-m)*-10000) or None."""
+_DROPOUT_COUNTER = {}
+
+
+def next_dropout_seed(device):
+    """A fresh device-resident uint64 seed per attention call, derived from a device counter that is
+    advanced by a (capturable) kernel — so every hipGraph replay draws new masks without host traffic.
+    The counter starts from torch's seeded CPU generator (torch.manual_seed controls it)."""
+    key = str(device)
+    if key not in _DROPOUT_COUNTER:
+        init = int(torch.randint(1, 2 ** 62, (1,)).item())
+        _DROPOUT_COUNTER[key] = torch.tensor([init], device=device, dtype=torch.int64)
+    ctr = _DROPOUT_COUNTER[key]
+    seed = ctr.clone()
+    ctr.add_(0x9E3779B97F4A7C15 - (1 << 64))          # odd 64-bit stride (wraps)
+    return seed
+
+
+def seq_attention(qkv, kmask, num_heads, dropout_p=0.0):
+    """BERT self-attention. qkv bf16 [B,S,3H]; kmask fp32 [B,S] additive ((1-m)*-10000) or None;
+    dropout_p: dropout on the attention probabilities (HF attention_probs_dropout_prob)."""
     B, S, C3 = qkv.shape
     hd = C3 // 3 // num_heads
-    kw = dict(mode=0, groups=B, N=S, nH=num_heads, hd=hd, scale=float(hd) ** -0.5)
-    return _Attention.apply(qkv, None, None, kmask, kw)
+    kw = dict(mode=0, groups=B, N=S, nH=num_heads, hd=hd, scale=float(hd) ** -0.5, dropout_p=float(dropout_p))
+    seed = next_dropout_seed(qkv.device) if dropout_p > 0 else None
+    return _Attention.apply(qkv, None, None, kmask, kw, seed)
 
 
 # --------------------------------------------------------------------------- patch embed

@@ -54,12 +54,15 @@ typedef struct ClvAttnGeom {
     int32_t ldq, ldk, ldv, ldo; /* row strides (elements) of q,k,v and o/do/dq.. */
     int32_t bias_ld;        /* row stride of bias/dbias [nH][N][bias_ld] (multiple of 16), 0 = none */
     float scale;            /* head_dim^-0.5 */
+    float dropout_p;        /* dropout on the attention probabilities (HF attention_probs_dropout_prob), 0 = off */
 } ClvAttnGeom;
 
 /* lse: float [groups][nH][N].  bias: float or NULL.  rid: int32 [nW][N] region ids of
- * compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL. */
+ * compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL.
+ * seed: device uint64[1], read when dropout_p > 0; the mask is a counter-based hash of
+ * (seed, group, head, query, key), so the backward regenerates it from the same seed. */
 int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
-                 const float* bias, const int32_t* rid, const float* kmask,
+                 const float* bias, const int32_t* rid, const float* kmask, const void* seed,
                  const ClvAttnGeom* geom_host, void* stream);
 
 /* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float, same shape as bias)
@@ -72,7 +75,7 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const float* lse, const float* bias, const float* biasT, const int32_t* rid,
                  const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
-                 const ClvAttnGeom* geom_host, void* stream);
+                 const void* seed, const ClvAttnGeom* geom_host, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm over the last dim (every norm site: swin_transformer_3d.py:450,483,

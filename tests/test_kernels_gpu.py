@@ -302,3 +302,33 @@ def test_layernorm_fused_residual_stream():
     assert rel(y, yr) < 1e-2 and rel(s, sr) < 1e-2
     assert rel(xg.grad, xr.grad) < 2e-2 and rel(rg.grad, rr.grad) < 2e-2
     assert rel(gg.grad, gr.grad) < 1e-2 and rel(bg.grad, br.grad) < 1e-2
+
+
+def test_seq_attention_dropout():
+    """Attention-probability dropout: recover the kernel's mask with uniform attention + identity V, then
+    check forward and backward against a torch reference that uses exactly that mask."""
+    B, S, nH, hd, pd = 2, 64, 2, 64, 0.25
+    Hd = nH * hd
+    seed = torch.tensor([123456789], device=DEV, dtype=torch.int64)
+    from clover_amd.ops import _Attention
+    kw = dict(mode=0, groups=B, N=S, nH=nH, hd=hd, scale=hd ** -0.5, dropout_p=pd)
+    # q = k = 0 -> P uniform 1/S ; V = identity per head -> O[i, j] = mask[i, j] / (S (1 - pd))
+    probe = torch.zeros(B, S, 3, nH, hd)
+    probe[:, :, 2] = torch.eye(S)[None, :, None, :hd].expand(B, S, nH, hd)
+    o = _Attention.apply(probe.reshape(B, S, 3 * Hd).to(BF).to(DEV), None, None, None, kw, seed)
+    mask = (o.float().view(B, S, nH, hd).permute(0, 2, 1, 3) * S * (1 - pd)).round().cpu()        # [B,nH,S(q),S(k)]
+    assert set(mask.unique().tolist()) <= {0.0, 1.0}
+    assert abs(mask.mean().item() - (1 - pd)) < 0.03                                         # drop rate
+    assert not torch.equal(mask[0, 0], mask[1, 1])                                           # varies over (b, h)
+    qkv = rnd(B, S, 3 * Hd, seed=91).to(BF)
+    do = rnd(B, S, Hd, seed=92).to(BF)
+    qr = qkv.float().requires_grad_()
+    q, k, v = qr.view(B, S, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    p = (q @ k.transpose(-1, -2) / hd ** 0.5).softmax(-1) * mask / (1 - pd)
+    o_ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, Hd)
+    o_ref.backward(do.float())
+    qg = qkv.to(DEV).requires_grad_()
+    o2 = _Attention.apply(qg, None, None, None, kw, seed)
+    o2.backward(do.to(DEV))
+    assert rel(o2, o_ref) < 2e-2, rel(o2, o_ref)
+    assert rel(qg.grad, qr.grad) < 3e-2, rel(qg.grad, qr.grad)
