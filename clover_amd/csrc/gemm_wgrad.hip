@@ -144,6 +144,36 @@ __global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __rest
     }
 }
 
+// db[n] += sum_m dy[m][n] for the library-GEMM layers (M of a few hundred..thousand rows): block = 64
+// columns (8 lanes x 16 B) x 32 row-lanes, rows additionally split over blockIdx.y; LDS tree + atomics.
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int64_t M,
+                                                     int N, int ld) {
+    __shared__ float sh[32][65];
+    const int c8 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col = blockIdx.x * 64 + c8 * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col < N) {
+        for (int64_t m = (int64_t)blockIdx.y * 32 + rl; m < M; m += (int64_t)gridDim.y * 32) {
+            Frag8 v;
+            v.u4 = *reinterpret_cast<const uint4*>(dy + m * ld + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v.h[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[rl][c8 * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) a += sh[r][threadIdx.x];
+        const int n = blockIdx.x * 64 + threadIdx.x;
+        if (n < N) atomicAdd(db + n, a);
+    }
+}
+
 int pick_splits(int64_t M, int tiles) {
     int64_t s = (768 + tiles - 1) / tiles;             // ~3 workgroups per CU
     const int64_t max_by_rows = (M + 255) / 256;        // >= 256 rows per slice
@@ -179,5 +209,17 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     const int64_t Eeff = db ? E2 : NK;
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK, E2,
                        splits);
+    return clv_check_launch();
+}
+
+extern "C" int clv_colsum(const void* dy, float* db, int64_t M, int32_t N, int32_t ld, void* stream) {
+    if (!dy || !db || M <= 0 || N <= 0 || (N & 7) || (ld & 7)) return CLV_ERR_ARG;
+    const int xb = (N + 63) / 64;
+    int64_t ys = (M + 63) / 64;                      // >= 2 rows per row-lane per block
+    const int64_t want = (512 + xb - 1) / xb;
+    if (ys > want) ys = want;
+    if (ys < 1) ys = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3(xb, (unsigned)ys), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, db,
+                       M, (int)N, (int)ld);
     return clv_check_launch();
 }

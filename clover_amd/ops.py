@@ -116,12 +116,17 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None):
                                  x2.stride(0), _stream()), 'clv_linear_wgrad')
         return (None, None) if sink else (dw, db)
     dwb = torch.mm(dy2.t(), x2)
+    db = None
+    if want_bias:
+        db = db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)
+        if N % 8 == 0 and dy2.stride(0) % 8 == 0:
+            check(_lib.lib().clv_colsum(_ptr(dy2), _ptr(db), M, N, dy2.stride(0), _stream()), 'clv_colsum')
+        else:
+            db.add_(dy2.sum(0, dtype=torch.float32))
     if sink:
         dw_out.add_(dwb)                                    # fp32 += bf16, one kernel
-        if want_bias:
-            db_out.add_(dy2.sum(0, dtype=torch.float32))
         return None, None
-    return dwb.float(), (dy2.sum(0, dtype=torch.float32) if want_bias else None)
+    return dwb.float(), db
 
 
 class _Linear(torch.autograd.Function):

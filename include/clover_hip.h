@@ -132,6 +132,10 @@ int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
                      int32_t N, int32_t K, int32_t ldy, int32_t ldx, void* stream);
 
+/* db[n] += sum_m dy[m][n] (bf16 dy, row stride ld; N, ld multiples of 8): the bias gradient of the
+ * library-GEMM Linear layers (BERT / fusion / MLM head), ACCUMULATED into db. */
+int clv_colsum(const void* dy, float* db, int64_t M, int32_t N, int32_t ld, void* stream);
+
 /* ------------------------------------------------------------------ focal MLM loss
  * SoftmaxFocalLossMultiClass.forward (mmaction/models/losses/focal_loss.py:61-72) on the
  * masked rows selected by multimodal_transformer_pretrain.py:137-139, fused:
