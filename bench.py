@@ -240,12 +240,19 @@ def main():
     if graphed and not args.no_kernel_timing:
         # per-kernel durations: HIP events cannot bracket launches inside a replayed graph, so the same
         # kernels (same shapes, same data) are timed on 3 eager steps right after the timed region
+        # kernels (same shapes, same data) are timed on 3 eager steps right after the timed region.  Each
+        # eager step is queued behind ~40 ms of filler GEMMs so that the host runs ahead and the step's
+        # kernels execute back-to-back at full clocks, as they do inside the graph.
         engine.graph, g = None, engine.graph
+        filler = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
         ops.PROF = {}
         prof_steps = 3
         for _ in range(prof_steps):
+            for _ in range(40):
+                torch.mm(filler, filler)
             engine.step(batch)
         sync()
+        del filler
         prof, ops.PROF = ops.PROF, None
         engine.graph = g
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -122,7 +122,7 @@ struct ScoreCtx {
 };
 
 // ------------------------------------------------------------------------- forward
-template <int HD, int NKT>
+template <int HD, int NKT, bool DROP>
 __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
         sum = grp4_sum(sum);
         if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = m + __logf(sum);
         const float inv = 1.0f / sum;
-        if (G.drop_thresh) {                               // dropout on the probabilities (after softmax)
+        if (DROP) {                                        // dropout on the probabilities (after softmax)
             const unsigned long long sd = *seedp;
             const unsigned rowid = (unsigned)((grp * G.g.nH + h) * N + nq);
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------- backward A: dQ, dbias, D
-template <int HD, int NKT>
+template <int HD, int NKT, bool DROP>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         dsm = grp4_sum(dsm);
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + nq;
         const unsigned rowid = (unsigned)li;
-        const unsigned long long sd = G.drop_thresh ? *seedp : 0ull;
+        const unsigned long long sd = DROP ? *seedp : 0ull;
         if (qv && lg == 0) dsum[li] = dsm;
         const float L = qv ? lse[li] : 0.f;
         const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
                 float pr = __expf(s);
                 if (!full) pr = (key0 + r < N) ? pr : 0.f;
                 float dp = pacc[r];
-                if (G.drop_thresh) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
+                if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
                 ds[r] = pr * (dp - dsm);
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
 }
 
 // ------------------------------------------------------------------------- backward B: dK, dV
-template <int HD, int NKT>
+template <int HD, int NKT, bool DROP>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
 
     const int nkt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
-    const unsigned long long sd = G.drop_thresh ? *seedp : 0ull;
+    const unsigned long long sd = DROP ? *seedp : 0ull;
     for (int kt = wave; kt < nkt; kt += WAVES) {
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                     if (!full) pr = (qn0 + r < N) ? pr : 0.f;
                     pr = kv ? pr : 0.f;
                     float ks = 1.f;
-                    if (G.drop_thresh)
+                    if (DROP)
                         ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + qn0 + r), (unsigned)nk, G.drop_thresh,
                                         G.inv_keep);
                     pv[r] = pr * ks;
@@ -587,13 +587,19 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     if (lds > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int nblk = G.g.groups * G.g.nH;
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
+    if (G.drop_thresh)
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
     return clv_check_launch();
 }
 
@@ -606,16 +612,26 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
         attr = true;
     }
     const int nblk = G.g.groups * G.g.nH;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_a, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o,
-                       (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, (bf16_t*)(bias ? ds_scratch : nullptr), dsum, seed, G);
+    bf16_t* dsp = (bf16_t*)(bias ? ds_scratch : nullptr);
+    if (G.drop_thresh)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds_a, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
+                           kmask, (bf16_t*)dq, dsp, dsum, seed, G);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds_a, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
+                           kmask, (bf16_t*)dq, dsp, dsum, seed, G);
     int rc = clv_check_launch();
     if (rc) return rc;
     if (bias) {
@@ -629,9 +645,14 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         rc = clv_check_launch();
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT>), dim3(nblk), dim3(THREADS), lds_b, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse,
-                       dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G);
+    if (G.drop_thresh)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds_b, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask,
+                           (bf16_t*)dk, (bf16_t*)dv, seed, G);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds_b, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask,
+                           (bf16_t*)dk, (bf16_t*)dv, seed, G);
     return clv_check_launch();
 }
 
