@@ -122,7 +122,7 @@ struct ScoreCtx {
 };
 
 // ------------------------------------------------------------------------- forward
-template <int HD, int NKT, bool DROP>
+template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
-        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
     }
     __syncthreads();
 
@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
         load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
 
         float p[NKT][4];
-        const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
-        const int rq = (rid && qv) ? rid_s[nq] : 0;
+        const float* brow = (MODE == 1 && bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
         // issue every bias load of this query row up front: one L2 latency instead of NKT serial ones
         constexpr bool PRE = NKT <= 16;
         float4 bpre[PRE ? NKT : 1];
@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
             if (PRE) bv = bpre[PRE ? t : 0];
             else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
             float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-            if (rid) {                                   // wave-uniform: shifted block, region-id mask
+            if (MODE == 1 && rid) {                                   // wave-uniform: shifted block, region-id mask
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
                 bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
                 bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
-            } else if (kmask) {
+            } else if (MODE == 0 && kmask) {
                 const float4 km = *reinterpret_cast<const float4*>(aux + key0);
                 bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
             }
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------- backward A: dQ, dbias, D
-template <int HD, int NKT, bool DROP>
+template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -282,8 +282,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
-        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
     }
     __syncthreads();
 
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         const unsigned long long sd = DROP ? *seedp : 0ull;
         if (qv && lg == 0) dsum[li] = dsm;
         const float L = qv ? lse[li] : 0.f;
-        const float* brow = (bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        const float* brow = (MODE == 1 && bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
         constexpr bool PRE = NKT <= 16;
         float4 bpre[PRE ? NKT : 1];
         if (PRE) {
@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        bf16_t* dsrow = (ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
-        const int rq = (rid && qv) ? rid_s[nq] : 0;
+        bf16_t* dsrow = (MODE == 1 && ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
+        const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
 
         Frag8 dsf[NKT / 2];
 #pragma unroll
@@ -339,13 +339,13 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             if (PRE) bv = bpre[PRE ? t : 0];
             else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
             float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-            if (rid) {
+            if (MODE == 1 && rid) {
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
                 bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
                 bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
-            } else if (kmask) {
+            } else if (MODE == 0 && kmask) {
                 const float4 km = *reinterpret_cast<const float4*>(aux + key0);
                 bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
             }
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
 }
 
 // ------------------------------------------------------------------------- backward B: dK, dV
-template <int HD, int NKT, bool DROP>
+template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
@@ -421,8 +421,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
         L_s[n] = (n < N) ? lse[li] : 0.f;
         D_s[n] = (n < N) ? dsum[li] : 0.f;
-        if (rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
     }
     __syncthreads();
 
@@ -436,9 +436,9 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
         Frag8 kf[KS], vf[KS];
         load_frags<HD>(kf, k + krow * G.g.ldk + h * HD, kv, lane);
         load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
-        const int rk = (rid && kv) ? rid_s[nk] : 0;
-        const float kmv = (!rid && kmask && kv) ? aux[nk] : 0.f;
-        const float* btrow = (biasT && kv) ? biasT + ((int64_t)h * N + nk) * G.g.bias_ld : nullptr;
+        const int rk = (MODE == 1 && rid && kv) ? rid_s[nk] : 0;
+        const float kmv = (MODE == 0 && kmask && kv) ? aux[nk] : 0.f;
+        const float* btrow = (MODE == 1 && biasT && kv) ? biasT + ((int64_t)h * N + nk) * G.g.bias_ld : nullptr;
 
         f32x4_t dvacc[NC], dkacc[NC];
 #pragma unroll
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                 float4 bv = make_float4(kmv, kmv, kmv, kmv);
                 if (btrow && qn0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(btrow + qn0);   // biasT[h][key][q..q+3]
                 float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-                if (rid) {
+                if (MODE == 1 && rid) {
                     const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
                     bb[0] += (rq4.x != rk) ? -100.0f : 0.0f;
                     bb[1] += (rq4.y != rk) ? -100.0f : 0.0f;
@@ -580,26 +580,42 @@ size_t dq_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (size_t)NKT * 1
 template <int HD, int NKT>
 size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
 
+// Three compiled variants per (HD, NKT): window (bias/rid, no dropout), sequence, sequence + dropout.
+#define CLV_PICK(KERNEL, ...)                                                                          \
+    do {                                                                                               \
+        if (G.g.mode == 1) { KERNEL<HD, NKT, false, 1> __VA_ARGS__; }                                  \
+        else if (G.drop_thresh) { KERNEL<HD, NKT, true, 0> __VA_ARGS__; }                              \
+        else { KERNEL<HD, NKT, false, 0> __VA_ARGS__; }                                                \
+    } while (0)
+
+template <int HD, int NKT>
+void set_attrs(size_t lds_f, size_t lds_a, size_t lds_b) {
+    static bool done = false;
+    if (done) return;
+    done = true;
+#define CLV_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 1>), lds_f);
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 0>), lds_f);
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, true, 0>), lds_f);
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 1>), lds_a);
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 0>), lds_a);
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, true, 0>), lds_a);
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 1>), lds_b);
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 0>), lds_b);
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, true, 0>), lds_b);
+#undef CLV_ATTR
+}
+
 template <int HD, int NKT>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
                const int32_t* rid, const float* kmask, const unsigned long long* seed, const Geom& G, hipStream_t st) {
     const size_t lds = fwd_lds<HD, NKT>();
-    if (lds > MAX_LDS) return CLV_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD, NKT, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    if (lds > MAX_LDS || dq_lds<HD, NKT>() > MAX_LDS || dkv_lds<HD, NKT>() > MAX_LDS) return CLV_ERR_UNSUPPORTED;
+    if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
+    set_attrs<HD, NKT>(lds, dq_lds<HD, NKT>(), dkv_lds<HD, NKT>());
     const int nblk = G.g.groups * G.g.nH;
-    if (G.drop_thresh)
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G);
+    CLV_PICK(attn_fwd_kernel, <<<dim3(nblk), dim3(THREADS), lds, st>>>((const bf16_t*)q, (const bf16_t*)k,
+             (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G));
     return clv_check_launch();
 }
 
@@ -610,28 +626,13 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
                hipStream_t st) {
     const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD, NKT, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD, NKT, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-        attr = true;
-    }
+    if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
+    set_attrs<HD, NKT>(fwd_lds<HD, NKT>(), lds_a, lds_b);
     const int nblk = G.g.groups * G.g.nH;
     bf16_t* dsp = (bf16_t*)(bias ? ds_scratch : nullptr);
-    if (G.drop_thresh)
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds_a, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
-                           kmask, (bf16_t*)dq, dsp, dsum, seed, G);
-    else
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds_a, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
-                           kmask, (bf16_t*)dq, dsp, dsum, seed, G);
+    CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
+             (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dsp, dsum,
+             seed, G));
     int rc = clv_check_launch();
     if (rc) return rc;
     if (bias) {
@@ -645,14 +646,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         rc = clv_check_launch();
         if (rc) return rc;
     }
-    if (G.drop_thresh)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT, true>), dim3(nblk), dim3(THREADS), lds_b, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask,
-                           (bf16_t*)dk, (bf16_t*)dv, seed, G);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, NKT, false>), dim3(nblk), dim3(THREADS), lds_b, st, (const bf16_t*)q,
-                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask,
-                           (bf16_t*)dk, (bf16_t*)dv, seed, G);
+    CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(THREADS), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
+             (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
     return clv_check_launch();
 }
 
