@@ -37,7 +37,9 @@ SIGNATURES = {
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),
     'clv_im2col_patches': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     'clv_linear_wgrad_work_floats': (C.c_int64, [_i64, _i32, _i32]),
-    'clv_linear_wgrad': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _i32, _p]),
+    'clv_linear_wgrad': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'clv_rowgemm_supported': (C.c_int, [_i32, _i32, _i32]),
+    'clv_rowgemm': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _f, _p]),
     'clv_colsum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p]),
     'clv_focal_ce_fwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
     'clv_focal_ce_bwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),

@@ -217,6 +217,8 @@ class SwinTransformerBlock3D(nn.Module):
         """Residual stream with a PENDING addition: the block input is x (+ branch); returns
         (stream, branch') with block output = stream + branch'.  Both residual adds of the reference
         (:498, :503) are folded into the LayerNorm kernels that follow them (fwd: sum_out, bwd: dsum)."""
+        if self._fused_ok(x):
+            return self._forward_pending_fused(x, branch)
         if branch is None:
             y1, s0 = self.norm1(x), x
         else:
@@ -224,6 +226,34 @@ class SwinTransformerBlock3D(nn.Module):
         a = self.drop_path(self.attn_part(y1))
         y2, s1 = self.norm2(a, residual=s0, return_sum=True)
         return s1, self.drop_path(self.mlp(y2))
+
+    def _fused_ok(self, x):
+        B, D, H, W, C = x.shape
+        ws = get_window_size((D, H, W), self.window_size)
+        no_pad = D % ws[0] == 0 and H % ws[1] == 0 and W % ws[2] == 0
+        return (x.is_cuda and no_pad and self.mlp.drop.p == 0.0 and self.attn.proj_drop.p == 0.0
+                and self.attn.qkv.bias is not None and type(self.mlp.act) is GELU
+                and ops.fused_block_supported(C, self.mlp.fc1.out_features))
+
+    def _forward_pending_fused(self, x, branch):
+        """Stage-0 widths (C <= 128, HBM-bound GEMMs): residual add + LayerNorm + projection fused into the
+        row-streaming MFMA kernel (qkv; fc1 with GELU), GELU backward fused into the fc2 dgrad."""
+        B, D, H, W, C = x.shape
+        ws, ss, rid = window_geometry((D, H, W), self.window_size, self.shift_size, x.device)
+        at = self.attn
+        if branch is None:
+            qkv, _ = ops.ln_linear(x, None, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
+                                   self.norm1.eps)
+            s0 = x
+        else:
+            qkv, s0 = ops.ln_linear(branch, x, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
+                                    self.norm1.eps)
+        bias = gathered_bias(at.relative_position_bias_table, at.relative_position_index, ws[0] * ws[1] * ws[2])
+        o = ops.window_attention(qkv, bias, rid if any(s > 0 for s in ss) else None, ws, ss, self.num_heads)
+        a = self.drop_path(at.proj(o))
+        m, s1 = ops.fused_mlp(a, s0, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                              self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps)
+        return s1, self.drop_path(m)
 
     def forward(self, x, mask_matrix=None):
         """x bf16 [B,D,H,W,C].  ``mask_matrix`` is accepted for signature compatibility and unused:

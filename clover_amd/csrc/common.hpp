@@ -73,9 +73,30 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution):
+// 1 rcp + 1 exp + ~10 fma instead of libm's erff — matters where GELU sits in a GEMM epilogue.
+// Phi(x) = 0.5 (1 + erf(x / sqrt2)); with z = |x| / sqrt2:  erf(z) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p z),
+// and exp(-z^2) = exp(-x^2 / 2) is exactly the factor the derivative needs as well.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    ex = __expf(-0.5f * x * x);
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float h = 0.5f * poly * t * ex;              // 0.5 (1 - erf(z))
+    cdf = (x >= 0.f) ? 1.0f - h : h;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float cdf, ex;
+    gelu_parts(x, cdf, ex);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float cdf, ex;
+    gelu_parts(x, cdf, ex);
+    return fmaf(x * 0.3989422804014327f, ex, cdf);
 }
 
 static inline int clv_check_launch() {

@@ -44,13 +44,33 @@ __device__ __forceinline__ void store_tile(bf16_t* dst, const uint4 (&v)[CHUNKS]
         *reinterpret_cast<uint4*>(dst + (idx >> 4) * LD + (idx & 15) * 8) = v[i];
     }
 }
+// same, but rows are standardised on the way: x_hat = (x - mean[m]) * rstd[m]  (the LayerNorm output that
+// the fused LN+GEMM forward never wrote to HBM)
+__device__ __forceinline__ void store_tile_std(bf16_t* dst, const uint4 (&v)[CHUNKS], int tid, const float* mean,
+                                               const float* rstd, int64_t m0, int64_t m_end) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int idx = tid + i * WG_THREADS;
+        const int64_t m = m0 + (idx >> 4);
+        Frag8 f;
+        f.u4 = v[i];
+        if (m < m_end) {
+            const float mu = mean[m], rs = rstd[m];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                f.u[e] = pack2bf((bf2f(f.h[2 * e]) - mu) * rs, (bf2f(f.h[2 * e + 1]) - mu) * rs);
+        }
+        *reinterpret_cast<uint4*>(dst + (idx >> 4) * LD + (idx & 15) * 8) = f.u4;
+    }
+}
 
 // Register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is
 // consumed from LDS (T14 "issue early / write late"); one LDS buffer, two barriers per 64 rows.
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            float* __restrict__ partial, int64_t M, int N, int K,
                                                            int ldy, int ldx, int tilesK, int64_t rows_per_split,
-                                                           int want_bias) {
+                                                           int want_bias, const float* __restrict__ xmean,
+                                                           const float* __restrict__ xrstd) {
     __shared__ __attribute__((aligned(16))) bf16_t dYs[TM * LD];
     __shared__ __attribute__((aligned(16))) bf16_t Xs[TM * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
@@ -80,7 +100,8 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
     for (int64_t m0 = m_begin; m0 < m_end; m0 += TM) {
         __syncthreads();                                   // previous tile fully consumed
         store_tile(dYs, ry, tid);
-        store_tile(Xs, rx, tid);
+        if (xmean) store_tile_std(Xs, rx, tid, xmean, xrstd, m0, m_end);
+        else store_tile(Xs, rx, tid);
         __syncthreads();
         if (m0 + TM < m_end) {                             // next tile's loads fly under the MFMAs below
             fetch_tile(ry, dy, m0 + TM, m_end, n0, N, ldy, tid);
@@ -192,7 +213,9 @@ extern "C" int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K)
 }
 
 extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
-                                int32_t N, int32_t K, int32_t ldy, int32_t ldx, void* stream) {
+                                int32_t N, int32_t K, int32_t ldy, int32_t ldx, const float* xmean,
+                                const float* xrstd, void* stream) {
+    if ((xmean == nullptr) != (xrstd == nullptr)) return CLV_ERR_ARG;
     if (!dy || !x || !dw || !work || M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (ldy & 7) || (ldx & 7))
         return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -202,7 +225,7 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     int64_t rows = (M + splits - 1) / splits;
     rows = (rows + TM - 1) / TM * TM;
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(WG_THREADS), 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)x, work, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows, db ? 1 : 0);
+                       (const bf16_t*)x, work, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows, db ? 1 : 0, xmean, xrstd);
     int rc = clv_check_launch();
     if (rc) return rc;
     const int64_t NK = (int64_t)N * K, E2 = NK + N;

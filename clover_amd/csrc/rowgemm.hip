@@ -1,0 +1,246 @@
+// Row-streaming MFMA GEMM for the token-parallel projections of the Swin stages (QKV, proj, fc1, fc2
+// and their input-gradient GEMMs):
+//        Y[M][N] = epilogue( prologue(X)[M][K] * Wt[N][K]^T + bias )
+// with M = 10^4..10^5 tokens and K, N of a few hundred, i.e. HBM-bound (AI = K N / (K + N) flop/B is
+// below the 312 flop/B ridge).  A library GEMM reaches ~2 TB/s on these shapes and needs separate
+// LayerNorm / GELU passes; here
+//   * the weight tile (<= 128 x K) sits in LDS for the whole launch, X rows stream through registers
+//     exactly once per column tile as MFMA A-fragments (16-B loads);
+//   * prologue (optional): x = a + r (residual add, written back as the new residual stream) and
+//     row standardisation (x - mean) * rstd — LayerNorm with its affine part folded into Wt / bias by
+//     the caller — from the very fragments the MFMA consumes (statistics also written out);
+//   * epilogue: + bias, optional erf-GELU (also emitting the pre-activation for the backward) or
+//     multiplication by gelu'(pre) (the GELU backward fused into the fc2 input-gradient GEMM);
+//   * results leave through a per-wave LDS tile as full 16-B row chunks.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+constexpr int RG_THREADS = 256;
+constexpr int RG_WAVES = 4;
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_BWD = 2 };
+
+template <int KS>
+struct RGCfg {
+    static constexpr int K = KS * 32;
+    static constexpr int TN = (KS <= 12) ? 128 : 64;       // columns per workgroup
+    static constexpr int LDW = K + 8;                       // padded LDS row of the weight tile
+    static constexpr int LDO = TN + 8;
+};
+
+template <int KS, bool STD, int EPI>
+__global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ sum_out,
+    float* __restrict__ mean, float* __restrict__ rstd, const bf16_t* __restrict__ wt,
+    const float* __restrict__ bias, const bf16_t* __restrict__ pre_in, bf16_t* __restrict__ y,
+    bf16_t* __restrict__ pre_out, int64_t M, int N, int ldx, int ldy, float eps) {
+    using C = RGCfg<KS>;
+    constexpr int K = C::K, TN = C::TN, LDW = C::LDW, LDO = C::LDO, NT = TN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* stage = Ws + TN * LDW;                          // [RG_WAVES][EPI ? 2 : 1][16 * LDO]
+    constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int n0 = blockIdx.y * TN;
+    const bool first_col = blockIdx.y == 0;
+
+    // ---- weight tile -> LDS (rows >= N zero)
+    for (int idx = tid; idx < TN * (K / 8); idx += RG_THREADS) {
+        const int r = idx / (K / 8), c8 = idx - r * (K / 8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n0 + r < N) v = *reinterpret_cast<const uint4*>(wt + (int64_t)(n0 + r) * K + c8 * 8);
+        *reinterpret_cast<uint4*>(Ws + r * LDW + c8 * 8) = v;
+    }
+    float bn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 16 + lr;
+        bn[nt] = (bias && n < N) ? bias[n] : 0.f;
+    }
+    __syncthreads();
+
+    bf16_t* st0 = stage + (wave * NST) * 16 * LDO;
+    bf16_t* st1 = st0 + 16 * LDO;
+    const int64_t ntiles = (M + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * RG_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * RG_WAVES) {
+        const int64_t m0 = tile * 16;
+        const int64_t row = m0 + lr;
+        const bool rv = row < M;
+        Frag8 af[KS];
+        // ---- A fragments (+ residual, + standardisation)
+        if (STD || res) {
+            float xs[KS * 8];
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Frag8 a, r;
+                a.u4 = rv ? *reinterpret_cast<const uint4*>(x + row * ldx + s * 32 + lg * 8) : make_uint4(0, 0, 0, 0);
+                r.u4 = (rv && res) ? *reinterpret_cast<const uint4*>(res + row * ldx + s * 32 + lg * 8)
+                                   : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = bf2f(a.h[e]) + bf2f(r.h[e]);
+                    xs[s * 8 + e] = v;
+                    sum += v;
+                }
+                if (res && sum_out && first_col && rv) {
+                    Frag8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.u[e] = pack2bf(xs[s * 8 + 2 * e], xs[s * 8 + 2 * e + 1]);
+                    *reinterpret_cast<uint4*>(sum_out + row * ldx + s * 32 + lg * 8) = o.u4;
+                }
+            }
+            float mu = 0.f, rs = 1.f;
+            if (STD) {
+                mu = grp4_sum(sum) * (1.0f / K);
+                float vs = 0.f;
+#pragma unroll
+                for (int i = 0; i < KS * 8; ++i) vs += (xs[i] - mu) * (xs[i] - mu);
+                rs = rsqrtf(grp4_sum(vs) * (1.0f / K) + eps);
+                if (first_col && rv && lg == 0) {
+                    mean[row] = mu;
+                    rstd[row] = rs;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    af[s].u[e] = pack2bf((xs[s * 8 + 2 * e] - mu) * rs, (xs[s * 8 + 2 * e + 1] - mu) * rs);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                af[s].u4 = rv ? *reinterpret_cast<const uint4*>(x + row * ldx + s * 32 + lg * 8) : make_uint4(0, 0, 0, 0);
+        }
+        // ---- GELU backward: stage the pre-activation tile (coalesced) before it is needed per element
+        if (EPI == EPI_GELU_BWD) {
+            for (int idx = lane; idx < 16 * (TN / 8); idx += 64) {
+                const int tr = idx / (TN / 8), c8 = idx - tr * (TN / 8);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m0 + tr < M && n0 + c8 * 8 < N)
+                    v = *reinterpret_cast<const uint4*>(pre_in + (m0 + tr) * ldy + n0 + c8 * 8);
+                *reinterpret_cast<uint4*>(st1 + tr * LDO + c8 * 8) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- MFMA over the column tiles; epilogue into the wave's staging tile
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Frag8 b;
+                b.u4 = *reinterpret_cast<const uint4*>(Ws + (nt * 16 + lr) * LDW + s * 32 + lg * 8);
+                acc = mfma16(af[s], b, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int off = (lg * 4 + r) * LDO + nt * 16 + lr;
+                float v = acc[r] + bn[nt];
+                if (EPI == EPI_GELU) {
+                    st1[off] = f2bf(v);                    // pre-activation (kept for the backward)
+                    v = gelu_erf(v);
+                } else if (EPI == EPI_GELU_BWD) {
+                    v *= gelu_erf_grad(bf2f(st1[off]));
+                }
+                st0[off] = f2bf(v);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < 16 * (TN / 8); idx += 64) {
+            const int tr = idx / (TN / 8), c8 = idx - tr * (TN / 8);
+            if (m0 + tr < M && n0 + c8 * 8 < N) {
+                *reinterpret_cast<uint4*>(y + (m0 + tr) * ldy + n0 + c8 * 8) =
+                    *reinterpret_cast<const uint4*>(st0 + tr * LDO + c8 * 8);
+                if (EPI == EPI_GELU)
+                    *reinterpret_cast<uint4*>(pre_out + (m0 + tr) * ldy + n0 + c8 * 8) =
+                        *reinterpret_cast<const uint4*>(st1 + tr * LDO + c8 * 8);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int KS, bool STD, int EPI>
+int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float* rstd, const void* wt,
+              const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int N, int ldx, int ldy,
+              float eps, hipStream_t st) {
+    using C = RGCfg<KS>;
+    constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
+    const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)RG_WAVES * NST * 16 * C::LDO * 2;
+    if (lds > 160 * 1024) return CLV_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KS, STD, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int ny = (N + C::TN - 1) / C::TN;
+    const int64_t row_blocks = ((M + 15) / 16 + RG_WAVES - 1) / RG_WAVES;
+    int64_t gx = 1536 / ny;
+    if (gx < 256) gx = 256;
+    if (gx > row_blocks) gx = row_blocks;
+    rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)gx, ny), dim3(RG_THREADS), lds, st>>>(
+        (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)sum_out, mean, rstd, (const bf16_t*)wt, bias,
+        (const bf16_t*)pre_in, (bf16_t*)y, (bf16_t*)pre_out, M, N, ldx, ldy, eps);
+    return clv_check_launch();
+}
+
+template <int KS>
+int dispatch_rg(bool stdz, int epi, const void* x, const void* res, void* sum_out, float* mean, float* rstd,
+                const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int N,
+                int ldx, int ldy, float eps, hipStream_t st) {
+#define RG_CALL(S, E) launch_rg<KS, S, E>(x, res, sum_out, mean, rstd, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st)
+    if (stdz) {
+        if constexpr (KS <= 8) {                            // standardisation keeps the fp32 row in registers
+            if (epi == EPI_NONE) return RG_CALL(true, EPI_NONE);
+            if (epi == EPI_GELU) return RG_CALL(true, EPI_GELU);
+        }
+        return CLV_ERR_UNSUPPORTED;
+    }
+    if (epi == EPI_NONE) return RG_CALL(false, EPI_NONE);
+    if (epi == EPI_GELU_BWD) return RG_CALL(false, EPI_GELU_BWD);
+    return CLV_ERR_UNSUPPORTED;
+#undef RG_CALL
+}
+
+}  // namespace
+
+extern "C" int clv_rowgemm_supported(int32_t N, int32_t K, int32_t standardise) {
+    static const int ks_ok[] = {3, 4, 6, 8, 9, 12, 16, 18, 24};
+    if (K % 32 || N % 8 || N <= 0) return 0;
+    const int ks = K / 32;
+    bool ok = false;
+    for (int v : ks_ok) ok |= (v == ks);
+    if (!ok) return 0;
+    if (standardise && ks > 8) return 0;
+    return 1;
+}
+
+extern "C" int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, const void* wt,
+                           const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+                           int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
+                           void* stream) {
+    if (!x || !wt || !y || M <= 0 || !clv_rowgemm_supported(N, K, standardise) || (ldx & 7) || (ldy & 7) || ldx < K ||
+        ldy < N)
+        return CLV_ERR_ARG;
+    if (standardise && (!mean || !rstd)) return CLV_ERR_ARG;
+    if (res && !sum_out) return CLV_ERR_ARG;
+    if (epilogue == EPI_GELU && !pre_out) return CLV_ERR_ARG;
+    if (epilogue == EPI_GELU_BWD && !pre_in) return CLV_ERR_ARG;
+    if (res && !standardise) return CLV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const bool sz = standardise != 0;
+#define RG_KS(V) case V: return dispatch_rg<V>(sz, epilogue, x, res, sum_out, mean, rstd, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st)
+    switch (K / 32) {
+        RG_KS(3); RG_KS(4); RG_KS(6); RG_KS(8); RG_KS(9); RG_KS(12); RG_KS(16); RG_KS(18); RG_KS(24);
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef RG_KS
+}

@@ -100,20 +100,25 @@ def _wgrad_custom(M, N, K):
     return M >= 2048 and N * K <= (1 << 20) and N % 8 == 0 and K % 8 == 0
 
 
-def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None):
+def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
     """dW fp32 [N,K] and db fp32 [N] of y = x W^T + b for bf16 dy2 [M,N], x2 [M,K].
     With dw_out / db_out (fp32, e.g. views of the engine's flat gradient slab) the result is
-    ACCUMULATED into them in place and (None, None) is returned."""
+    ACCUMULATED into them in place and (None, None) is returned.  xstats = (mean, rstd): the GEMM
+    operand is the row-standardised x (the LayerNorm output a fused forward never stored)."""
     M, N = dy2.shape
     K = x2.shape[1]
     sink = dw_out is not None
+    if xstats is not None and not _wgrad_custom(M, N, K):
+        x2 = ((x2.float() - xstats[0][:, None]) * xstats[1][:, None]).to(BF16)
+        xstats = None
     if _wgrad_custom(M, N, K):
         L = _lib.lib()
         dw = dw_out if sink else torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
         db = (db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)) if want_bias else None
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
         check(L.clv_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0),
-                                 x2.stride(0), _stream()), 'clv_linear_wgrad')
+                                 x2.stride(0), _ptr(xstats[0] if xstats else None),
+                                 _ptr(xstats[1] if xstats else None), _stream()), 'clv_linear_wgrad')
         return (None, None) if sink else (dw, db)
     dwb = torch.mm(dy2.t(), x2)
     db = None
@@ -127,6 +132,31 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None):
         dw_out.add_(dwb)                                    # fp32 += bf16, one kernel
         return None, None
     return dwb.float(), db
+
+
+def _rowgemm_fwd_ok(x, N, K):
+    """Forward y = x W^T: the row-streaming kernel wins for K <= 128 (stage-0 Swin widths)."""
+    return x.is_cuda and K <= 128 and x.stride(-1) == 1 and rowgemm_supported(N, K)
+
+
+def linear_dgrad(dy2, wb):
+    """dx [M,K] = dy [M,N] . W [N,K]: as a row-streaming GEMM over the contraction N when that is
+    short (<= 288) or the output is narrow (K <= 128); the library GEMM otherwise."""
+    N, K = wb.shape
+    if dy2.is_cuda and (N <= 288 or K <= 128 and N <= 384) and rowgemm_supported(K, N) and dy2.stride(1) == 1:
+        return rowgemm(dy2, wb.t().contiguous(), None)['y']
+    return torch.mm(dy2, wb)
+
+
+def _sink_or_return(param, grad):
+    """Accumulate `grad` into an engine-managed parameter's flat-slab view (returns None), or hand it
+    back to autograd."""
+    sink = getattr(param, '_clv_grad', None)
+    if sink is not None:
+        sink.add_(grad.view_as(sink))
+        param._clv_ready()
+        return None
+    return grad.to(param.dtype)
 
 
 class _Linear(torch.autograd.Function):
@@ -151,7 +181,12 @@ class _Linear(torch.autograd.Function):
             bb = getattr(bias, '_clv_shadow', None)
             if bb is None:
                 bb = bias.to(BF16)
-        y = torch.nn.functional.linear(xb, wb, bb)
+        N, K = wb.shape
+        if _rowgemm_fwd_ok(xb, N, K):
+            bf = bias if bias is not None and bias.dtype == torch.float32 else (bias.float() if bias is not None else None)
+            y = rowgemm(xb.reshape(-1, K), wb, bf)['y'].view(xb.shape[:-1] + (N,))
+        else:
+            y = torch.nn.functional.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.has_bias = bias is not None
         ctx.wdtype = weight.dtype
@@ -167,7 +202,7 @@ class _Linear(torch.autograd.Function):
             dy2 = dy2.to(BF16)
         dy2 = _c(dy2)
         x2 = _c(xb.reshape(-1, K))
-        dx = torch.mm(dy2, wb).view(xb.shape) if ctx.needs_input_grad[0] else None
+        dx = linear_dgrad(dy2, wb).view(xb.shape) if ctx.needs_input_grad[0] else None
         dw, db = (None, None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             wsink = getattr(ctx.wref, '_clv_grad', None)
@@ -184,8 +219,179 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
+    """dx = LayerNorm-backward of dxhat w.r.t. x for the affine-free standardisation (+ dsum)."""
+    rows, C_ = x.shape
+    L = _lib.lib()
+    nblk = L.clv_layernorm_bwd_blocks(rows, C_)
+    dev = x.device
+    partial = torch.empty(2 * nblk * C_, device=dev, dtype=torch.float32)
+    ones = torch.ones(C_, device=dev, dtype=torch.float32)
+    junk = torch.zeros(2 * C_, device=dev, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    ds2 = None
+    if dsum is not None:
+        ds2 = _c(dsum).view(rows, C_)
+        if ds2.dtype != BF16:
+            ds2 = ds2.to(BF16)
+    check(L.clv_layernorm_bwd(_ptr(dxhat), _ptr(x), _ptr(None), _ptr(ones), _ptr(mean), _ptr(rstd), _ptr(ds2),
+                              _ptr(dx), _ptr(junk), C.c_void_p(junk.data_ptr() + 4 * C_), _ptr(partial), rows, C_, 0,
+                              _stream()), 'clv_layernorm_bwd')
+    return dx
+
+
+def fold_layernorm(weight, bias, gamma, beta):
+    """LayerNorm's affine part folded into the following Linear (tiny autograd-tracked torch ops):
+    (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta)."""
+    wf = weight.float() * gamma.float()[None, :]
+    bf = torch.mv(weight.float(), beta.float())
+    if bias is not None:
+        bf = bf + bias.float()
+    return wf, bf
+
+
+class _FusedLNLinear(torch.autograd.Function):
+    """(y, s) = (LN_noaffine(a [+ r]) Wf^T + bf,  a + r) in ONE row-streaming kernel: residual add,
+    LayerNorm statistics + standardisation and the projection (swin_transformer_3d.py:450 + :376)."""
+
+    @staticmethod
+    def forward(ctx, a, r, wf, bf, eps):
+        _need_gpu(a, wf)
+        K = a.shape[-1]
+        N = wf.shape[0]
+        a2 = _c(a).view(-1, K)
+        r2 = _c(r).view(-1, K) if r is not None else None
+        wt = wf.to(BF16)
+        out = rowgemm(a2, wt, bf, res=r2, standardise=True, eps=eps)
+        xs = out['sum'] if r is not None else a2
+        ctx.save_for_backward(xs, out['mean'], out['rstd'], wt)
+        ctx.has_res = r is not None
+        ctx.shape = a.shape
+        y = out['y'].view(a.shape[:-1] + (N,))
+        return y, (out['sum'].view(a.shape) if r is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy, ds):
+        xs, mean, rstd, wt = ctx.saved_tensors
+        N, K = wt.shape
+        dy2 = _c(dy.reshape(-1, N))
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dxhat = linear_dgrad(dy2, wt)
+        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
+        dwf, dbf = linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
+        return dx, (dx if ctx.has_res else None), dwf, dbf, None
+
+
+def ln_linear(a, r, ln_weight, ln_bias, weight, bias, eps=1e-5):
+    """y = Linear(LayerNorm(a [+ r])), s = a + r (None without r)."""
+    wf, bf = fold_layernorm(weight, bias, ln_weight, ln_bias)
+    return _FusedLNLinear.apply(a, r, wf, bf, eps)
+
+
+class _FusedMLP(torch.autograd.Function):
+    """(out, s) = (fc2(GELU(fc1(LN(a + r)))),  a + r): kernel 1 = residual add + LayerNorm + fc1 + bias +
+    GELU (pre-activation kept), kernel 2 = fc2; backward: fc2 input-gradient GEMM with the GELU
+    backward in its epilogue, split-M weight gradients (fc1's on the re-standardised rows), LayerNorm
+    backward with the residual-path gradient folded in (swin_transformer_3d.py:482-483,262-268,503)."""
+
+    @staticmethod
+    def forward(ctx, a, r, wf1, bf1, w2, b2, eps):
+        _need_gpu(a, wf1)
+        K = a.shape[-1]
+        a2 = _c(a).view(-1, K)
+        r2 = _c(r).view(-1, K) if r is not None else None
+        wt1 = wf1.to(BF16)
+        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps)
+        xs = o1['sum'] if r is not None else a2
+        w2b = getattr(w2, '_clv_shadow', None)
+        if w2b is None:
+            w2b = w2.to(BF16)
+        b2b = None
+        if b2 is not None:
+            b2b = getattr(b2, '_clv_shadow', None)
+            if b2b is None:
+                b2b = b2.to(BF16)
+        out = torch.nn.functional.linear(o1['y'], w2b, b2b)
+        ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b)
+        ctx.has_res = r is not None
+        ctx.shape = a.shape
+        ctx.w2ref, ctx.b2ref = w2, b2
+        return out.view(a.shape), (o1['sum'].view(a.shape) if r is not None else None)
+
+    @staticmethod
+    def backward(ctx, dout, ds):
+        xs, mean, rstd, wt1, pre, act, w2b = ctx.saved_tensors
+        C_, Hd = w2b.shape                              # fc2: [C, 4C]
+        do2 = _c(dout.reshape(-1, C_))
+        if do2.dtype != BF16:
+            do2 = do2.to(BF16)
+        # d pre = (d out . W2) * gelu'(pre)
+        if rowgemm_supported(Hd, C_) and C_ <= 288:
+            dpre = rowgemm(do2, w2b.t().contiguous(), None, epilogue=2, pre_in=pre)['y']
+        else:
+            dact = torch.mm(do2, w2b)
+            dpre = torch.empty_like(dact)
+            check(_lib.lib().clv_gelu_bwd(_ptr(dact), _ptr(pre), _ptr(dpre), dact.numel(), 0, _stream()), 'clv_gelu_bwd')
+        # fc2 parameter gradients
+        w2, b2 = ctx.w2ref, ctx.b2ref
+        wsink = getattr(w2, '_clv_grad', None)
+        bsink = getattr(b2, '_clv_grad', None) if b2 is not None else None
+        dw2 = db2 = None
+        if wsink is not None and (bsink is not None or b2 is None):
+            linear_wgrad(do2, act, b2 is not None, wsink, bsink)
+            w2._clv_ready()
+            if b2 is not None:
+                b2._clv_ready()
+        else:
+            dw2, db2 = linear_wgrad(do2, act, b2 is not None)
+            dw2 = dw2.to(w2.dtype)
+            db2 = db2.to(b2.dtype) if db2 is not None else None
+        # fc1 + LayerNorm
+        dxhat = linear_dgrad(dpre, wt1)
+        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
+        dwf1, dbf1 = linear_wgrad(dpre, xs, True, xstats=(mean, rstd))
+        return dx, (dx if ctx.has_res else None), dwf1, dbf1, dw2, db2, None
+
+
+def fused_mlp(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps=1e-5):
+    """out = fc2(GELU(fc1(LayerNorm(a [+ r])))), s = a + r."""
+    wf1, bf1 = fold_layernorm(w1, b1, ln_weight, ln_bias)
+    return _FusedMLP.apply(a, r, wf1, bf1, w2, b2, eps)
+
+
+def fused_block_supported(C_, hidden):
+    """Widths for which the fused LN+projection / MLP kernels are used (stage-0 Swin-T/B: 96, 128)."""
+    return (C_ <= 128 and rowgemm_supported(3 * C_, C_, True) and rowgemm_supported(hidden, C_, True)
+            and hidden % 32 == 0)
+
+
 def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------- row-streaming GEMM
+def rowgemm_supported(N, K, standardise=False):
+    return bool(_lib.lib().clv_rowgemm_supported(int(N), int(K), int(bool(standardise))))
+
+
+def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=None, eps=1e-5):
+    """Raw launcher of clv_rowgemm (no autograd).  x bf16 [M,K]; wt bf16 [N,K]; bias fp32 [N] | None.
+    Returns dict(y, sum, mean, rstd, pre) (entries None when not produced)."""
+    _need_gpu(x, wt)
+    M, K = x.shape
+    N = wt.shape[0]
+    assert x.dtype == BF16 and wt.dtype == BF16 and x.stride(1) == 1 and wt.is_contiguous()
+    y = torch.empty(M, N, device=x.device, dtype=BF16)
+    ssum = torch.empty_like(x) if res is not None else None
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if standardise else None
+    rstd = torch.empty_like(mean) if standardise else None
+    pre = torch.empty_like(y) if epilogue == 1 else None
+    bf = _c(bias.float()) if bias is not None else None
+    check(_lib.lib().clv_rowgemm(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(wt), _ptr(bf),
+                                 _ptr(pre_in), _ptr(y), _ptr(pre), M, N, K, x.stride(0), N, int(bool(standardise)),
+                                 int(epilogue), float(eps), _stream()), 'clv_rowgemm')
+    return dict(y=y, sum=ssum, mean=mean, rstd=rstd, pre=pre)
 
 
 # --------------------------------------------------------------------------- LayerNorm

@@ -127,10 +127,32 @@ int clv_im2col_patches(const float* x, void* patches, int32_t B, int32_t T, int3
  * 361-363,518; the conv3d weight of :665 through clv_im2col_patches) for huge M and small N x K,
  * where the contraction (token) dimension is split over the whole chip.  dy bf16 [M][N] (row stride
  * ldy), x bf16 [M][K] (row stride ldx); dw float [N][K], db float [N] or NULL — both ACCUMULATED
- * into.  N, K, ldy, ldx multiples of 8.  work: float scratch, clv_linear_wgrad_work_floats(). */
+ * into.  N, K, ldy, ldx multiples of 8.  work: float scratch, clv_linear_wgrad_work_floats().
+ * xmean / xrstd (float [M], both or neither): X rows are standardised on load,
+ * x_hat = (x - mean) * rstd — the LayerNorm output the fused clv_rowgemm forward never stored. */
 int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
-                     int32_t N, int32_t K, int32_t ldy, int32_t ldx, void* stream);
+                     int32_t N, int32_t K, int32_t ldy, int32_t ldx, const float* xmean,
+                     const float* xrstd, void* stream);
+
+/* ------------------------------------------------------------------ token-parallel projections
+ * Y[M][N] = epilogue( prologue(X)[M][K] * Wt[N][K]^T + bias ) — the QKV / proj / fc1 / fc2 Linears of
+ * the high-resolution Swin stages and their input-gradient GEMMs (swin_transformer_3d.py:376,398,
+ * 263-266), HBM-bound (K, N of a few hundred, M = 10^4..10^5 tokens), with the neighbouring
+ * memory-bound ops folded in:
+ *   prologue  standardise != 0: x = X (+ res; the sum is written to sum_out), then (x - mean) * rstd —
+ *             nn.LayerNorm (:450,483) with its affine part folded into Wt/bias by the caller; mean, rstd
+ *             (float [M]) are outputs;
+ *   epilogue  0: + bias;  1: + bias, erf-GELU (:264), the pre-activation goes to pre_out;
+ *             2: multiply by gelu'(pre_in) (GELU backward fused into the fc2 input-gradient GEMM).
+ * X, res, sum_out bf16 [M][K] (row stride ldx); Wt bf16 [N][K] contiguous; bias float [N] or NULL;
+ * Y, pre_in, pre_out bf16 [M][N] (row stride ldy).  K in {96,128,192,256,288,384,512,576,768}
+ * (<= 256 with standardise), N % 8 == 0: query clv_rowgemm_supported(). */
+int clv_rowgemm_supported(int32_t N, int32_t K, int32_t standardise);
+int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, const void* wt,
+                const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+                int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
+                void* stream);
 
 /* db[n] += sum_m dy[m][n] (bf16 dy, row stride ld; N, ld multiples of 8): the bias gradient of the
  * library-GEMM Linear layers (BERT / fusion / MLM head), ACCUMULATED into db. */

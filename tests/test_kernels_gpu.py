@@ -332,3 +332,83 @@ def test_seq_attention_dropout():
     o2.backward(do.to(DEV))
     assert rel(o2, o_ref) < 2e-2, rel(o2, o_ref)
     assert rel(qg.grad, qr.grad) < 3e-2, rel(qg.grad, qr.grad)
+
+
+# ----------------------------------------------------------------------------- row-streaming GEMM
+@pytest.mark.parametrize('M,N,K', [(5000, 288, 96), (3001, 96, 384), (2000, 768, 192), (1000, 192, 768), (777, 96, 288)])
+def test_rowgemm_plain_and_gelu_bwd(M, N, K):
+    x = rnd(M, K, seed=101).to(BF)
+    w = rnd(N, K, scale=0.1, seed=102).to(BF)
+    b = rnd(N, scale=0.1, seed=103)
+    ref = x.float() @ w.float().t() + b
+    out = ops().rowgemm(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert rel(out['y'], ref) < 1e-2
+    pre = rnd(M, N, seed=104).to(BF)
+    xr = pre.float().requires_grad_()
+    om.gelu(xr).backward(ref - b)                                  # = (x W^T) * gelu'(pre)
+    out2 = ops().rowgemm(x.to(DEV), w.to(DEV), None, epilogue=2, pre_in=pre.to(DEV))
+    assert rel(out2['y'], xr.grad) < 2e-2
+
+
+@pytest.mark.parametrize('M,N,K,with_res,gelu', [(5000, 288, 96, True, False), (3001, 384, 96, True, True),
+                                                 (2000, 576, 192, False, False), (1000, 768, 192, True, True),
+                                                 (900, 384, 128, False, True)])
+def test_rowgemm_layernorm_prologue(M, N, K, with_res, gelu):
+    x = rnd(M, K, seed=111).to(BF)
+    r = rnd(M, K, seed=112).to(BF) if with_res else None
+    w = rnd(N, K, scale=0.1, seed=113).to(BF)
+    b = rnd(N, scale=0.1, seed=114)
+    s = x.float() + (r.float() if with_res else 0)
+    xh = F.layer_norm(s, (K,), None, None, 1e-5)
+    pre = xh @ w.float().t() + b
+    out = ops().rowgemm(x.to(DEV), w.to(DEV), b.to(DEV), res=r.to(DEV) if with_res else None, standardise=True,
+                        epilogue=1 if gelu else 0)
+    assert rel(out['y'], om.gelu(pre) if gelu else pre) < 1.5e-2
+    if gelu:
+        assert rel(out['pre'], pre) < 1.5e-2
+    if with_res:
+        assert rel(out['sum'], s) < 1e-2
+    assert rel(out['mean'], s.mean(-1)) < 1e-3 and rel(out['rstd'], (s.var(-1, unbiased=False) + 1e-5).rsqrt()) < 1e-3
+
+
+@pytest.mark.parametrize('C,with_res', [(96, True), (128, False)])
+def test_fused_ln_linear_and_mlp(C, with_res):
+    """Fused residual + LayerNorm + projection, and the fused MLP block, against the plain fp32 composition."""
+    M, Hd = 3000, 4 * C
+    a, r = rnd(M, C, seed=121).to(BF), rnd(M, C, seed=122).to(BF)
+    P = dict(g=1 + 0.1 * rnd(C, seed=123), b=0.1 * rnd(C, seed=124), wq=rnd(3 * C, C, scale=0.1, seed=125),
+             bq=0.1 * rnd(3 * C, seed=126), w1=rnd(Hd, C, scale=0.1, seed=127), b1=0.1 * rnd(Hd, seed=128),
+             w2=rnd(C, Hd, scale=0.05, seed=129), b2=0.1 * rnd(C, seed=130))
+    dq, dm, ds = rnd(M, 3 * C, seed=131).to(BF), rnd(M, C, seed=132).to(BF), rnd(M, C, seed=133).to(BF)
+
+    def run(dev, fused):
+        ar, rr = a.to(dev).float().requires_grad_(), r.to(dev).float().requires_grad_()
+        Q = {k: v.to(dev).clone().requires_grad_() for k, v in P.items()}
+        if fused:
+            ab, rb = ar.to(BF), (rr.to(BF) if with_res else None)
+            q, s = ops().ln_linear(ab, rb, Q['g'], Q['b'], Q['wq'], Q['bq'])
+            m, s2 = ops().fused_mlp(ab, rb, Q['g'], Q['b'], Q['w1'], Q['b1'], Q['w2'], Q['b2'])
+            outs, grads = [q, m], [dq.to(dev), dm.to(dev)]
+            if with_res:
+                outs += [s, s2]
+                grads += [ds.to(dev), ds.to(dev)]
+        else:
+            s = ar + rr if with_res else ar
+            y = F.layer_norm(s, (C,), Q['g'], Q['b'], 1e-5)
+            q = F.linear(y, Q['wq'], Q['bq'])
+            m = F.linear(om.gelu(F.linear(y, Q['w1'], Q['b1'])), Q['w2'], Q['b2'])
+            outs, grads = [q, m], [dq.float(), dm.float()]
+            if with_res:
+                outs += [s, s]
+                grads += [ds.float(), ds.float()]
+        torch.autograd.backward(outs, grads)
+        return outs, ar.grad, (rr.grad if with_res else None), {k: v.grad for k, v in Q.items()}
+
+    o_ref, ga_ref, gr_ref, gp_ref = run('cpu', False)
+    o, ga, gr, gp = run(DEV, True)
+    assert rel(o[0], o_ref[0]) < 2e-2 and rel(o[1], o_ref[1]) < 2e-2
+    assert rel(ga, ga_ref) < 3e-2
+    if with_res:
+        assert rel(gr, gr_ref) < 3e-2 and rel(o[2], o_ref[2]) < 1e-2
+    for k in P:
+        assert rel(gp[k], gp_ref[k]) < 3e-2, (k, rel(gp[k], gp_ref[k]))
