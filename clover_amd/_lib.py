@@ -28,7 +28,7 @@ _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
-    'clv_attn_bwd': (C.c_int, [_p] * 17 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_bwd': (C.c_int, [_p] * 17 + [_i32, C.POINTER(ClvAttnGeom), _p]),
     'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _p]),
@@ -37,7 +37,7 @@ SIGNATURES = {
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),
     'clv_im2col_patches': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     'clv_linear_wgrad_work_floats': (C.c_int64, [_i64, _i32, _i32]),
-    'clv_linear_wgrad': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'clv_linear_wgrad': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
     'clv_rowgemm_supported': (C.c_int, [_i32, _i32, _i32]),
     'clv_rowgemm': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _f, _p]),
     'clv_colsum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p]),

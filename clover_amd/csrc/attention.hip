@@ -622,20 +622,23 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                const float* lse, const float* bias, const float* biasT, const int32_t* rid, const float* kmask, void* dq,
-               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const unsigned long long* seed, const Geom& G,
-               hipStream_t st) {
+               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const unsigned long long* seed, int stages,
+               const Geom& G, hipStream_t st) {
     const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>(fwd_lds<HD, NKT>(), lds_a, lds_b);
     const int nblk = G.g.groups * G.g.nH;
     bf16_t* dsp = (bf16_t*)(bias ? ds_scratch : nullptr);
-    CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
-             (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dsp, dsum,
-             seed, G));
-    int rc = clv_check_launch();
-    if (rc) return rc;
-    if (bias) {
+    int rc = CLV_OK;
+    if (stages & 1) {
+        CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
+                 (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dsp, dsum,
+                 seed, G));
+        rc = clv_check_launch();
+        if (rc) return rc;
+    }
+    if (bias && (stages & 2)) {
         const int64_t E8 = (int64_t)G.g.nH * G.g.N * G.g.bias_ld / 8;
         const int xb = (int)((E8 + 255) / 256);
         int splits = 1024 / (xb > 0 ? xb : 1);
@@ -646,9 +649,12 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         rc = clv_check_launch();
         if (rc) return rc;
     }
-    CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(THREADS), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
-             (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
-    return clv_check_launch();
+    if (stages & 4) {
+        CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(THREADS), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
+                 (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
+        rc = clv_check_launch();
+    }
+    return rc;
 }
 
 // smallest instantiated key-tile count >= need
@@ -691,16 +697,17 @@ extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const v
                             const float* lse, const float* bias, const float* biasT, const int32_t* rid,
                             const float* kmask,
                             void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
-                            const void* seed, const ClvAttnGeom* geom, void* stream) {
+                            const void* seed, int32_t stages, const ClvAttnGeom* geom, void* stream) {
     Geom G;
     const unsigned long long* sp = (const unsigned long long*)seed;
+    if (stages == 0) stages = 7;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
     if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch || !biasT)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     if (G.drop_thresh && !seed) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st) }
-    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st)
 }

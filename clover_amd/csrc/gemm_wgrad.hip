@@ -1,19 +1,20 @@
-// Weight / bias gradient of a Linear layer for the token-parallel (huge-M, small N x K) shapes of
-// the Swin stages and the patch embedding:
+// Weight / bias gradient of a Linear layer:
 //       dW[n][k] += sum_m dY[m][n] * X[m][k]        db[n] += sum_m dY[m][n]
-// A library GEMM tiles the N x K OUTPUT (e.g. 288 x 96 -> ~10 workgroups on 256 CUs) and walks
-// M = 200 704 serially.  Here the contraction dimension is split over the whole chip: every
-// workgroup owns a 128 x 128 output tile for one M-slice, streams dY and X once (16-B coalesced
-// rows into LDS), feeds both MFMA operands with LDS transpose reads (the contraction index m runs
-// along the ROWS of both tiles), and writes an fp32 partial; a second streaming kernel folds the
-// partials into dW/db.  HBM-bound: algorithmic bytes = M (N + K) * 2.
+// For the token-parallel layers (Swin stages, patch embedding: M = 12 544 .. 200 704 rows, N x K small) a library
+// GEMM tiles the N x K OUTPUT (e.g. 288 x 96 -> ~10 workgroups on 256 CUs) and walks M serially.  Here the
+// contraction dimension is split over the whole chip: every workgroup owns a 128 x 128 output tile for one
+// M-slice, streams its dY and X rows through LDS, feeds both MFMA operands with LDS transpose reads (the
+// contraction index m runs along the ROWS of both tiles), and writes an fp32 partial; a second streaming
+// kernel folds the partials into dW/db.  With one M-slice (M <= 1024: the text / fusion layers) the tile is
+// accumulated straight into dW/db and there is no second kernel.  HBM-bound: algorithmic bytes = M (N + K) * 2.
 #include "common.hpp"
 #include "../../include/clover_hip.h"
 
 namespace {
 
 constexpr int WG_THREADS = 256;
-constexpr int TN = 128, TK = 128, TM = 64, LD = 128 + 8;
+constexpr int TN = 128, TK = 128, TM = 64;
+constexpr int LD = 128 + 16;   // row stride 72 dwords = 8 banks: the 4 rows x 32 B of a transpose read tile the banks
 constexpr int CHUNKS = TM * (128 / 8) / WG_THREADS;       // 16-B chunks per thread per tile (= 4)
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -66,15 +67,16 @@ __device__ __forceinline__ void store_tile_std(bf16_t* dst, const uint4 (&v)[CHU
 
 // Register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is
 // consumed from LDS (T14 "issue early / write late"); one LDS buffer, two barriers per 64 rows.
-__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            float* __restrict__ partial, int64_t M, int N, int K,
-                                                           int ldy, int ldx, int tilesK, int64_t rows_per_split,
-                                                           int want_bias, const float* __restrict__ xmean,
+                                                           int ldy, int ldx, int tiles, int tilesK,
+                                                           int64_t rows_per_split, int want_bias,
+                                                           const float* __restrict__ xmean,
                                                            const float* __restrict__ xrstd) {
     __shared__ __attribute__((aligned(16))) bf16_t dYs[TM * LD];
     __shared__ __attribute__((aligned(16))) bf16_t Xs[TM * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
     const int tn = tile / tilesK, tk = tile - tn * tilesK;
     const int n0 = tn * TN, k0 = tk * TK;
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;            // this wave's 64 x 64 sub-tile
@@ -143,6 +145,153 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const bf16_t* __restr
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default): the 32-row stages of dY and X go global -> LDS directly
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a two-slot ring, so no staging VGPRs and
+// no ds_write pass: ~110 VGPRs -> 4 workgroups per CU, each with one stage in flight while it feeds
+// the MFMAs from the other.  The DMA writes LDS linearly (wave base + lane x 16 B), rows are 256 B
+// (all rows on the same banks), so the 16-B chunk a lane fetches is XOR-swizzled on the SOURCE side
+// and the transpose reads apply the same involution: 32-B pair p of row r lives at pair p ^ (r & 7).
+constexpr int SM = 32;                                    // rows per stage
+constexpr int STAGE = SM * 128;                           // bf16 elements per tensor per stage (8 KiB)
+constexpr int RING = 4;                                   // ring slots (16 KiB each); RING-1 stages in flight
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of out-of-range chunks
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_byte .. +1 KiB), asynchronously.
+// Issued from asm so that hipcc does not count it: the loop below keeps RING-1 stages in flight across its
+// barriers with counted s_waitcnt vmcnt(N); the compiler's own bookkeeping would drain to vmcnt(0) at each one.
+__device__ __forceinline__ void dma16(const bf16_t* src, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_byte)
+                 : "memory");
+}
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+__device__ __forceinline__ uint2 tr4s(const bf16_t* base, int row, int c0, int lr) {
+    // rows row..row+3 (lane lr>>2), columns c0 + (lr&3)*4 .. +4 of the swizzled [SM][128] stage
+    const int r = row + (lr >> 2);
+    const bf16_t* p = base + r * 128 + ((((c0 >> 4) ^ (r & 7)) << 4) | ((lr & 3) << 2));
+    const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+    union { v4s_t v; uint2 u; } cv;
+    cv.v = v;
+    return cv.u;
+}
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma_kernel(const bf16_t* __restrict__ dy,
+                                                                  const bf16_t* __restrict__ x,
+                                                                  float* __restrict__ out, float* __restrict__ out_b,
+                                                                  int64_t M, int N, int K, int ldy, int ldx, int tiles,
+                                                                  int tilesK, int64_t rows_per_split, int want_bias) {
+    __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+    const int tn = tile / tilesK, tk = tile - tn * tilesK;
+    const int n0 = tn * TN, k0 = tk * TK;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int64_t m_begin = (int64_t)split * rows_per_split;
+    int64_t m_end = m_begin + rows_per_split;
+    if (m_end > M) m_end = M;
+    const bool do_bias = want_bias && tk == 0 && wk == 0;
+
+    // this lane's two chunks per tensor per stage: LDS position p = j*256 + tid -> row p>>4, physical chunk p&15
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+    int rowj[2];
+    const bf16_t *sy[2], *sx[2];
+    bool vy[2], vx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 256 + tid;
+        const int r = p >> 4, c = ((p & 15) ^ ((r & 7) << 1)) * 8;
+        rowj[j] = r;
+        vy[j] = n0 + c < N;
+        vx[j] = k0 + c < K;
+        sy[j] = dy + (m_begin + r) * ldy + n0 + c;
+        sx[j] = x + (m_begin + r) * ldx + k0 + c;
+    }
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)&ring[0][0][0] + (unsigned)wave * 1024u);
+    // every stage is issued as exactly 4 pieces per wave, also past m_end (all-zero source), so that the
+    // counted waits below stay uniform
+    auto issue = [&](int slot, int64_t m0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool in = m0 + rowj[j] < m_end;
+            dma16((in && vy[j]) ? sy[j] : zero, ring_base + (unsigned)((slot * 2 + 0) * STAGE * 2 + j * 4096));
+            dma16((in && vx[j]) ? sx[j] : zero, ring_base + (unsigned)((slot * 2 + 1) * STAGE * 2 + j * 4096));
+            sy[j] += (int64_t)SM * ldy;
+            sx[j] += (int64_t)SM * ldx;
+        }
+    };
+
+    f32x4_t acc[4][4];
+    f32x4_t bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    Frag8 ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d) issue(d, m_begin + d * SM);
+    int slot = 0;
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += SM) {
+        wait_vm<(RING - 2) * 4>();       // this wave's pieces of stage m0 have landed (RING-2 later stages may fly on)
+        __builtin_amdgcn_s_barrier();    // ... and every other wave's; everyone is also done reading the previous slot
+        issue(slot == 0 ? RING - 1 : slot - 1, m0 + (int64_t)(RING - 1) * SM);
+        const bf16_t* Ys = ring[slot][0];
+        const bf16_t* Xs = ring[slot][1];
+        slot = slot == RING - 1 ? 0 : slot + 1;
+        Frag8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i].u2[0] = tr4s(Ys, lg * 4, wn + i * 16, lr);
+            a[i].u2[1] = tr4s(Ys, 16 + lg * 4, wn + i * 16, lr);
+            b[i].u2[0] = tr4s(Xs, lg * 4, wk + i * 16, lr);
+            b[i].u2[1] = tr4s(Xs, 16 + lg * 4, wk + i * 16, lr);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            if (do_bias) bacc[i] = mfma16(a[i], ones, bacc[i]);
+        }
+    }
+    wait_vm<0>();                        // drain the all-zero tail stages before the LDS is released
+    // ACCUM: out = dW (+=), out_b = db (+=).  Otherwise out = this split's partial [N*K dW | N db].
+    float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
+    float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn + i * 16 + lg * 4 + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + j * 16 + lr;
+                if (k < K) {
+                    // ACCUM: this workgroup is the only writer of the element; the no-return L2 atomic is
+                    // fire-and-forget, where "+=" would be 64 dependent load -> add -> store round trips
+                    if (ACCUM) atomicAdd(&pw[(int64_t)n * K + k], acc[i][j][r]);
+                    else pw[(int64_t)n * K + k] = acc[i][j][r];
+                }
+            }
+            if (do_bias && lr == 0) {
+                if (ACCUM) atomicAdd(&pb[n], bacc[i][r]);
+                else pb[n] = bacc[i][r];
+            }
+        }
+}
+
 // dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N).  Block = 64 consecutive e x
 // 16 split-lanes (1024 threads): coalesced 256-B reads, 16-way parallel splits loop, LDS tree at the end.
 __global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
@@ -196,11 +345,11 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 }
 
 int pick_splits(int64_t M, int tiles) {
-    int64_t s = (768 + tiles - 1) / tiles;             // ~3 workgroups per CU
+    if (M <= 1024) return 1;                            // few rows: one slice, accumulate directly (no partials)
+    int64_t s = (256 + tiles - 1) / tiles;              // ~1 workgroup per CU, 3 stages each in flight
     const int64_t max_by_rows = (M + 255) / 256;        // >= 256 rows per slice
     if (s > max_by_rows) s = max_by_rows;
     if (s < 1) s = 1;
-    if (s > 1024) s = 1024;
     return (int)s;
 }
 
@@ -214,7 +363,8 @@ extern "C" int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K)
 
 extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
                                 int32_t N, int32_t K, int32_t ldy, int32_t ldx, const float* xmean,
-                                const float* xrstd, void* stream) {
+                                const float* xrstd, int32_t stages, void* stream) {
+    if (stages == 0) stages = 3;
     if ((xmean == nullptr) != (xrstd == nullptr)) return CLV_ERR_ARG;
     if (!dy || !x || !dw || !work || M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (ldy & 7) || (ldx & 7))
         return CLV_ERR_ARG;
@@ -224,15 +374,32 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     const int splits = pick_splits(M, tiles);
     int64_t rows = (M + splits - 1) / splits;
     rows = (rows + TM - 1) / TM * TM;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(WG_THREADS), 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)x, work, M, (int)N, (int)K, (int)ldy, (int)ldx, tilesK, rows, db ? 1 : 0, xmean, xrstd);
-    int rc = clv_check_launch();
-    if (rc) return rc;
-    const int64_t NK = (int64_t)N * K, E2 = NK + N;
-    const int64_t Eeff = db ? E2 : NK;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK, E2,
-                       splits);
-    return clv_check_launch();
+    const bf16_t* dyp = (const bf16_t*)dy;
+    const bf16_t* xp = (const bf16_t*)x;
+    int rc = CLV_OK;
+    if (stages & 1) {
+        const int total = tiles * splits;
+        if (xmean) {                       // standardise-on-load needs the register-staged kernel
+            hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, M, (int)N, (int)K,
+                               (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0, xmean, xrstd);
+        } else if (splits == 1) {          // one M-slice: accumulate straight into dW / db, no partials, no fold
+            hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M, (int)N,
+                               (int)K, (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr, M,
+                               (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0);
+        }
+        rc = clv_check_launch();
+        if (rc) return rc;
+    }
+    if ((stages & 2) && (splits > 1 || xmean)) {
+        const int64_t NK = (int64_t)N * K, E2 = NK + N;
+        const int64_t Eeff = db ? E2 : NK;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK,
+                           E2, splits);
+        rc = clv_check_launch();
+    }
+    return rc;
 }
 
 extern "C" int clv_colsum(const void* dy, float* db, int64_t M, int32_t N, int32_t ld, void* stream) {

@@ -53,12 +53,19 @@ class _Timed:
     def __exit__(self, *a):
         if PROF is not None:
             self.e.record()
-            rec = PROF.setdefault(self.key, dict(events=[], flops=self.flops, bytes=self.nbytes))
-            rec['events'].append((self.s, self.e))
+            PROF.setdefault(self.key, []).append((self.s, self.e, self.flops, self.nbytes))
+
+
+def _kname(kernel, g):
+    """Device-kernel name as rocprofv3 prints it: template <HD, NKT, DROP, MODE> (attention.hip CLV_PICK)."""
+    need = (g.N + 15) // 16
+    nkt = next(o for o in (2, 8, 14, 16, 28) if o >= need)
+    drop = 'true' if (g.dropout_p > 0 and g.mode == 0) else 'false'
+    return f'{kernel}<{g.hd}, {nkt}, {drop}, {g.mode}>'
 
 
 def _attn_work(g, backward):
-    """Algorithmic work of one attention launch: 2 flops/MAC over the
+    """Algorithmic work of one attention call: 2 flops/MAC over the
     N x N x hd products (2 matmuls forward, 5 backward); bytes = q,k,v read + o written
     (forward) or q,k,v,o,do read + dq,dk,dv written (backward), bf16."""
     per = g.groups * g.nH * g.N * g.N * g.hd
@@ -69,26 +76,30 @@ def _attn_work(g, backward):
 
 
 def roofline_from_prof(prof, steps):
-    """-> (roofline dict of the dominant instrumented kernel, per-kernel table)."""
+    """-> (roofline dict of the dominant instrumented KERNEL, per-kernel table).  Keys are device
+    kernel names (as rocprofv3 --stats prints them); a kernel launched with many shapes is aggregated:
+    achieved = sum(algorithmic work) / sum(duration), avg_us = mean launch duration."""
     rows = []
-    for key, rec in prof.items():
-        ms = [s.elapsed_time(e) for s, e in rec['events']]
+    for key, evs in prof.items():
+        ms = [s.elapsed_time(e) for s, e, _, _ in evs]
         rows.append(dict(kernel=key, launches_per_step=len(ms) / steps, avg_us=1e3 * sum(ms) / len(ms),
-                         total_ms_per_step=sum(ms) / steps, flops=rec['flops'], bytes=rec['bytes']))
+                         total_ms_per_step=sum(ms) / steps, secs=sum(ms) * 1e-3,
+                         flops=sum(f for _, _, f, _ in evs), bytes=sum(b for _, _, _, b in evs)))
     rows.sort(key=lambda r: -r['total_ms_per_step'])
     top = rows[0]
-    t = top['avg_us'] * 1e-6
+    n = len(prof[top['kernel']])
     t_hbm, t_mfma = top['bytes'] / 8.0e12, top['flops'] / 2.5e15
     if t_hbm >= t_mfma:
-        roof = dict(bound='hbm', achieved=round(top['bytes'] / t / 1e9, 1), peak=8000.0, unit='GB/s',
-                    frac=round(top['bytes'] / t / 8.0e12, 4), traffic=None)
+        roof = dict(bound='hbm', achieved=round(top['bytes'] / top['secs'] / 1e9, 1), peak=8000.0, unit='GB/s',
+                    frac=round(top['bytes'] / top['secs'] / 8.0e12, 4), traffic=None)
     else:
-        roof = dict(bound='mfma', achieved=round(top['flops'] / t / 1e12, 2), peak=2500.0, unit='TFLOP/s',
-                    frac=round(top['flops'] / t / 2.5e15, 4), traffic=None)
+        roof = dict(bound='mfma', achieved=round(top['flops'] / top['secs'] / 1e12, 2), peak=2500.0, unit='TFLOP/s',
+                    frac=round(top['flops'] / top['secs'] / 2.5e15, 4), traffic=None)
     roof['kernel'] = top['kernel']
     roof['avg_us'] = round(top['avg_us'], 2)
-    roof['algorithmic_bytes'] = top['bytes']
-    roof['algorithmic_flops'] = top['flops']
+    roof['launches_per_step'] = round(top['launches_per_step'], 2)
+    roof['algorithmic_bytes_per_launch'] = int(top['bytes'] / n)
+    roof['algorithmic_flops_per_launch'] = int(top['flops'] / n)
     table = [dict(kernel=r['kernel'], launches_per_step=round(r['launches_per_step'], 2),
                   avg_us=round(r['avg_us'], 2), ms_per_step=round(r['total_ms_per_step'], 3)) for r in rows[:12]]
     return roof, table
@@ -96,8 +107,10 @@ def roofline_from_prof(prof, steps):
 
 # --------------------------------------------------------------------------- Linear
 def _wgrad_custom(M, N, K):
-    """Token-parallel shapes (huge M, small N x K): the library GEMM under-fills the chip."""
-    return M >= 2048 and N * K <= (1 << 20) and N % 8 == 0 and K % 8 == 0
+    """Shapes the split-M kernel takes: token-parallel ones (huge M, small N x K — the library GEMM
+    under-fills the chip) and few-row ones (M <= 1024: one M-slice accumulated straight into the fp32
+    gradient, replacing library GEMM + fp32 add + column sum)."""
+    return (M >= 2048 and N * K <= (1 << 20) or M <= 1024) and N % 8 == 0 and K % 8 == 0
 
 
 def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
@@ -116,9 +129,15 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         dw = dw_out if sink else torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
         db = (db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)) if want_bias else None
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
-        check(L.clv_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0),
-                                 x2.stride(0), _ptr(xstats[0] if xstats else None),
-                                 _ptr(xstats[1] if xstats else None), _stream()), 'clv_linear_wgrad')
+        args = (_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0), x2.stride(0),
+                _ptr(xstats[0] if xstats else None), _ptr(xstats[1] if xstats else None))
+        if PROF is None:
+            check(L.clv_linear_wgrad(*args, 0, _stream()), 'clv_linear_wgrad')
+        else:                                  # one event pair per device kernel
+            kname = 'wgrad_kernel' if xstats else ('wgrad_dma_kernel<true>' if M <= 1024 else 'wgrad_dma_kernel<false>')
+            with _Timed(kname, 2 * M * N * K, M * (N + K) * 2):
+                check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
+            check(L.clv_linear_wgrad(*args, 2, _stream()), 'clv_linear_wgrad')
         return (None, None) if sink else (dw, db)
     dwb = torch.mm(dy2.t(), x2)
     db = None
@@ -524,7 +543,7 @@ class _Attention(torch.autograd.Function):
         o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=BF16)
         lse = torch.empty(g.groups * g.nH * g.N, device=qkv.device, dtype=torch.float32)
         base = qkv.data_ptr()
-        with _Timed(f'attn_fwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, False)):
+        with _Timed(_kname('attn_fwd_kernel', g), *_attn_work(g, False)):
             check(_lib.lib().clv_attn_fwd(C.c_void_p(base), C.c_void_p(base + 2 * Cdim),
                                           C.c_void_p(base + 4 * Cdim), _ptr(o), _ptr(lse), _ptr(bias), _ptr(rid),
                                           _ptr(kmask), _ptr(seed), C.byref(g), _stream()), 'clv_attn_fwd')
@@ -549,13 +568,19 @@ class _Attention(torch.autograd.Function):
             biasT = torch.zeros_like(bias)                 # [nH][key][query], same row stride
             biasT[:, :, :g.N] = bias[:, :, :g.N].transpose(1, 2)
         b, d = qkv.data_ptr(), dqkv.data_ptr()
-        with _Timed(f'attn_bwd[mode{g.mode},N{g.N},hd{g.hd},nH{g.nH},groups{g.groups}]', *_attn_work(g, True)):
-            check(_lib.lib().clv_attn_bwd(C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim),
-                                          _ptr(o), _ptr(doc), _ptr(lse), _ptr(bias), _ptr(biasT), _ptr(rid),
-                                          _ptr(kmask),
-                                          C.c_void_p(d), C.c_void_p(d + 2 * Cdim), C.c_void_p(d + 4 * Cdim),
-                                          _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), _ptr(seed), C.byref(g),
-                                          _stream()), 'clv_attn_bwd')
+        args = (C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim), _ptr(o), _ptr(doc), _ptr(lse),
+                _ptr(bias), _ptr(biasT), _ptr(rid), _ptr(kmask), C.c_void_p(d), C.c_void_p(d + 2 * Cdim),
+                C.c_void_p(d + 4 * Cdim), _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), _ptr(seed))
+        L = _lib.lib()
+        if PROF is None:
+            check(L.clv_attn_bwd(*args, 0, C.byref(g), _stream()), 'clv_attn_bwd')
+        else:                                  # one event pair per device kernel (work split 2:3 of the 5 matmuls)
+            fl, by = _attn_work(g, True)
+            with _Timed(_kname('attn_bwd_dq_kernel', g), fl * 0.4, by * 0.5):
+                check(L.clv_attn_bwd(*args, 1, C.byref(g), _stream()), 'clv_attn_bwd')
+            check(L.clv_attn_bwd(*args, 2, C.byref(g), _stream()), 'clv_attn_bwd')
+            with _Timed(_kname('attn_bwd_dkv_kernel', g), fl * 0.6, by * 0.5):
+                check(L.clv_attn_bwd(*args, 4, C.byref(g), _stream()), 'clv_attn_bwd')
         return dqkv, dbias, None, None, None, None
 
 

@@ -75,7 +75,9 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const float* lse, const float* bias, const float* biasT, const int32_t* rid,
                  const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
-                 const void* seed, const ClvAttnGeom* geom_host, void* stream);
+                 const void* seed, int32_t stages, const ClvAttnGeom* geom_host, void* stream);
+/* stages: 0 = everything; otherwise a bit mask 1 = dQ (+dS scratch, dsum) kernel, 2 = dbias reduction,
+ * 4 = dK/dV kernel — lets a profiler bracket each kernel of the call with its own events. */
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm over the last dim (every norm site: swin_transformer_3d.py:450,483,
@@ -133,7 +135,8 @@ int clv_im2col_patches(const float* x, void* patches, int32_t B, int32_t T, int3
 int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
                      int32_t N, int32_t K, int32_t ldy, int32_t ldx, const float* xmean,
-                     const float* xrstd, void* stream);
+                     const float* xrstd, int32_t stages, void* stream);
+/* stages: 0 = both kernels; bit 1 = split-M partial kernel, bit 2 = fold of the partials (profiling). */
 
 /* ------------------------------------------------------------------ token-parallel projections
  * Y[M][N] = epilogue( prologue(X)[M][K] * Wt[N][K]^T + bias ) — the QKV / proj / fc1 / fc2 Linears of

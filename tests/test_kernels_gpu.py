@@ -266,7 +266,8 @@ def test_adamw_and_clip():
 
 
 # ----------------------------------------------------------------------------- linear weight grad
-@pytest.mark.parametrize('M,N,K', [(50176, 288, 96), (12544, 96, 384), (4096, 1152, 384), (3000, 96, 96), (777, 3072, 768)])
+@pytest.mark.parametrize('M,N,K', [(50176, 288, 96), (12544, 96, 384), (4096, 1152, 384), (3000, 96, 96), (777, 3072, 768),
+                                   (256, 768, 3072), (1000, 200, 104), (33, 8, 8), (1500, 768, 768)])
 def test_linear_and_wgrad(M, N, K):
     x = rnd(M, K, seed=71).to(BF)
     w = rnd(N, K, scale=0.05, seed=72)
@@ -282,6 +283,25 @@ def test_linear_and_wgrad(M, N, K):
     assert rel(xg.grad, xr.grad) < 1e-2
     assert rel(wg.grad, wr.grad) < 5e-3, rel(wg.grad, wr.grad)
     assert rel(bg.grad, br.grad) < 5e-3, rel(bg.grad, br.grad)
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 768, 768), (1024, 136, 264), (2100, 384, 96), (50176, 192, 384), (5000, 96, 96)])
+@pytest.mark.parametrize('bias', [True, False])
+def test_wgrad_accumulates_into_sink(M, N, K, bias):
+    """clv_linear_wgrad with gradient sinks: dW / db are ADDED to what the fp32 slab views already hold —
+    one M-slice (direct accumulation, M <= 1024) and split-M (partials + fold) alike; ragged tiles."""
+    x, dy = rnd(M, K, seed=75).to(BF).to(DEV), rnd(M, N, seed=76).to(BF).to(DEV)
+    dw0, db0 = rnd(N, K, seed=77).to(DEV), rnd(N, seed=78).to(DEV)
+    dw, db = dw0.clone(), db0.clone()
+    assert ops()._wgrad_custom(M, N, K)
+    out = ops().linear_wgrad(dy, x, bias, dw, db if bias else None)
+    assert out == (None, None)
+    ref_w = dw0.double() + dy.double().t() @ x.double()
+    assert rel(dw, ref_w.cpu()) < 1e-5, rel(dw, ref_w.cpu())
+    if bias:
+        assert rel(db, (db0.double() + dy.double().sum(0)).cpu()) < 1e-5
+    else:
+        assert torch.equal(db, db0)
 
 
 def test_layernorm_fused_residual_stream():

@@ -21,6 +21,14 @@ LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_
 LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=3e-2, rank_t_tm_loss=3e-2, v_nce_loss=3e-2, rank_v_vm_loss=3e-2, loss=6e-2)
 
 
+def grad_tol(name):
+    """max|err| / max|ref| bound for a parameter gradient.  Parameters whose ONLY gradient source is a
+    contrastive loss (the projector / masked-feature heads feeding cosine logits divided by the
+    temperature 0.05) inherit that x20 amplification of the bf16 backbone rounding: 1e-1.  Everything
+    else (backbones, fusion, MLM head; observed <= 2e-2): 3e-2."""
+    return 1e-1 if name.startswith(('ssl_head.', 'mlm_ssl_V_head.', 'mlm_ssl_T_head.')) else 3e-2
+
+
 def rel(a, b):
     a = a.detach().float().cpu().numpy().astype(np.float64).reshape(-1)
     b = np.asarray(b, dtype=np.float64).reshape(-1)
@@ -120,6 +128,6 @@ def test_step_losses_and_grads(model, B):
         worst[k] = rel_packed(g, f'B{B}.grad.{k}', named[k].grad)
     print('grad rel errors', B, worst)
     for k, e in worst.items():
-        assert e < 6e-2, (k, e)
+        assert e < grad_tol(k), (k, e)
     unused = sorted(k for k, p in named.items() if p.grad is None)
     assert unused == gutil.unused_params()
