@@ -103,9 +103,19 @@ class BertSelfAttention(nn.Module):
         self.value = Linear(H, H)
         self.attn_dropout_p = cfg['attention_probs_dropout_prob']
 
+    def clv_fuse_groups(self):
+        """Parameters applied as ONE GEMM: the engine lays them out adjacently and hands back fused
+        views (``_clv_fused``), so the Q|K|V projection needs no per-step cat / cast / gradient split."""
+        return [[self.query.weight, self.key.weight, self.value.weight],
+                [self.query.bias, self.key.bias, self.value.bias]]
+
     def forward(self, x, kmask):
-        w = torch.cat([self.query.weight, self.key.weight, self.value.weight], dim=0)
-        b = torch.cat([self.query.bias, self.key.bias, self.value.bias], dim=0)
+        fused = getattr(self, '_clv_fused', None)
+        if fused is not None:
+            w, b = fused
+        else:
+            w = torch.cat([self.query.weight, self.key.weight, self.value.weight], dim=0)
+            b = torch.cat([self.query.bias, self.key.bias, self.value.bias], dim=0)
         qkv = ops.linear(x, w, b)
         return ops.seq_attention(qkv.contiguous(), kmask, self.num_attention_heads,
                                  self.attn_dropout_p if self.training else 0.0)

@@ -88,6 +88,22 @@ class _Segment:
             p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
         self.shadow.copy_(self.flat_p)
 
+    def fused_view(self, members):
+        """One Parameter-like view over `members` (adjacent slots of this slab, equal trailing dims,
+        concatenated along dim 0): fp32 data, bf16 shadow and gradient sink are slices of the slabs, so a
+        module that applies the members as ONE GEMM (BERT Q|K|V) needs no cat / cast / gradient split."""
+        idx = [next(i for i, q in enumerate(self.params) if q is m) for m in members]
+        assert idx == list(range(idx[0], idx[0] + len(idx))), 'fusion group is not adjacent in the slab'
+        assert all(m.numel() % 4 == 0 and m.shape[1:] == members[0].shape[1:] for m in members)
+        off, n = self.offsets[idx[0]], sum(m.numel() for m in members)
+        shape = (sum(m.shape[0] for m in members),) + tuple(members[0].shape[1:])
+        f = torch.nn.Parameter(self.flat_p[off:off + n].view(shape))
+        f._clv_grad = self.flat_g[off:off + n].view(shape)
+        f._clv_shadow = self.shadow[off:off + n].view(shape)
+        f._clv_members = list(members)
+        f._clv_ready = lambda ms=f._clv_members: [m._clv_ready() for m in ms] and None
+        return f
+
 
 class CloverEngine:
     def __init__(self, model, sample_batch, lr=5e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.005,
@@ -114,11 +130,29 @@ class CloverEngine:
         out = model.train_step(sample_batch, None)
         out['loss'].backward()
         used = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+        name_of = {id(p): n for n, p in model.named_parameters()}
         self.unused_names = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
         model.zero_grad(set_to_none=True)
 
         # reverse registration order ~ order in which backward produces the gradients
         used = list(reversed(used))
+        # modules that apply several parameters as one GEMM ask for adjacent slab slots (clv_fuse_groups())
+        groups = []
+        used_ids = {id(p) for _, p in used}
+        for mod in model.modules():
+            for grp in (mod.clv_fuse_groups() if hasattr(mod, 'clv_fuse_groups') else []):
+                if all(id(q) in used_ids for q in grp) and len({wd_map[name_of[id(q)]] > 0 for q in grp}) == 1:
+                    groups.append((mod, grp))
+        member = {id(q): gi for gi, (_, grp) in enumerate(groups) for q in grp}
+        ordered, placed = [], set()
+        for n, p_ in used:
+            gi = member.get(id(p_))
+            if gi is None:
+                ordered.append((n, p_))
+            elif gi not in placed:
+                placed.add(gi)
+                ordered.extend((name_of[id(q)], q) for q in groups[gi][1])
+        used = ordered
         decay = [(n, p) for n, p in used if wd_map[n] > 0]
         no_decay = [(n, p) for n, p in used if wd_map[n] == 0]
         self.segments = [s for s in (_Segment(decay, weight_decay, device) if decay else None,
@@ -129,6 +163,12 @@ class CloverEngine:
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
         self.reducer = BucketedGradReducer([(seg.flat_g, seg.params, seg.offsets) for seg in self.segments],
                                            bucket_bytes=bucket_mb << 20)
+        per_mod = {}
+        for mod, grp in groups:
+            seg = next(sg for sg in self.segments if any(q is grp[0] for q in sg.params))
+            per_mod.setdefault(id(mod), (mod, []))[1].append(seg.fused_view(grp))
+        for mod, views in per_mod.values():
+            mod._clv_fused = views                       # same order as clv_fuse_groups()
 
     # ------------------------------------------------------------------ one step
     def current_lr(self):

@@ -50,6 +50,30 @@ def test_engine_matches_torch_adamw_and_clip():
     assert worst < 0.1, worst
 
 
+def test_engine_gradient_slab_equals_plain_autograd():
+    """The engine's plumbing — gradient sinks into the flat fp32 slab, bf16 shadow weights, fused Q|K|V slab
+    views (clv_fuse_groups) — must leave exactly the gradients plain autograd computes on an identical model."""
+    from clover_amd.engine import CloverEngine
+    from clover_amd.backbones.bert_layers import BertSelfAttention
+    b = batch(tag='slab')
+    m1, m2 = make_model(), make_model()
+    eng = CloverEngine(m1, b, lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+    fused = [m for m in m1.modules() if isinstance(m, BertSelfAttention) and getattr(m, '_clv_fused', None)]
+    assert fused, 'no BERT self-attention got fused Q|K|V views'
+    w, bb = fused[0]._clv_fused
+    assert w.shape[0] == 3 * fused[0].query.weight.shape[0] and w.data_ptr() == fused[0].query.weight.data_ptr()
+    assert bb._clv_grad.data_ptr() == fused[0].query.bias.grad.data_ptr()
+    m1.train_step(b, None)['loss'].backward()
+    m2.train_step(b, None)['loss'].backward()
+    p1 = dict(m1.named_parameters())
+    for n, p in m2.named_parameters():
+        if n in eng.unused_names:
+            continue
+        ref = p.grad.detach().float()
+        err = (p1[n].grad.float() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        assert err < 2e-2, (n, err)
+
+
 def test_graph_capture_equals_eager_and_loss_decreases():
     from clover_amd.engine import CloverEngine
     b = batch(4, 'eng4')
