@@ -178,6 +178,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of as one hipGraph')
+    ap.add_argument('--no-gemm-tuning', action='store_true', help='library GEMMs with default heuristics')
+    ap.add_argument('--tune-gemms', metavar='CSV', help='benchmark library GEMM algorithms and write the table')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -206,6 +208,11 @@ def main():
     import clover_amd
     from clover_amd import ops
     from clover_amd.engine import CloverEngine
+
+    tuned = 0
+    if not args.no_gemm_tuning:
+        from clover_amd.utils.gemm_tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms(tune_missing=bool(args.tune_gemms), out_path=args.tune_gemms)
 
     torch.manual_seed(1234)                              # identical init on every rank (== DDP broadcast)
     cfg = model_cfg(args.variant, args.frames)
@@ -270,7 +277,7 @@ def main():
             'metric': 'video-text pairs/sec (8f x 224^2, 32-tok), full pre-training step',
             'value': round(pairs_s, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'hip_graph': graphed,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'hip_graph': graphed, 'tuned_gemm_shapes': tuned,
             'config': {'workload': f'VideoSwin-{args.variant} + BERT-base + 3-layer fusion, MLM + tri-modal '
                                    f'exclusive InfoNCE + rank losses, {args.frames}f x 224^2, {args.tokens}-tok',
                        'per_gpu_batch': args.batch, 'global_batch': gb, 'parallelism': f'dp{world}',

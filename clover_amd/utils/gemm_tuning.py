@@ -1,0 +1,35 @@
+"""Library-GEMM algorithm selection (PyTorch TunableOp over hipBLASLt / rocBLAS).
+
+The plain GEMMs of the step (Swin stages 1-3 forward/dgrad, BERT, fusion, MLM decoder) go through the
+ROCm libraries; their default heuristics are tuned for large square problems and pick poor kernels
+for several of this workload's tall-skinny shapes.  ``clover_amd/tuning/*.csv`` holds the per-shape
+winners measured once on an MI355X (``bench.py --tune-gemms`` regenerates the file); loading it costs
+nothing at run time and shapes that are not listed keep the library default.  torch validates the file
+header (torch / hipBLASLt / rocBLAS versions, gfx arch) and ignores a file that does not match."""
+import os
+import tempfile
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_FILE = os.path.join(_HERE, 'tuning', 'gemm_gfx950_bench_b8.csv')
+
+
+def enable_tuned_gemms(path=None, tune_missing=False, out_path=None):
+    """Turn TunableOp on with the committed selections.  tune_missing=True additionally benchmarks every
+    GEMM shape met for the first time (tens of seconds on the first step) and writes the merged table to
+    `out_path` at exit.  Returns the number of selections loaded."""
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.tuning_enable(bool(tune_missing))
+    if tune_missing:
+        t.set_max_tuning_duration(150)
+        t.set_max_tuning_iterations(200)
+        t.set_rotating_buffer_size(512)
+        if out_path:
+            t.set_filename(out_path)
+    else:                                   # torch rewrites its table at exit: keep that out of the cwd
+        t.set_filename(os.path.join(tempfile.gettempdir(), 'clover_tunableop.csv'))
+    path = path or DEFAULT_FILE
+    ok = os.path.exists(path) and t.read_file(path)
+    return len(t.get_results()) if ok else 0
