@@ -24,14 +24,21 @@ class ClvAttnGeom(C.Structure):
 
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
+
+class ClvLnExtra(C.Structure):
+    """Mirror of ``struct ClvLnExtra`` (include/clover_hip.h)."""
+    _fields_ = [('xscale', _p), ('rows_per_sample', _i32), ('drop_p', _f), ('seed', _p), ('dy2', _p), ('dres', _p),
+                ('x_is_sum', _i32)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 17 + [_i32, C.POINTER(ClvAttnGeom), _p]),
-    'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, _p]),
+    'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
-    'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _p]),
+    'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
     'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),

@@ -129,8 +129,12 @@ class BertSelfOutput(nn.Module):
         self.LayerNorm = LayerNorm(H, eps=cfg['layer_norm_eps'])
         self.dropout = nn.Dropout(cfg['hidden_dropout_prob'])
 
-    def forward(self, hidden, residual):
-        return self.LayerNorm(self.dropout(self.dense(hidden)), residual=residual)
+    def forward(self, hidden, residual, fork=False):
+        """LayerNorm(dropout(dense(h)) + residual): the dropout runs inside the LayerNorm kernel.  fork=True
+        returns the output twice (one storage): one edge for the next sub-layer's GEMM, one for its residual
+        input, and the two gradients meet inside the LayerNorm backward kernel instead of an autograd add."""
+        return self.LayerNorm(self.dense(hidden), residual=residual,
+                              x_dropout_p=self.dropout.p if self.training else 0.0, fork=fork)
 
 
 class BertAttention(nn.Module):
@@ -139,8 +143,8 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(cfg)
         self.output = BertSelfOutput(cfg)
 
-    def forward(self, x, kmask):
-        return self.output(self.self(x, kmask), x)
+    def forward(self, x, kmask, x_res=None, fork=False):
+        return self.output(self.self(x, kmask), x if x_res is None else x_res, fork=fork)
 
 
 class BertIntermediate(nn.Module):
@@ -159,9 +163,10 @@ class BertLayer(nn.Module):
         self.intermediate = BertIntermediate(cfg)
         self.output = BertSelfOutput(cfg, in_features=cfg['intermediate_size'])
 
-    def forward(self, x, kmask):
-        a = self.attention(x, kmask)
-        return self.output(self.intermediate(a), a)
+    def forward(self, x, kmask, x_res=None, fork_out=False):
+        """x_res: the alias of x a forked producer handed out for the residual input (see BertSelfOutput)."""
+        a, a_res = self.attention(x, kmask, x_res, fork=True)
+        return self.output(self.intermediate(a), a_res, fork=fork_out)
 
 
 class BertEncoder(nn.Module):
@@ -170,8 +175,12 @@ class BertEncoder(nn.Module):
         self.layer = nn.ModuleList([BertLayer(cfg) for _ in range(cfg['num_hidden_layers'])])
 
     def forward(self, x, kmask):
-        for layer in self.layer:
-            x = layer(x, kmask)
+        x_res, last = None, len(self.layer) - 1
+        for i, layer in enumerate(self.layer):
+            if i < last:
+                x, x_res = layer(x, kmask, x_res, fork_out=True)
+            else:
+                x = layer(x, kmask, x_res)
         return x
 
 

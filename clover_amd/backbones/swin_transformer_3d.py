@@ -213,19 +213,24 @@ class SwinTransformerBlock3D(nn.Module):
     def forward_part2(self, x):
         return self.drop_path(self.mlp(self.norm2(x)))
 
-    def forward_pending(self, x, branch=None):
-        """Residual stream with a PENDING addition: the block input is x (+ branch); returns
-        (stream, branch') with block output = stream + branch'.  Both residual adds of the reference
-        (:498, :503) are folded into the LayerNorm kernels that follow them (fwd: sum_out, bwd: dsum)."""
+    def _dp_scale(self, x):
+        return self.drop_path.scale(x) if isinstance(self.drop_path, DropPath) else None
+
+    def forward_pending(self, x, branch=None, bscale=None):
+        """Residual stream with a PENDING addition: the block input is x (+ bscale * branch); returns
+        (stream, branch', bscale') with block output = stream + bscale' * branch'.  Both residual adds of the
+        reference (:498, :503) AND the DropPath factors on the branches are folded into the LayerNorm kernels
+        that follow them (fwd: x_scale / sum_out, bwd: dsum)."""
         if self._fused_ok(x):
-            return self._forward_pending_fused(x, branch)
+            return self._forward_pending_fused(x, DropPath.apply_scale(branch, bscale) if branch is not None else None)
         if branch is None:
             y1, s0 = self.norm1(x), x
         else:
-            y1, s0 = self.norm1(branch, residual=x, return_sum=True)
-        a = self.drop_path(self.attn_part(y1))
-        y2, s1 = self.norm2(a, residual=s0, return_sum=True)
-        return s1, self.drop_path(self.mlp(y2))
+            y1, s0 = self.norm1(branch, residual=x, return_sum=True, x_scale=bscale)
+        a = self.attn_part(y1)
+        y2, s1 = self.norm2(a, residual=s0, return_sum=True, x_scale=self._dp_scale(a))
+        m = self.mlp(y2)
+        return s1, m, self._dp_scale(m)
 
     def _fused_ok(self, x):
         B, D, H, W, C = x.shape
@@ -253,13 +258,13 @@ class SwinTransformerBlock3D(nn.Module):
         a = self.drop_path(at.proj(o))
         m, s1 = ops.fused_mlp(a, s0, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
                               self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps)
-        return s1, self.drop_path(m)
+        return s1, self.drop_path(m), None
 
     def forward(self, x, mask_matrix=None):
         """x bf16 [B,D,H,W,C].  ``mask_matrix`` is accepted for signature compatibility and unused:
         the shift mask is evaluated from region ids inside the kernel."""
-        s, m = self.forward_pending(x)
-        return s + m
+        s, m, sc = self.forward_pending(x)
+        return s + DropPath.apply_scale(m, sc)
 
 
 class PatchMerging(nn.Module):
@@ -275,11 +280,11 @@ class PatchMerging(nn.Module):
         B, D, H, W, C = x.shape
         if (H % 2 == 1) or (W % 2 == 1):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x0 = x[:, :, 0::2, 0::2, :]
-        x1 = x[:, :, 1::2, 0::2, :]
-        x2 = x[:, :, 0::2, 1::2, :]
-        x3 = x[:, :, 1::2, 1::2, :]
-        return torch.cat([x0, x1, x2, x3], -1)
+        B, D, H, W, C = x.shape
+        # concat order [x(h even,w even), x(h odd,w even), x(h even,w odd), x(h odd,w odd)] = channel block
+        # 2 * (w parity) + (h parity): ONE strided copy forward and ONE backward instead of 4 slices + cat
+        v = x.view(B, D, H // 2, 2, W // 2, 2, C).permute(0, 1, 2, 4, 5, 3, 6)
+        return v.reshape(B, D, H // 2, W // 2, 4 * C)
 
     def forward(self, x):
         return self.reduction(self.norm(self.merge_gather(x)))
@@ -304,16 +309,16 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         """x bf16 channels-last [B,D,H,W,C] -> [B,D,H',W',C'] (the reference takes/returns B C D H W)."""
-        s, m = self.forward_pending(x)
-        x = s + m
+        s, m, sc = self.forward_pending(x)
+        x = s + DropPath.apply_scale(m, sc)
         if self.downsample is not None:
             x = self.downsample(x)
         return x
 
-    def forward_pending(self, x, branch=None):
+    def forward_pending(self, x, branch=None, bscale=None):
         for blk in self.blocks:
-            x, branch = blk.forward_pending(x, branch)
-        return x, branch
+            x, branch, bscale = blk.forward_pending(x, branch, bscale)
+        return x, branch, bscale
 
 
 class PatchEmbed3D(nn.Module):
@@ -450,12 +455,28 @@ class SwinTransformer3D(nn.Module):
             raise TypeError('pretrained must be a str or None')
 
     # ---- channels-last core -------------------------------------------------------------
+    def _draw_drop_paths(self, B, device):
+        """All DropPath factors of this pass from ONE RNG call: [n, B] = bernoulli(keep_i) / keep_i."""
+        if not self.training:
+            return
+        if getattr(self, '_dp_mods', None) is None:
+            self._dp_mods = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0]
+            self._dp_keep = None
+        if not self._dp_mods:
+            return
+        if self._dp_keep is None or self._dp_keep.device != device:
+            self._dp_keep = torch.tensor([1.0 - m.drop_prob for m in self._dp_mods], device=device)[:, None]
+        scales = (torch.rand(len(self._dp_mods), B, device=device) < self._dp_keep).float() / self._dp_keep
+        for i, m in enumerate(self._dp_mods):
+            m.preset(scales[i])
+
     def _stages(self, x):
+        self._draw_drop_paths(x.shape[0], x.device)
         x = self.pos_drop(x)
         for layer in self.layers[:-1]:
             x = layer(x)
-        s, m = self.layers[-1].forward_pending(x)        # last stage has no downsample:
-        return self.norm(m, residual=s)                  # its final residual add rides in the norm
+        s, m, sc = self.layers[-1].forward_pending(x)    # last stage has no downsample:
+        return self.norm(m, residual=s, x_scale=sc)      # its final residual add rides in the norm
 
     def forward_tokens(self, x, mask=None):
         """[B,3,T,H,W] -> channels-last features [B,T',h,w,Cf] (masked pass if `mask` given)."""

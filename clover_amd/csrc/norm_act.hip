@@ -109,7 +109,8 @@ template <int ITERS, typename T>
 __global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const T* __restrict__ dsum, T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
+    const T* __restrict__ dsum, T* __restrict__ dx, float* __restrict__ partial, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int64_t rows, int C) {
     __shared__ float red[ITERS * 128 * 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + wv;
@@ -182,6 +183,13 @@ __global__ void __launch_bounds__(LN_THREADS) ln_bwd_kernel(
         __syncthreads();
     }
     const int nblk = gridDim.x;
+    if (dgamma) {                                   // few blocks: add straight into dgamma/dbeta, no second kernel
+        for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+            atomicAdd(dgamma + c, red[c]);
+            atomicAdd(dbeta + c, red[ITERS * 128 + c]);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += LN_THREADS) {
         partial[(int64_t)blockIdx.x * C + c] = red[c];
         partial[((int64_t)nblk + blockIdx.x) * C + c] = red[ITERS * 128 + c];
@@ -243,6 +251,334 @@ int ln_fwd_blocks(int64_t rows) {
         default: return CLV_ERR_UNSUPPORTED;                                             \
     }
 
+// =====================================================================================================
+// Vector LayerNorm (C % 8 == 0, C <= 3072): 16-byte lane accesses; a row is owned by a GROUP of 16 / 32 / 64
+// lanes (so C = 96 packs 4 rows per wave, C = 192 two), ITERS chunks of 8 elements per lane.  The x operand
+// may carry the transforms that precede the norm in the model, applied on the fly instead of as separate
+// elementwise kernels:  t = keep(x) * x / (1 - p) * xscale[sample] + res   (nn.Dropout on the sub-layer
+// output, BertSelfOutput / BertOutput; per-sample DropPath scale, swin_transformer_3d.py:498,503).  The
+// dropout mask is a pure function of (seed, row, column), so the backward regenerates it.
+struct LnX {
+    const float* xscale;                 // [rows / rows_per_sample] or null
+    int rows_per_sample;
+    unsigned thresh;                     // P(drop) = thresh / 2^32, 0 = off
+    float inv_keep;
+    const unsigned long long* seed;
+    int on_load;                         // backward: 1 = x is the raw operand (re-apply), 0 = x already holds t
+};
+
+__device__ __forceinline__ float ln_keep(unsigned long long seed, unsigned row, unsigned col, unsigned thresh,
+                                         float inv_keep) {
+    unsigned x = (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u) ^ (unsigned)seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += (unsigned)(seed >> 32);
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    return (x >= thresh) ? inv_keep : 0.f;
+}
+
+template <typename T> struct IO8;
+template <> struct IO8<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+        Frag8 f;
+        f.u4 = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(f.h[e]);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+        Frag8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.u[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<uint4*>(p) = f.u4;
+    }
+};
+template <> struct IO8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) { IO8<float>::ld(p, v); }
+
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// t = xform(x) + res for this lane's ITERS chunks of `row`; m[] receives the multiplier applied to x
+template <int GROUP, int ITERS, typename T, bool XF>
+__device__ __forceinline__ void lnv_load(float (&t)[ITERS][8], float (&m)[ITERS][8], const T* x, const T* res,
+                                         int64_t row, int C, int gl, const LnX& xf, bool apply) {
+    float xs = 1.f;
+    unsigned long long sd = 0;
+    if (XF) {
+        if (xf.xscale) xs = xf.xscale[row / xf.rows_per_sample];
+        if (xf.thresh) sd = *xf.seed;
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (i * GROUP + gl) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t[i][e] = 0.f; m[i][e] = 1.f; }
+        if (c < C) {
+            IO8<T>::ld(x + row * C + c, t[i]);
+            if (XF) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float k = xs;
+                    if (xf.thresh) k *= ln_keep(sd, (unsigned)row, (unsigned)(c + e), xf.thresh, xf.inv_keep);
+                    m[i][e] = k;
+                    if (apply) t[i][e] *= k;
+                }
+            }
+            if (res) {
+                float r[8];
+                IO8<T>::ld(res + row * C + c, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[i][e] += r[e];
+            }
+        }
+    }
+}
+
+template <int GROUP, int ITERS, typename T, bool XF>
+__global__ void __launch_bounds__(LN_THREADS) lnv_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, T* __restrict__ y, T* __restrict__ sum_out, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t rows, int C, float eps, LnX xf) {
+    constexpr int RPW = 64 / GROUP;
+    const int lane = threadIdx.x & 63, gl = lane & (GROUP - 1), sub = lane / GROUP;
+    const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * LN_WAVES * RPW;
+    const float invC = 1.0f / (float)C;
+    for (int64_t row0 = wave * RPW; row0 < rows; row0 += stride) {
+        const int64_t row = row0 + sub;
+        const bool live = row < rows;
+        float t[ITERS][8], m[ITERS][8];
+        if (live) lnv_load<GROUP, ITERS, T, XF>(t, m, x, res, row, C, gl, xf, true);
+        else {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[i][e] = 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += t[i][e];
+        const float mu = group_sum<GROUP>(s) * invC;
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if ((i * GROUP + gl) * 8 < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = t[i][e] - mu;
+                    vs += d * d;
+                }
+            }
+        const float rs = rsqrtf(group_sum<GROUP>(vs) * invC + eps);
+        if (!live) continue;
+        if (gl == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = (i * GROUP + gl) * 8;
+            if (c < C) {
+                float g[8], b[8], o[8];
+                ld8f(gamma + c, g);
+                ld8f(beta + c, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (t[i][e] - mu) * rs * g[e] + b[e];
+                IO8<T>::st(y + row * C + c, o);
+                if (sum_out) IO8<T>::st(sum_out + row * C + c, t[i]);
+            }
+        }
+    }
+}
+
+// dx = d t * (x multiplier) [-> dx], d t itself [-> dres, when given];  d t = LN-backward(dy (+ dy2)) (+ dsum)
+template <int GROUP, int ITERS, typename T, bool XF>
+__global__ void __launch_bounds__(LN_THREADS) lnv_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x, const T* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const T* __restrict__ dsum, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, LnX xf) {
+    constexpr int RPW = 64 / GROUP;
+    constexpr int CW = ITERS * GROUP * 8;               // padded row width
+    __shared__ float red[2 * CW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gl = lane & (GROUP - 1), sub = lane / GROUP;
+    const int64_t wave = (int64_t)blockIdx.x * LN_WAVES + wv;
+    const int64_t stride = (int64_t)gridDim.x * LN_WAVES * RPW;
+    const float invC = 1.0f / (float)C;
+    float dg[ITERS][8], db[ITERS][8];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = 0.f;
+    for (int64_t row0 = wave * RPW; row0 < rows; row0 += stride) {
+        const int64_t row = row0 + sub;
+        const bool live = row < rows;
+        float t[ITERS][8], m[ITERS][8], d[ITERS][8];
+        float mu = 0.f, rs = 0.f;
+        if (live) {
+            lnv_load<GROUP, ITERS, T, XF>(t, m, x, res, row, C, gl, xf, xf.on_load != 0);
+            mu = mean[row];
+            rs = rstd[row];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = (i * GROUP + gl) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[i][e] = 0.f;
+            if (live && c < C) {
+                IO8<T>::ld(dy + row * C + c, d[i]);
+                if (dy2) {
+                    float d2[8];
+                    IO8<T>::ld(dy2 + row * C + c, d2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[i][e] += d2[e];
+                }
+                float g[8];
+                ld8f(gamma + c, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (t[i][e] - mu) * rs;
+                    t[i][e] = xh;
+                    dg[i][e] += d[i][e] * xh;
+                    db[i][e] += d[i][e];
+                    d[i][e] *= g[e];                    // g * dy
+                    s1 += d[i][e];
+                    s2 += d[i][e] * xh;
+                }
+            }
+        }
+        s1 = group_sum<GROUP>(s1) * invC;
+        s2 = group_sum<GROUP>(s2) * invC;
+        if (!live) continue;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = (i * GROUP + gl) * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (d[i][e] - s1 - t[i][e] * s2);
+                if (dsum) {                              // gradient arriving through the residual stream
+                    float a[8];
+                    IO8<T>::ld(dsum + row * C + c, a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += a[e];
+                }
+                if (dres) IO8<T>::st(dres + row * C + c, o);
+                if (XF) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] *= m[i][e];
+                }
+                IO8<T>::st(dx + row * C + c, o);
+            }
+        }
+    }
+    // dgamma/dbeta: fold the row groups of the wave, then the 4 waves through LDS (they take turns)
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = GROUP; o < 64; o <<= 1) {
+                dg[i][e] += __shfl_xor(dg[i][e], o, 64);
+                db[i][e] += __shfl_xor(db[i][e], o, 64);
+            }
+        }
+    for (int w = 0; w < LN_WAVES; ++w) {
+        if (wv == w && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int c = (i * GROUP + gl) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (w == 0) {
+                        red[c + e] = dg[i][e];
+                        red[CW + c + e] = db[i][e];
+                    } else {
+                        red[c + e] += dg[i][e];
+                        red[CW + c + e] += db[i][e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int nblk = gridDim.x;
+    if (dgamma) {                                   // few blocks: add straight into dgamma/dbeta, no second kernel
+        for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+            atomicAdd(dgamma + c, red[c]);
+            atomicAdd(dbeta + c, red[CW + c]);
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+        partial[(int64_t)blockIdx.x * C + c] = red[c];
+        partial[((int64_t)nblk + blockIdx.x) * C + c] = red[CW + c];
+    }
+}
+
+struct LnvCfg { int group, iters; };
+inline bool lnv_config(int C, LnvCfg& cfg) {
+    if (C % 8 || C > 3072) return false;
+    const int chunks = C / 8;
+    if (chunks <= 16) cfg = {16, 1};
+    else if (chunks <= 32) cfg = {32, 1};
+    else {
+        const int need = (chunks + 63) / 64;
+        const int opts[] = {1, 2, 3, 4, 6};
+        cfg.group = 64;
+        cfg.iters = 6;
+        for (int o : opts) if (o >= need) { cfg.iters = o; break; }
+    }
+    return true;
+}
+inline int lnv_blocks(int64_t rows, int group) {
+    const int rpb = LN_WAVES * (64 / group);           // rows per block per pass
+    int64_t b = (rows + rpb - 1) / rpb;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define LNV_CASE(G, I, KERNEL, TY, XF, GRID, ...)                                                             \
+    if (cfg.group == G && cfg.iters == I) {                                                                   \
+        if (XF) hipLaunchKernelGGL((KERNEL<G, I, TY, true>), dim3(GRID), dim3(LN_THREADS), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<G, I, TY, false>), dim3(GRID), dim3(LN_THREADS), 0, st, __VA_ARGS__);   \
+    }
+#define LNV_DISPATCH(KERNEL, TY, XF, GRID, ...)                                                 \
+    LNV_CASE(16, 1, KERNEL, TY, XF, GRID, __VA_ARGS__) LNV_CASE(32, 1, KERNEL, TY, XF, GRID, __VA_ARGS__) \
+    LNV_CASE(64, 1, KERNEL, TY, XF, GRID, __VA_ARGS__) LNV_CASE(64, 2, KERNEL, TY, XF, GRID, __VA_ARGS__) \
+    LNV_CASE(64, 3, KERNEL, TY, XF, GRID, __VA_ARGS__) LNV_CASE(64, 4, KERNEL, TY, XF, GRID, __VA_ARGS__) \
+    LNV_CASE(64, 6, KERNEL, TY, XF, GRID, __VA_ARGS__)
+
+inline bool make_lnx(const ClvLnExtra* ex, LnX& xf) {
+    xf = LnX{nullptr, 1, 0u, 1.f, nullptr, 0};
+    if (!ex) return false;
+    xf.xscale = ex->xscale;
+    xf.rows_per_sample = ex->rows_per_sample > 0 ? ex->rows_per_sample : 1;
+    if (ex->drop_p > 0.f) {
+        xf.thresh = (unsigned)((double)ex->drop_p * 4294967296.0);
+        xf.inv_keep = 1.0f / (1.0f - ex->drop_p);
+        xf.seed = (const unsigned long long*)ex->seed;
+    }
+    xf.on_load = ex->x_is_sum ? 0 : 1;
+    return xf.xscale != nullptr || xf.thresh != 0;
+}
+
 // --------------------------------------------------------------------------- GELU
 __global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -301,10 +637,26 @@ int ew_blocks(int64_t n8) {
 
 extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                                  void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,
-                                 float eps, int32_t is_f32, void* stream) {
+                                 float eps, int32_t is_f32, const ClvLnExtra* extra, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || C <= 0 || (C & 1)) return CLV_ERR_ARG;
     if (rows == 0) return CLV_OK;
     hipStream_t st = (hipStream_t)stream;
+    LnX xf;
+    const bool XF = make_lnx(extra, xf);
+    if (xf.thresh && !xf.seed) return CLV_ERR_ARG;
+    LnvCfg cfg;
+    if (lnv_config(C, cfg)) {
+        const int grid = lnv_blocks(rows, cfg.group);
+        if (is_f32) {
+            LNV_DISPATCH(lnv_fwd_kernel, float, XF, grid, (const float*)x, (const float*)res, gamma, beta, (float*)y,
+                         (float*)sum_out, mean, rstd, rows, (int)C, eps, xf)
+        } else {
+            LNV_DISPATCH(lnv_fwd_kernel, bf16_t, XF, grid, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
+                         (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)C, eps, xf)
+        }
+        return clv_check_launch();
+    }
+    if (XF) return CLV_ERR_UNSUPPORTED;              // the scalar fallback has no operand transforms
     const int it = ln_iters(C);
     const int grid = ln_fwd_blocks(rows);
     if (is_f32) {
@@ -318,7 +670,8 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
 }
 
 extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
-    (void)C;
+    LnvCfg cfg;
+    if (lnv_config(C, cfg)) return lnv_blocks(rows, cfg.group);
     int64_t b = (rows + LN_WAVES - 1) / LN_WAVES;      // one row per wave until the chip is full
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
@@ -328,22 +681,44 @@ extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
 extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                                  const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma,
                                  float* dbeta, float* partial, int64_t rows, int32_t C, int32_t is_f32,
-                                 void* stream) {
+                                 const ClvLnExtra* extra, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows <= 0 || C <= 0 ||
         (C & 1))
         return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int it = ln_iters(C);
+    LnX xf;
+    const bool XF = make_lnx(extra, xf);
+    if (xf.thresh && !xf.seed) return CLV_ERR_ARG;
+    const void* dy2 = extra ? extra->dy2 : nullptr;
+    void* dres = extra ? extra->dres : nullptr;
     const int grid = clv_layernorm_bwd_blocks(rows, C);
-    if (is_f32) {
-        LN_DISPATCH(it, ln_bwd_kernel, float, grid, (const float*)dy, (const float*)x, (const float*)res, gamma,
-                    mean, rstd, (const float*)dsum, (float*)dx, partial, rows, (int)C)
+    const bool direct = grid <= 256;              // up to 256 partial rows: atomics beat a second launch
+    float* dgd = direct ? dgamma : nullptr;
+    float* dbd = direct ? dbeta : nullptr;
+    LnvCfg cfg;
+    if (lnv_config(C, cfg)) {
+        if (is_f32) {
+            LNV_DISPATCH(lnv_bwd_kernel, float, XF, grid, (const float*)dy, (const float*)dy2, (const float*)x,
+                         (const float*)res, gamma, mean, rstd, (const float*)dsum, (float*)dx, (float*)dres, partial,
+                         dgd, dbd, rows, (int)C, xf)
+        } else {
+            LNV_DISPATCH(lnv_bwd_kernel, bf16_t, XF, grid, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)x,
+                         (const bf16_t*)res, gamma, mean, rstd, (const bf16_t*)dsum, (bf16_t*)dx, (bf16_t*)dres,
+                         partial, dgd, dbd, rows, (int)C, xf)
+        }
     } else {
-        LN_DISPATCH(it, ln_bwd_kernel, bf16_t, grid, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)res,
-                    gamma, mean, rstd, (const bf16_t*)dsum, (bf16_t*)dx, partial, rows, (int)C)
+        if (XF || dy2 || dres) return CLV_ERR_UNSUPPORTED;
+        const int it = ln_iters(C);
+        if (is_f32) {
+            LN_DISPATCH(it, ln_bwd_kernel, float, grid, (const float*)dy, (const float*)x, (const float*)res, gamma,
+                        mean, rstd, (const float*)dsum, (float*)dx, partial, dgd, dbd, rows, (int)C)
+        } else {
+            LN_DISPATCH(it, ln_bwd_kernel, bf16_t, grid, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)res,
+                        gamma, mean, rstd, (const bf16_t*)dsum, (bf16_t*)dx, partial, dgd, dbd, rows, (int)C)
+        }
     }
     int rc = clv_check_launch();
-    if (rc) return rc;
+    if (rc || direct) return rc;
     const int ysplit = grid >= 256 ? 8 : 1;      // > 1: atomics into dgamma/dbeta (caller zeroes them)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64, ysplit), dim3(1024), 0, st, partial, dgamma, dbeta,
                        grid, (int)C);

@@ -34,8 +34,9 @@ class LinearFP32(nn.Linear):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, residual=None, return_sum=False):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual, return_sum=return_sum)
+    def forward(self, x, residual=None, return_sum=False, x_scale=None, x_dropout_p=0.0, fork=False):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual, return_sum=return_sum,
+                              x_scale=x_scale, x_dropout_p=x_dropout_p, fork=fork)
 
 
 class GELU(nn.Module):
@@ -44,18 +45,34 @@ class GELU(nn.Module):
 
 
 class DropPath(nn.Module):
-    """Per-sample stochastic depth (timm DropPath; swin_transformer_3d.py:441,498,503)."""
+    """Per-sample stochastic depth (timm DropPath; swin_transformer_3d.py:441,498,503).
+
+    ``scale(x)`` returns the per-sample factor [B] (mask / keep_prob, fp32) or None when inactive, so that a
+    consumer can fold it into its own kernel (the LayerNorm that follows: ``x_scale=``).  A parent module may
+    preset the factors of all its DropPaths with one RNG call per step (``preset``)."""
 
     def __init__(self, drop_prob=0.):
         super().__init__()
         self.drop_prob = float(drop_prob)
+        self._preset = None
+
+    def preset(self, scale):
+        self._preset = scale
+
+    def scale(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return None
+        if self._preset is not None and self._preset.shape[0] == x.shape[0]:
+            return self._preset
+        keep = 1.0 - self.drop_prob
+        return torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep) / keep
+
+    @staticmethod
+    def apply_scale(x, scale):
+        return x if scale is None else x * scale.view((x.shape[0],) + (1,) * (x.dim() - 1)).to(x.dtype)
 
     def forward(self, x):
-        if self.drop_prob == 0. or not self.training:
-            return x
-        keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
-        return x * (mask / keep)
+        return self.apply_scale(x, self.scale(x))
 
     def extra_repr(self):
         return f'drop_prob={self.drop_prob}'

@@ -255,7 +255,7 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
             ds2 = ds2.to(BF16)
     check(L.clv_layernorm_bwd(_ptr(dxhat), _ptr(x), _ptr(None), _ptr(ones), _ptr(mean), _ptr(rstd), _ptr(ds2),
                               _ptr(dx), _ptr(junk), C.c_void_p(junk.data_ptr() + 4 * C_), _ptr(partial), rows, C_, 0,
-                              _stream()), 'clv_layernorm_bwd')
+                              None, _stream()), 'clv_layernorm_bwd')
     return dx
 
 
@@ -414,13 +414,25 @@ def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=No
 
 
 # --------------------------------------------------------------------------- LayerNorm
+def _ln_extra(xscale, rows_per_sample, drop_p, seed, dy2=None, dres=None, x_is_sum=False):
+    """ClvLnExtra for the C call, or None when nothing is requested (keeps its tensors alive via the caller)."""
+    if xscale is None and not drop_p and dy2 is None and dres is None:
+        return None
+    return _lib.ClvLnExtra(_ptr(xscale), int(rows_per_sample), float(drop_p or 0.0), _ptr(seed), _ptr(dy2),
+                           _ptr(dres), int(x_is_sum))
+
+
 class _LayerNorm(torch.autograd.Function):
-    """y = LN(x [+ res]); with want_sum also returns s = x + res (the updated residual stream), and the
+    """y = LN(f(x) [+ res]); with want_sum also returns s = f(x) + res (the updated residual stream), and the
     backward folds the gradient arriving on s into dx — the Swin residual adds never run as kernels.
+    f = the transforms that sit between the sub-layer and the norm in the model, applied while the row is
+    loaded instead of as elementwise kernels: nn.Dropout(p) (BertSelfOutput / BertOutput) and the per-sample
+    DropPath factor xscale [B] (swin_transformer_3d.py:498,503).  fork: y is returned twice (two autograd
+    edges, one storage) and the backward reads both upstream gradients itself instead of autograd adding them.
     Engine-managed gamma/beta receive their gradients directly in the flat slab (atomics)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, want_sum):
+    def forward(ctx, x, res, gamma, beta, eps, want_sum, xscale, drop_p, fork):
         _need_gpu(x, gamma)
         C_ = x.shape[-1]
         x2 = _c(x).view(-1, C_)
@@ -437,37 +449,52 @@ class _LayerNorm(torch.autograd.Function):
         ssum = torch.empty_like(x2) if want_sum else None
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        xs = rps = seed = None
+        if xscale is not None:
+            xs = _c(xscale.reshape(-1).float())
+            rps = rows // xs.numel()
+            assert rps * xs.numel() == rows, 'xscale must have one entry per leading-dim sample'
+        if drop_p:
+            seed = next_dropout_seed(x.device)
+        ex = _ln_extra(xs, rps or 1, drop_p, seed)
         check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), _ptr(ssum), _ptr(mean),
-                                           _ptr(rstd), rows, C_, float(eps), int(f32), _stream()),
+                                           _ptr(rstd), rows, C_, float(eps), int(f32),
+                                           C.byref(ex) if ex is not None else None, _stream()),
               'clv_layernorm_fwd')
         if want_sum:
-            ctx.save_for_backward(ssum, None, g, mean, rstd)    # x + res is all the backward needs
+            ctx.save_for_backward(ssum, None, g, mean, rstd, xs, seed)    # f(x) + res is all the backward needs
         else:
-            ctx.save_for_backward(x2, r2, g, mean, rstd)
+            ctx.save_for_backward(x2, r2, g, mean, rstd, xs, seed)
+        ctx.x_is_sum = bool(want_sum)
+        ctx.rps, ctx.drop_p = rps or 1, float(drop_p or 0.0)
         ctx.has_res = res is not None
         ctx.xshape = x.shape
         ctx.gdtype = gamma.dtype
         ctx.gref, ctx.bref = gamma, beta
-        if want_sum:
-            return y.view(x.shape), ssum.view(x.shape)
-        return y.view(x.shape), None
+        yv = y.view(x.shape)
+        return yv, (ssum.view(x.shape) if want_sum else None), (yv.view_as(yv) if fork else None)
 
     @staticmethod
-    def backward(ctx, dy, dsum):
-        x2, r2, g, mean, rstd = ctx.saved_tensors
+    def backward(ctx, dy, dsum, dyf):
+        x2, r2, g, mean, rstd, xs, seed = ctx.saved_tensors
         rows, C_ = x2.shape
-        dy2 = _c(dy).view(rows, C_)
-        if dy2.dtype != x2.dtype:
-            dy2 = dy2.to(x2.dtype)
-        ds2 = None
-        if dsum is not None:
-            ds2 = _c(dsum).view(rows, C_)
-            if ds2.dtype != x2.dtype:
-                ds2 = ds2.to(x2.dtype)
+
+        def prep(t):
+            if t is None:
+                return None
+            t = _c(t).view(rows, C_)
+            return t if t.dtype == x2.dtype else t.to(x2.dtype)
+        dy2, ds2, dyf2 = prep(dy), prep(dsum), prep(dyf)
+        if dy2 is None:
+            dy2, dyf2 = dyf2, None
+        if dy2 is None:
+            dy2 = torch.zeros_like(x2)
         L = _lib.lib()
         nblk = L.clv_layernorm_bwd_blocks(rows, C_)
         partial = torch.empty(2 * nblk * C_, device=x2.device, dtype=torch.float32)
         dx = torch.empty_like(x2)
+        xform = xs is not None or ctx.drop_p > 0
+        dres = torch.empty_like(x2) if (xform and ctx.has_res) else None
         gsink = getattr(ctx.gref, '_clv_grad', None)
         bsink = getattr(ctx.bref, '_clv_grad', None)
         sink = gsink is not None and bsink is not None and gsink.dtype == torch.float32
@@ -476,22 +503,31 @@ class _LayerNorm(torch.autograd.Function):
         else:
             dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
             db = torch.zeros_like(dg)
+        ex = _ln_extra(xs, ctx.rps, ctx.drop_p, seed, dyf2, dres, ctx.x_is_sum)
         check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(ds2),
                                   _ptr(dx), _ptr(dg), _ptr(db), _ptr(partial), rows, C_,
-                                  int(x2.dtype == torch.float32), _stream()), 'clv_layernorm_bwd')
+                                  int(x2.dtype == torch.float32), C.byref(ex) if ex is not None else None,
+                                  _stream()), 'clv_layernorm_bwd')
         dxv = dx.view(ctx.xshape)
+        drv = None
+        if ctx.has_res:
+            drv = dres.view(ctx.xshape) if dres is not None else dxv
         if sink:
             ctx.gref._clv_ready()
             ctx.bref._clv_ready()
-            return dxv, (dxv if ctx.has_res else None), None, None, None, None
-        return dxv, (dxv if ctx.has_res else None), dg.to(ctx.gdtype), db.to(ctx.gdtype), None, None
+            return dxv, drv, None, None, None, None, None, None, None
+        return dxv, drv, dg.to(ctx.gdtype), db.to(ctx.gdtype), None, None, None, None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False):
-    """y = LayerNorm(x [+ residual]) over the last dim; bf16 (or fp32) in/out, fp32 statistics.
-    return_sum=True -> (y, x + residual)."""
-    y, s = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum))
-    return (y, s) if return_sum else y
+def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_scale=None, x_dropout_p=0.0,
+               fork=False):
+    """y = LayerNorm(f(x) [+ residual]) over the last dim; bf16 (or fp32) in/out, fp32 statistics.
+    f: optional dropout(p = x_dropout_p) then per-sample factor x_scale [B] on x (fused, see _LayerNorm).
+    return_sum=True -> (y, f(x) + residual);  fork=True -> y is returned twice (y, y2 share storage; use one
+    for each consumer and their gradients meet inside the LayerNorm backward kernel)."""
+    y, s, y2 = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum), x_scale, float(x_dropout_p), bool(fork))
+    out = (y,) + ((s,) if return_sum else ()) + ((y2,) if fork else ())
+    return out if len(out) > 1 else y
 
 
 # --------------------------------------------------------------------------- GELU
@@ -604,17 +640,61 @@ def window_attention(qkv, bias, rid, window, shift, num_heads):
 _DROPOUT_COUNTER = {}
 
 
-def next_dropout_seed(device):
-    """A fresh device-resident uint64 seed per attention call, derived from a device counter that is
-    advanced by a (capturable) kernel — so every hipGraph replay draws new masks without host traffic.
-    The counter starts from torch's seeded CPU generator (torch.manual_seed controls it)."""
-    key = str(device)
+_SEED_STRIDE = 0x9E3779B97F4A7C15 - (1 << 64)          # odd 64-bit stride (wraps)
+_SEED_POOL = {}
+
+
+def _dev_key(device):
+    d = torch.device(device)
+    return f'cuda:{torch.cuda.current_device() if d.index is None else d.index}' if d.type == 'cuda' else str(d)
+
+
+def _wrap64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def dropout_seeds_begin(device, n=128):
+    """Refresh the step's pool of dropout seeds: ONE kernel writes n fresh device-resident uint64 seeds and
+    one advances the counter; every next_dropout_seed() until the next begin() is then a free slice.  Call
+    it inside the captured region (start of the forward), so each hipGraph replay draws new masks."""
+    key = _dev_key(device)
+    ctr = _dropout_counter(device)
+    pool = _SEED_POOL.get(key)
+    if pool is None or pool['seeds'].numel() != n:
+        pool = dict(seeds=torch.empty(n, device=device, dtype=torch.int64),
+                    steps=torch.arange(n, device=device, dtype=torch.int64) * _SEED_STRIDE, idx=0)
+        _SEED_POOL[key] = pool
+    torch.add(pool['steps'], ctr, out=pool['seeds'])
+    ctr.add_(_wrap64(n * _SEED_STRIDE))
+    pool['idx'] = 0
+
+
+def dropout_seeds_end(device):
+    """Back to one counter update per seed (ops used outside a step)."""
+    _SEED_POOL.pop(_dev_key(device), None)
+
+
+def _dropout_counter(device):
+    key = _dev_key(device)
     if key not in _DROPOUT_COUNTER:
         init = int(torch.randint(1, 2 ** 62, (1,)).item())
         _DROPOUT_COUNTER[key] = torch.tensor([init], device=device, dtype=torch.int64)
-    ctr = _DROPOUT_COUNTER[key]
+    return _DROPOUT_COUNTER[key]
+
+
+def next_dropout_seed(device):
+    """A fresh device-resident uint64 seed per dropout site, derived from a device counter that is
+    advanced by a (capturable) kernel — so every hipGraph replay draws new masks without host traffic.
+    The counter starts from torch's seeded CPU generator (torch.manual_seed controls it)."""
+    pool = _SEED_POOL.get(_dev_key(device))
+    if pool is not None and pool['idx'] < pool['seeds'].numel():
+        i = pool['idx']
+        pool['idx'] = i + 1
+        return pool['seeds'][i:i + 1]
+    ctr = _dropout_counter(device)
     seed = ctr.clone()
-    ctr.add_(0x9E3779B97F4A7C15 - (1 << 64))          # odd 64-bit stride (wraps)
+    ctr.add_(_SEED_STRIDE)
     return seed
 
 
@@ -690,7 +770,8 @@ class _PatchEmbed(torch.autograd.Function):
             dg = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
             db = torch.zeros_like(dg)
             check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(None), _ptr(dz),
-                                      _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, _stream()), 'clv_layernorm_bwd')
+                                      _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, None, _stream()),
+                  'clv_layernorm_bwd')
         else:
             dz, dg, db = dyb, None, None
         patches = torch.empty(M, 96, device=xc.device, dtype=BF16)

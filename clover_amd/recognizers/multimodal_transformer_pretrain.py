@@ -12,6 +12,8 @@ LayerNorm only — so batching passes along dim 0 changes no value):
 """
 import torch
 
+from .. import ops
+
 from ..builder import RECOGNIZERS, build_backbone, build_head, build_loss
 from .base import BaseRecognizer
 
@@ -65,6 +67,8 @@ class CloverPretrain(BaseRecognizer):
             raise NotImplementedError('the MI355X path implements the full pre-training recipe (ssl_head + '
                                       'mlm_head + mlm_ssl_head V/T + use_Cmask + symmetry_rank + mlm_label + '
                                       'v_token_mask), i.e. configs/exp_local/pretrain_webvid_cc3m.py')
+        if self.training and imgs.is_cuda:
+            ops.dropout_seeds_begin(imgs.device)        # one RNG-counter kernel for all dropout sites of the step
         imgs = imgs.reshape((-1,) + imgs.shape[2:])                                   # :81
         if self.from_scratch:
             imgs = imgs / 255.0

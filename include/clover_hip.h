@@ -87,16 +87,32 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
  * float [rows].  res (same type as x, may be NULL): y = LN(x + res) (BERT post-LN residual;
  * the Swin residual adds of :498,503 fused into the following norm).  sum_out (may be NULL)
  * receives x + res — the updated residual stream. */
+/* Optional operand transforms / extra operands (pass NULL for a plain LayerNorm; C % 8 == 0 and C <= 3072 only):
+ *   forward   t = keep(x) * x / (1 - drop_p) * xscale[row / rows_per_sample] + res,  y = LN(t)
+ * i.e. the nn.Dropout on the sub-layer output (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input))
+ * and the per-sample DropPath factor (swin_transformer_3d.py:498,503) applied while the row is loaded.  The
+ * dropout mask is a pure function of (*seed, row, column); the backward regenerates it.
+ *   backward  d t = LN-backward(dy + dy2) + dsum;  dres (may be NULL) receives d t, dx receives d t times the
+ * multiplier x carried.  x_is_sum = 1: the x argument of the backward already holds t (a saved sum_out). */
+typedef struct ClvLnExtra {
+    const float* xscale;       /* per-sample factor on x, or NULL */
+    int32_t rows_per_sample;
+    float drop_p;              /* dropout probability on x, 0 = off */
+    const void* seed;          /* device uint64, required when drop_p > 0 */
+    const void* dy2;           /* backward: second upstream gradient (same type as dy), or NULL */
+    void* dres;                /* backward: gradient wrt res when it differs from dx, or NULL */
+    int32_t x_is_sum;
+} ClvLnExtra;
 int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                       void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,
-                      float eps, int32_t is_f32, void* stream);
-/* dx [rows][C] (gradient wrt x and, identically, wrt res) = LN backward of dy (+ dsum, the
- * gradient arriving on sum_out, may be NULL); dgamma,dbeta float [C]
+                      float eps, int32_t is_f32, const ClvLnExtra* extra, void* stream);
+/* dx [rows][C] (gradient wrt x and, identically, wrt res unless extra says otherwise) = LN backward of dy
+ * (+ dsum, the gradient arriving on sum_out, may be NULL); dgamma,dbeta float [C]
  * ACCUMULATED into (caller zeroes); partial: float scratch [2][nblk][C] with nblk = clv_layernorm_bwd_blocks(). */
 int clv_layernorm_bwd_blocks(int64_t rows, int32_t C);
 int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                       const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma, float* dbeta,
-                      float* partial, int64_t rows, int32_t C, int32_t is_f32, void* stream);
+                      float* partial, int64_t rows, int32_t C, int32_t is_f32, const ClvLnExtra* extra, void* stream);
 
 /* ------------------------------------------------------------------ GELU (erf)
  * nn.GELU / HF 'gelu' (swin_transformer_3d.py:264; BertIntermediate; ssl_head.py:53). */

@@ -324,6 +324,78 @@ def test_layernorm_fused_residual_stream():
     assert rel(gg.grad, gr.grad) < 1e-2 and rel(bg.grad, br.grad) < 1e-2
 
 
+@pytest.mark.parametrize('rows,C,f32', [(1000, 96, False), (777, 192, False), (300, 384, False), (130, 768, False),
+                                        (65, 1536, False), (64, 2048, False), (50, 3072, False), (40, 64, True),
+                                        (37, 100, False), (9, 768, True)])
+def test_layernorm_shapes(rows, C, f32):
+    """Every lane-group configuration of the vector kernels (C % 8 == 0) and the scalar fallback (C = 100),
+    bf16 and fp32 storage, plain and with residual + residual-stream output."""
+    dt = torch.float32 if f32 else BF
+    x, r = rnd(rows, C, seed=181).to(dt), rnd(rows, C, seed=182).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=183), 0.1 * rnd(C, seed=184)
+    dy, ds = rnd(rows, C, seed=185).to(dt), rnd(rows, C, seed=186).to(dt)
+    for with_res in (False, True):
+        xr, rr = x.float().clone().requires_grad_(), r.float().clone().requires_grad_()
+        gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+        sr = xr + rr if with_res else xr
+        yr = F.layer_norm(sr, (C,), gr, br, 1e-5)
+        xg, rg = x.to(DEV).detach().requires_grad_(), r.to(DEV).detach().requires_grad_()
+        gg, bg = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        if with_res:
+            torch.autograd.backward([yr, sr], [dy.float(), ds.float()])
+            y, s_ = ops().layer_norm(xg, gg, bg, 1e-5, residual=rg, return_sum=True)
+            torch.autograd.backward([y, s_], [dy.to(DEV), ds.to(DEV)])
+            assert rel(rg.grad, rr.grad) < (1e-4 if f32 else 2e-2)
+        else:
+            yr.backward(dy.float())
+            y = ops().layer_norm(xg, gg, bg, 1e-5)
+            y.backward(dy.to(DEV))
+        tol = 1e-4 if f32 else 2e-2
+        assert rel(y, yr) < tol and rel(xg.grad, xr.grad) < tol
+        assert rel(gg.grad, gr.grad) < (1e-4 if f32 else 1e-2) and rel(bg.grad, br.grad) < (1e-4 if f32 else 1e-2)
+
+
+@pytest.mark.parametrize('B,T,C', [(4, 50, 96), (6, 33, 384), (2, 64, 768)])
+def test_layernorm_operand_transforms(B, T, C):
+    """LN(dropout(x) * xscale[b] + res): recover the kernel's dropout mask from an all-ones operand, then
+    check forward, every input gradient, the residual-stream output and the forked output against torch."""
+    pd = 0.2
+    x, r = rnd(B, T, C, seed=191).to(BF), rnd(B, T, C, seed=192).to(BF)
+    g, b = 1 + 0.1 * rnd(C, seed=193), 0.1 * rnd(C, seed=194)
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25][:B])
+    dy, dy2, ds = rnd(B, T, C, seed=195).to(BF), rnd(B, T, C, seed=196).to(BF), rnd(B, T, C, seed=197).to(BF)
+    torch.manual_seed(5)
+    o = ops()
+    state = o._dropout_counter(torch.device(DEV)).clone()
+    o.dropout_seeds_begin(torch.device(DEV))
+    try:
+        # mask probe: same seed slot (pool index 0) as the real call below, after the counter is rewound
+        ones = torch.ones(B, T, C, device=DEV, dtype=BF)
+        _, probe = o.layer_norm(ones, g.to(DEV), b.to(DEV), 1e-5, residual=torch.zeros_like(ones), return_sum=True,
+                                x_dropout_p=pd)
+        mask = (probe.float() > 0.5).float().cpu()                   # kept elements hold 1 / (1 - p)
+        assert abs(mask.mean().item() - (1 - pd)) < 0.03
+        o._dropout_counter(torch.device(DEV)).copy_(state)      # rewind: the next begin() redraws the same seeds
+        o.dropout_seeds_begin(torch.device(DEV))
+        xg, rg = x.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+        gg, bg = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        y, s_, y2 = o.layer_norm(xg, gg, bg, 1e-5, residual=rg, return_sum=True, x_scale=sc.to(DEV), x_dropout_p=pd,
+                                 fork=True)
+        assert y2.data_ptr() == y.data_ptr()
+        torch.autograd.backward([y, s_, y2], [dy.to(DEV), ds.to(DEV), dy2.to(DEV)])
+    finally:
+        o.dropout_seeds_end(torch.device(DEV))
+    xr, rr = x.float().requires_grad_(), r.float().requires_grad_()
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    sr = xr * mask / (1 - pd) * sc[:, None, None] + rr
+    yr = F.layer_norm(sr, (C,), gr, br, 1e-5)
+    torch.autograd.backward([yr, sr], [dy.float() + dy2.float(), ds.float()])
+    assert rel(s_, sr) < 1e-2 and rel(y, yr) < 2e-2
+    assert rel(xg.grad, xr.grad) < 2e-2 and rel(rg.grad, rr.grad) < 2e-2
+    assert rel(gg.grad, gr.grad) < 1e-2 and rel(bg.grad, br.grad) < 1e-2
+    assert float(xg.grad[0].abs().max()) == 0.0                      # sample 0 is dropped by its path factor
+
+
 def test_seq_attention_dropout():
     """Attention-probability dropout: recover the kernel's mask with uniform attention + identity V, then
     check forward and backward against a torch reference that uses exactly that mask."""
