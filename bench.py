@@ -288,6 +288,12 @@ def main():
         }
         if prof:
             res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, prof_steps)
+            # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes (tools/pmc_traffic.sh; counters
+            # cannot be read from inside the process), null when no measurement of this kernel is committed
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(res['roofline']['kernel'])
+                res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
         print(json.dumps(res))

@@ -187,10 +187,24 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma_kernel(const bf16_t* 
                                                                   const bf16_t* __restrict__ x,
                                                                   float* __restrict__ out, float* __restrict__ out_b,
                                                                   int64_t M, int N, int K, int ldy, int ldx, int tiles,
-                                                                  int tilesK, int64_t rows_per_split, int want_bias) {
+                                                                  int tilesK, int nsplits, int64_t rows_per_split,
+                                                                  int want_bias) {
     __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
-    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+    // Workgroup i runs on XCD i % 8 (round-robin dispatch).  All output tiles of one M-slice are placed on ONE
+    // XCD, in consecutive slots, so the dY / X rows they share come from HBM once and are re-read from that
+    // XCD's L2 (the slices' workgroups start together and walk their rows at the same pace).
+    // (nsplits < 0: plain order — few slices, or few tiles per slice, where spreading over all XCDs wins.)
+    int split, tile;
+    if (nsplits > 0) {
+        const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+        split = xcd + 8 * (xslot / tiles);
+        tile = xslot % tiles;
+        if (split >= nsplits) return;
+    } else {
+        split = blockIdx.x / tiles;
+        tile = blockIdx.x - split * tiles;
+    }
     const int tn = tile / tilesK, tk = tile - tn * tilesK;
     const int n0 = tn * TN, k0 = tk * TK;
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
@@ -347,6 +361,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 int pick_splits(int64_t M, int tiles) {
     if (M <= 1024) return 1;                            // few rows: one slice, accumulate directly (no partials)
     int64_t s = (256 + tiles - 1) / tiles;              // ~1 workgroup per CU, 3 stages each in flight
+    if (tiles >= 4) s = (s + 7) / 8 * 8;                // whole M-slices per XCD (see wgrad_dma_kernel)
     const int64_t max_by_rows = (M + 255) / 256;        // >= 256 rows per slice
     if (s > max_by_rows) s = max_by_rows;
     if (s < 1) s = 1;
@@ -379,15 +394,18 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     int rc = CLV_OK;
     if (stages & 1) {
         const int total = tiles * splits;
+        const bool xcd_map = splits >= 8 && tiles >= 4;
+        const int dma_grid = xcd_map ? 8 * tiles * ((splits + 7) / 8) : total;     // slots x 8 XCDs
+        const int nsp = xcd_map ? splits : -1;
         if (xmean) {                       // standardise-on-load needs the register-staged kernel
             hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, M, (int)N, (int)K,
                                (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0, xmean, xrstd);
         } else if (splits == 1) {          // one M-slice: accumulate straight into dW / db, no partials, no fold
-            hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M, (int)N,
-                               (int)K, (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0);
+            hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+                               (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr, M,
-                               (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0);
+            hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
+                               M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         }
         rc = clv_check_launch();
         if (rc) return rc;
