@@ -389,6 +389,9 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     const int splits = pick_splits(M, tiles);
     int64_t rows = (M + splits - 1) / splits;
     rows = (rows + TM - 1) / TM * TM;
+    // up to 24 slices add their tiles into dW with no-return fp32 atomics (measured: cheaper than partials + fold;
+    // with more slices the same-address contention at the memory-side atomic units costs more than the fold)
+    const bool atomic_acc = splits <= 24;
     const bf16_t* dyp = (const bf16_t*)dy;
     const bf16_t* xp = (const bf16_t*)x;
     int rc = CLV_OK;
@@ -400,7 +403,7 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
         if (xmean) {                       // standardise-on-load needs the register-staged kernel
             hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, M, (int)N, (int)K,
                                (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0, xmean, xrstd);
-        } else if (splits == 1) {          // one M-slice: accumulate straight into dW / db, no partials, no fold
+        } else if (atomic_acc) {           // few M-slices: accumulate straight into dW / db, no partials, no fold
             hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
                                (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else {
@@ -410,7 +413,7 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
         rc = clv_check_launch();
         if (rc) return rc;
     }
-    if ((stages & 2) && (splits > 1 || xmean)) {
+    if ((stages & 2) && !(atomic_acc && !xmean)) {
         const int64_t NK = (int64_t)N * K, E2 = NK + N;
         const int64_t Eeff = db ? E2 : NK;
         hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK,
