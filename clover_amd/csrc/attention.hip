@@ -80,22 +80,26 @@ __device__ __forceinline__ void lds_frags(Frag8 (&f)[(HD + 31) / 32], const bf16
     }
 }
 
-// Stage `N` rows of a [tokens][ld] bf16 matrix (cols h*HD .. +HD) of group `grp` row-major into
+// Stage `N` rows (tensor rows row_s[n]) of a [tokens][ld] bf16 matrix (cols h*HD .. +HD) row-major into
 // LDS rm[NK][HD+8]; pad rows are zeroed.  Transposed operands are NOT materialised: they are read
 // with the gfx950 LDS transpose read (tr4 below).
 template <int HD, int NK>
-__device__ __forceinline__ void stage(const Geom& G, const bf16_t* base, int ld, int grp, int h,
-                                      bf16_t* rm, int tid) {
+__device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int ld, int h, int N, bf16_t* rm, int tid) {
     constexpr int CH = HD / 8, LDR = HD + 8;
     for (int idx = tid; idx < NK * CH; idx += THREADS) {
         const int n = idx / CH, c = idx - n * CH;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (n < G.g.N) {
-            const int64_t row = tok_row(G, grp, n);
-            val = *reinterpret_cast<const uint4*>(base + row * ld + h * HD + c * 8);
-        }
+        if (n < N) val = *reinterpret_cast<const uint4*>(base + (int64_t)row_s[n] * ld + h * HD + c * 8);
         *reinterpret_cast<uint4*>(rm + n * LDR + c * 8) = val;
     }
+}
+
+// The token -> tensor-row map of this window (roll / partition folded in, ~60 integer VALU ops with five
+// divisions) is evaluated ONCE per workgroup into LDS; staging and the per-tile operand loads index it.
+template <int NK>
+__device__ __forceinline__ void token_rows(const Geom& G, int grp, int* row_s, int tid) {
+    for (int n = tid; n < NK; n += THREADS) row_s[n] = (n < G.g.N) ? (int)tok_row(G, grp, n) : 0;
+    __syncthreads();
 }
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -111,6 +115,12 @@ __device__ __forceinline__ uint2 tr4(const bf16_t* base, int LD, int row0, int c
     return cv.u;
 }
 
+// exp(x - L) as ONE v_exp_f32: exp2(x * log2e - L * log2e).  __expf costs a multiply plus two v_cndmask of
+// denormal-range handling per element, which is a third of the softmax VALU work here; a result below 2^-126 is
+// flushed to zero, which is what a probability that small contributes anyway.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float exp_sub(float x, float negL2) { return __builtin_amdgcn_exp2f(fmaf(x, LOG2E, negL2)); }
+
 // score epilogue for one Sᵀ tile element
 struct ScoreCtx {
     const float* bias_row;   // bias + (h*N + q)*bias_ld or nullptr
@@ -123,7 +133,7 @@ struct ScoreCtx {
 
 // ------------------------------------------------------------------------- forward
 template <int HD, int NKT, bool DROP, int MODE>
-__global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
+__global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
     const int* __restrict__ rid, const float* __restrict__ kmask, const unsigned long long* __restrict__ seedp,
@@ -139,13 +149,18 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
     const int N = G.g.N;
 
-    stage<HD, NK>(G, k, G.g.ldk, grp, h, Ks, tid);
-    stage<HD, NK>(G, v, G.g.ldv, grp, h, Vs, tid);
+    int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
+    token_rows<NK>(G, grp, row_s, tid);
+    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
+    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
     int* rid_s = reinterpret_cast<int*>(aux);
+    // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
+    // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
+    float* kadd = aux + NK;
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
         if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
     }
     __syncthreads();
 
@@ -154,23 +169,24 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
     for (int qt = wave; qt < nqt; qt += WAVES) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
-        const int64_t qrow = qv ? tok_row(G, grp, nq) : 0;
+        const int64_t qrow = row_s[qv ? nq : 0];
         Frag8 qf[KS];
         load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
 
         float p[NKT][4];
-        const float* brow = (MODE == 1 && bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
+        // bias row of this query (row 0 for the pad queries: any valid address, the result is never stored);
+        // key offsets past the padded row are clamped (those keys are masked below) — no per-tile branch
+        const float* brow = (MODE == 1 && bias) ? bias + ((int64_t)h * N + (qv ? nq : 0)) * G.g.bias_ld : nullptr;
+        const int kmax = G.g.bias_ld - 4;
         const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
-        // issue every bias load of this query row up front: one L2 latency instead of NKT serial ones
-        constexpr bool PRE = NKT <= 16;
-        float4 bpre[PRE ? NKT : 1];
-        if (PRE) {
+        // bias loads run PD tiles ahead of their use (a rolling window of PD float4, not the whole row: the
+        // row in registers costs 56 VGPRs and an occupancy step); the compiler barrier below keeps hipcc from
+        // hoisting every load of the unrolled loop to the top again
+        constexpr int PD = NKT < 4 ? NKT : 4;
+        float4 bq[PD];
+        if (brow) {
 #pragma unroll
-            for (int t = 0; t < (PRE ? NKT : 1); ++t) {
-                const int key0 = t * 16 + lg * 4;
-                bpre[t] = (brow && key0 < G.g.bias_ld) ? *reinterpret_cast<const float4*>(brow + key0)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int t = 0; t < PD; ++t) bq[t] = *reinterpret_cast<const float4*>(brow + min(t * 16 + lg * 4, kmax));
         }
         float m = -INFINITY;
 #pragma unroll
@@ -182,35 +198,36 @@ __global__ void __launch_bounds__(THREADS) attn_fwd_kernel(
             for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
             const int key0 = t * 16 + lg * 4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PRE) bv = bpre[PRE ? t : 0];
-            else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
-            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (brow) {
+                bv = bq[t % PD];
+                asm volatile("" ::: "memory");
+                if (t + PD < NKT)
+                    bq[t % PD] = *reinterpret_cast<const float4*>(brow + min((t + PD) * 16 + lg * 4, kmax));
+            }
+            const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+            float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
             if (MODE == 1 && rid) {                                   // wave-uniform: shifted block, region-id mask
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
                 bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
                 bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
-            } else if (MODE == 0 && kmask) {
-                const float4 km = *reinterpret_cast<const float4*>(aux + key0);
-                bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
             }
-            const bool full = (t * 16 + 16) <= N;          // wave-uniform: every key of the tile is real
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = fmaf(acc[r], G.g.scale, bb[r]);
-                if (!full) s = (key0 + r < N) ? s : -INFINITY;
+                const float s = fmaf(acc[r], G.g.scale, bb[r]);
                 p[t][r] = s;
                 m = fmaxf(m, s);
             }
         }
         m = grp4_max(m);
+        const float nm2 = -m * LOG2E;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(p[t][r] - m);
+                const float e = exp_sub(p[t][r], nm2);
                 p[t][r] = e;
                 sum += e;
             }
@@ -277,13 +294,18 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
     const int N = G.g.N;
 
-    stage<HD, NK>(G, k, G.g.ldk, grp, h, Ks, tid);
-    stage<HD, NK>(G, v, G.g.ldv, grp, h, Vs, tid);
+    int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
+    token_rows<NK>(G, grp, row_s, tid);
+    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
+    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
     int* rid_s = reinterpret_cast<int*>(aux);
+    // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
+    // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
+    float* kadd = aux + NK;
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
         if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
     }
     __syncthreads();
 
@@ -292,7 +314,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     for (int qt = wave; qt < nqt; qt += WAVES) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
-        const int64_t qrow = qv ? tok_row(G, grp, nq) : 0;
+        const int64_t qrow = row_s[qv ? nq : 0];
         Frag8 qf[KS], dof[KS], of[KS];
         load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
         load_frags<HD>(dof, dout + qrow * G.g.ldo + h * HD, qv, lane);
@@ -307,17 +329,14 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         const unsigned rowid = (unsigned)li;
         const unsigned long long sd = DROP ? *seedp : 0ull;
         if (qv && lg == 0) dsum[li] = dsm;
-        const float L = qv ? lse[li] : 0.f;
-        const float* brow = (MODE == 1 && bias && qv) ? bias + ((int64_t)h * N + nq) * G.g.bias_ld : nullptr;
-        constexpr bool PRE = NKT <= 16;
-        float4 bpre[PRE ? NKT : 1];
-        if (PRE) {
+        const float nL2 = qv ? -lse[li] * LOG2E : 0.f;
+        const float* brow = (MODE == 1 && bias) ? bias + ((int64_t)h * N + (qv ? nq : 0)) * G.g.bias_ld : nullptr;
+        const int kmax = G.g.bias_ld - 4;
+        constexpr int PD = NKT < 4 ? NKT : 4;               // rolling bias prefetch, see attn_fwd_kernel
+        float4 bq[PD];
+        if (brow) {
 #pragma unroll
-            for (int t = 0; t < (PRE ? NKT : 1); ++t) {
-                const int key0 = t * 16 + lg * 4;
-                bpre[t] = (brow && key0 < G.g.bias_ld) ? *reinterpret_cast<const float4*>(brow + key0)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int t = 0; t < PD; ++t) bq[t] = *reinterpret_cast<const float4*>(brow + min(t * 16 + lg * 4, kmax));
         }
         bf16_t* dsrow = (MODE == 1 && ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
         const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
@@ -336,26 +355,25 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             }
             const int key0 = t * 16 + lg * 4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PRE) bv = bpre[PRE ? t : 0];
-            else if (brow && key0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(brow + key0);
-            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (brow) {
+                bv = bq[t % PD];
+                asm volatile("" ::: "memory");
+                if (t + PD < NKT)
+                    bq[t % PD] = *reinterpret_cast<const float4*>(brow + min((t + PD) * 16 + lg * 4, kmax));
+            }
+            const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+            float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
             if (MODE == 1 && rid) {
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
                 bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
                 bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
-            } else if (MODE == 0 && kmask) {
-                const float4 km = *reinterpret_cast<const float4*>(aux + key0);
-                bb[0] += km.x; bb[1] += km.y; bb[2] += km.z; bb[3] += km.w;
             }
-            const bool full = (t * 16 + 16) <= N;
             float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = fmaf(sacc[r], G.g.scale, bb[r]) - L;
-                float pr = __expf(s);
-                if (!full) pr = (key0 + r < N) ? pr : 0.f;
+                const float pr = exp_sub(fmaf(sacc[r], G.g.scale, bb[r]), nL2);    // pad keys: exp2(-inf) = 0
                 float dp = pacc[r];
                 if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
                 ds[r] = pr * (dp - dsm);
@@ -413,13 +431,15 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
     const int N = G.g.N;
 
-    stage<HD, NK>(G, q, G.g.ldq, grp, h, Qs, tid);
-    stage<HD, NK>(G, dout, G.g.ldo, grp, h, dOs, tid);
+    int* row_s = reinterpret_cast<int*>(aux + NK);
+    token_rows<NK>(G, grp, row_s, tid);
+    stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid);
+    stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
-        L_s[n] = (n < N) ? lse[li] : 0.f;
+        L_s[n] = (n < N) ? -lse[li] * LOG2E : -INFINITY;    // -L * log2e (exp_sub's form); pad queries: P = exp2(-inf) = 0
         D_s[n] = (n < N) ? dsum[li] : 0.f;
         if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
         else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
@@ -432,13 +452,14 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     for (int kt = wave; kt < nkt; kt += WAVES) {
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
-        const int64_t krow = kv ? tok_row(G, grp, nk) : 0;
+        const int64_t krow = row_s[kv ? nk : 0];
         Frag8 kf[KS], vf[KS];
         load_frags<HD>(kf, k + krow * G.g.ldk + h * HD, kv, lane);
         load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
         const int rk = (MODE == 1 && rid && kv) ? rid_s[nk] : 0;
         const float kmv = (MODE == 0 && kmask && kv) ? aux[nk] : 0.f;
-        const float* btrow = (MODE == 1 && biasT && kv) ? biasT + ((int64_t)h * N + nk) * G.g.bias_ld : nullptr;
+        const float* btrow = (MODE == 1 && biasT) ? biasT + ((int64_t)h * N + (kv ? nk : 0)) * G.g.bias_ld : nullptr;
+        const int qmax = G.g.bias_ld - 4;
 
         f32x4_t dvacc[NC], dkacc[NC];
 #pragma unroll
@@ -464,7 +485,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                 float pv[4], dsv[4];
                 const int qn0 = qt * 16 + lg * 4;
                 float4 bv = make_float4(kmv, kmv, kmv, kmv);
-                if (btrow && qn0 < G.g.bias_ld) bv = *reinterpret_cast<const float4*>(btrow + qn0);   // biasT[h][key][q..q+3]
+                if (btrow) bv = *reinterpret_cast<const float4*>(btrow + min(qn0, qmax));   // biasT[h][key][q..q+3]
                 float bb[4] = {bv.x, bv.y, bv.z, bv.w};
                 if (MODE == 1 && rid) {
                     const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
@@ -476,12 +497,11 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                 const float4 L4 = *reinterpret_cast<const float4*>(L_s + qn0);
                 const float4 D4 = *reinterpret_cast<const float4*>(D_s + qn0);
                 const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-                const bool full = (qt * 16 + 16) <= N;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = __expf(fmaf(sacc[r], G.g.scale, bb[r]) - Lr[r]);
-                    if (!full) pr = (qn0 + r < N) ? pr : 0.f;
-                    pr = kv ? pr : 0.f;
+                    // pad queries carry L = -inf (P = 0); pad-key lanes compute finite garbage in output columns
+                    // that are never stored, so neither needs a select here
+                    const float pr = exp_sub(fmaf(sacc[r], G.g.scale, bb[r]), Lr[r]);
                     float ks = 1.f;
                     if (DROP)
                         ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + qn0 + r), (unsigned)nk, G.drop_thresh,
@@ -574,11 +594,11 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
 constexpr size_t MAX_LDS = 160 * 1024;
 
 template <int HD, int NKT>
-size_t fwd_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (size_t)NKT * 16 * 4; }
+size_t fwd_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
 template <int HD, int NKT>
-size_t dq_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (size_t)NKT * 16 * 4; }
+size_t dq_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
 template <int HD, int NKT>
-size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
+size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4; }
 
 // Three compiled variants per (HD, NKT): window (bias/rid, no dropout), sequence, sequence + dropout.
 #define CLV_PICK(KERNEL, ...)                                                                          \

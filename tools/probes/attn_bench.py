@@ -3,7 +3,8 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
-from clover_amd import ops
+from clover_amd import ops, _lib
+if os.environ.get('PROBE_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['PROBE_LIB'])
 from clover_amd.backbones.swin_transformer_3d import window_geometry, gathered_bias, build_relative_position_index
 B, D, H, W, C, nH = 16, 4, 56, 56, 96, 3
 if len(sys.argv) > 1 and sys.argv[1] == 's2':
@@ -12,18 +13,24 @@ torch.manual_seed(0)
 qkv = torch.randn(B, D, H, W, 3 * C, device='cuda').to(torch.bfloat16).requires_grad_()
 table = (torch.randn(15 * 13 * 13, nH, device='cuda') * 0.5).requires_grad_()
 rpi = build_relative_position_index((8, 7, 7)).cuda()
-ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), (4, 3, 3), 'cuda')
+SHIFT = (0, 0, 0) if os.environ.get('PROBE_NOSHIFT') else (4, 3, 3)
+ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), SHIFT, 'cuda')
+if not any(SHIFT): rid = None
 do = torch.randn(B, D, H, W, C, device='cuda').to(torch.bfloat16)
 for it in range(5):
     bias = gathered_bias(table, rpi, 196)
     o = ops.window_attention(qkv, bias, rid, ws, ss, nH)
     o.backward(do)
 torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-bias = gathered_bias(table, rpi, 196).detach()
-s.record()
+filler = torch.randn(8192, 8192, device='cuda', dtype=torch.bfloat16)
+ops.PROF = {}
 for _ in range(10):
-    with torch.no_grad():
-        o = ops.window_attention(qkv.detach(), bias, rid, ws, ss, nH)
-e.record(); torch.cuda.synchronize()
-print('fwd us', s.elapsed_time(e) * 100)
+    for _ in range(10): torch.mm(filler, filler)          # keep the host ahead so kernels run back-to-back
+    bias = gathered_bias(table, rpi, 196) if not os.environ.get('PROBE_NOBIAS') else None
+    o = ops.window_attention(qkv, bias, rid, ws, ss, nH)
+    o.backward(do)
+torch.cuda.synchronize()
+prof, ops.PROF = ops.PROF, None
+for k, evs in prof.items():
+    ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+    print(f'{k:45s} {1e3 * sum(ms) / len(ms):8.1f} us')

@@ -13,6 +13,11 @@ for r in rows:
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     if runs and runs[-1][0] == key: runs[-1][1].append(d)
     else: runs.append((key, [d]))
+if '--agg' in sys.argv:                      # aggregate by (kernel, grid) instead of consecutive runs
+    agg = {}
+    for k, v in runs:
+        agg.setdefault(k, []).extend(v)
+    runs = list(agg.items())
 tot = 0
 for k, v in runs:
     if len(v) < 5: continue
