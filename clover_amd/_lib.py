@@ -19,7 +19,7 @@ class ClvAttnGeom(C.Structure):
     """Mirror of ``struct ClvAttnGeom`` (include/clover_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in
                 ('mode', 'groups', 'N', 'nH', 'hd', 'D', 'H', 'W', 'wd', 'wh', 'ww', 'sd', 'sh', 'sw',
-                 'ldq', 'ldk', 'ldv', 'ldo', 'bias_ld')] + [('scale', C.c_float), ('dropout_p', C.c_float)]
+                 'ldq', 'ldk', 'ldv', 'ldo', 'bwd', 'bwh', 'bww')] + [('scale', C.c_float), ('dropout_p', C.c_float)]
 
 
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -35,7 +35,8 @@ class ClvLnExtra(C.Structure):
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
-    'clv_attn_bwd': (C.c_int, [_p] * 17 + [_i32, C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_bwd_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),
     'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, C.POINTER(ClvLnExtra), _p]),

@@ -92,33 +92,11 @@ def window_geometry(x_size, cfg_ws, cfg_ss, device):
     return ws, ss, rid
 
 
-class _GatherBias(torch.autograd.Function):
-    """table[idx] -> [nH, N, Npad]; backward = index_add_ (atomics) of the kernel's dbias into the
-    2535-row table — torch's generic advanced-indexing backward sorts the 38 416 indices every call."""
-
-    @staticmethod
-    def forward(ctx, table, idx_flat, N):
-        nH = table.shape[1]
-        npad = (N + 15) // 16 * 16
-        b = table.float().index_select(0, idx_flat).view(N, N, nH).permute(2, 0, 1)
-        out = table.new_zeros((nH, N, npad), dtype=torch.float32)
-        out[:, :, :N] = b
-        ctx.save_for_backward(idx_flat)
-        ctx.meta = (table.shape, table.dtype, N)
-        return out
-
-    @staticmethod
-    def backward(ctx, dbias):
-        (idx_flat,) = ctx.saved_tensors
-        shape, dtype, N = ctx.meta
-        d = dbias[:, :, :N].permute(1, 2, 0).reshape(N * N, shape[1])
-        dtable = torch.zeros(shape, device=dbias.device, dtype=torch.float32).index_add_(0, idx_flat, d)
-        return dtable.to(dtype), None, None
-
-
 def gathered_bias(table, rel_index, N):
-    """table[index[:N,:N]] -> fp32 [nH, N, Npad] (Npad = N rounded up to 16), reference :382-384."""
-    return _GatherBias.apply(table, rel_index[:N, :N].reshape(-1).contiguous(), N)
+    """table[index[:N,:N]] -> fp32 [nH, N, N] (reference :382-384).  Not on the hot path any more — the attention
+    kernels read the table itself (LDS) — kept as the host-side statement of what they compute."""
+    nH = table.shape[1]
+    return table.float()[rel_index[:N, :N].reshape(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
 
 
 def mask_blend_weight(mask, T, H, W):
@@ -170,8 +148,8 @@ class WindowAttention3D(nn.Module):
         """x bf16 [B,Dp,Hp,Wp,C] (already LN'd and padded) -> same shape."""
         N = ws[0] * ws[1] * ws[2]
         qkv = self.qkv(x)
-        bias = gathered_bias(self.relative_position_bias_table, self.relative_position_index, N)
-        o = ops.window_attention(qkv, bias, rid if any(s > 0 for s in ss) else None, ws, ss, self.num_heads)
+        o = ops.window_attention(qkv, self.relative_position_bias_table, rid if any(s > 0 for s in ss) else None,
+                                 ws, ss, self.num_heads, table_window=self.window_size)
         return self.proj_drop(self.proj(o))
 
 
@@ -253,8 +231,8 @@ class SwinTransformerBlock3D(nn.Module):
         else:
             qkv, s0 = ops.ln_linear(branch, x, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
                                     self.norm1.eps)
-        bias = gathered_bias(at.relative_position_bias_table, at.relative_position_index, ws[0] * ws[1] * ws[2])
-        o = ops.window_attention(qkv, bias, rid if any(s > 0 for s in ss) else None, ws, ss, self.num_heads)
+        o = ops.window_attention(qkv, at.relative_position_bias_table, rid if any(s > 0 for s in ss) else None, ws, ss,
+                                 self.num_heads, table_window=at.window_size)
         a = self.drop_path(at.proj(o))
         m, s1 = ops.fused_mlp(a, s0, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
                               self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps)

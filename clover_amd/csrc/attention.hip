@@ -26,7 +26,26 @@ struct Geom {
     int nWh, nWw, nW;  // windows per axis / per clip (mode 1)
     unsigned drop_thresh;   // attention-probability dropout: P(drop) = drop_thresh / 2^32 (0 = off)
     float inv_keep;
+    // relative-position bias table (mode 1): bias[i][j] = table[h][lin(i) - lin(j) + tcst] with
+    // lin(n) = (n / (bwh*bww)) * ts_d + ((n / bww) % bwh) * ts_h + n % bww  — the reference's
+    // relative_position_index[:N,:N] of the window the table was built for (swin_transformer_3d.py:343-360,386)
+    int ts_d, ts_h, tcst, tlen, tls;     // tls: tlen rounded up to 4 (LDS / partial-table row stride)
 };
+
+__device__ __forceinline__ int win_lin(const Geom& G, int n) {
+    const int hw = G.g.bwh * G.g.bww;
+    const int tz = n / hw, tr = n - tz * hw;
+    const int ty = tr / G.g.bww, tx = tr - ty * G.g.bww;
+    return tz * G.ts_d + ty * G.ts_h + tx;
+}
+
+// Per-workgroup bias state in LDS (mode 1): the head's table and 4 * lin(n) per window token (byte offsets).
+template <int NK>
+__device__ __forceinline__ void load_bias_table(const Geom& G, const float* table, int h, float* tab_s, int* linb_s,
+                                                int tid, int nthreads) {
+    for (int i = tid; i < G.tlen; i += nthreads) tab_s[i] = table[(int64_t)i * G.g.nH + h];   // [tlen][nH] parameter layout
+    for (int n = tid; n < NK; n += nthreads) linb_s[n] = (n < G.g.N) ? 4 * win_lin(G, n) : 0;
+}
 
 // Counter-based dropout mask: a pure function of (seed, (group, head, query) row id, key), so the
 // backward kernels regenerate exactly the forward's mask.  Returns 1/(1-p) (kept) or 0 (dropped).
@@ -50,6 +69,17 @@ __device__ __forceinline__ int64_t tok_row(const Geom& G, int grp, int n) {
     int h = wy * G.g.wh + ty + G.g.sh; if (h >= G.g.H) h -= G.g.H;
     int w = wx * G.g.ww + tx + G.g.sw; if (w >= G.g.W) w -= G.g.W;
     return (((int64_t)b * G.g.D + d) * G.g.H + h) * G.g.W + w;
+}
+
+// bias of 4 consecutive keys for one query: tp = table + 4 * (lin(q) + tcst) bytes, kb = 4 * lin(key..key+3)
+__device__ __forceinline__ float4 table_bias4(const char* tp, const int* kb_ptr) {
+    const int4 kb = *reinterpret_cast<const int4*>(kb_ptr);
+    float4 b;
+    b.x = *reinterpret_cast<const float*>(tp - kb.x);
+    b.y = *reinterpret_cast<const float*>(tp - kb.y);
+    b.z = *reinterpret_cast<const float*>(tp - kb.z);
+    b.w = *reinterpret_cast<const float*>(tp - kb.w);
+    return b;
 }
 
 // XCD-aware remap: consecutive logical ids (the heads of one window) share an XCD/L2.
@@ -121,16 +151,6 @@ __device__ __forceinline__ uint2 tr4(const bf16_t* base, int LD, int row0, int c
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float exp_sub(float x, float negL2) { return __builtin_amdgcn_exp2f(fmaf(x, LOG2E, negL2)); }
 
-// score epilogue for one Sᵀ tile element
-struct ScoreCtx {
-    const float* bias_row;   // bias + (h*N + q)*bias_ld or nullptr
-    const int* rid_s;        // LDS region ids or nullptr
-    const float* km_s;       // LDS additive key mask or nullptr
-    int rid_q;
-    float scale;
-    int N, bias_ld;
-};
-
 // ------------------------------------------------------------------------- forward
 template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
@@ -150,9 +170,12 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
     const int N = G.g.N;
 
     int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
+    int* linb_s = row_s + NK;                                // mode 1 + bias: 4 * lin(n)
+    float* tab_s = reinterpret_cast<float*>(linb_s + NK);    //                the head's bias table
     token_rows<NK>(G, grp, row_s, tid);
     stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
+    if (MODE == 1 && bias) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
     int* rid_s = reinterpret_cast<int*>(aux);
     // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
     // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
@@ -174,20 +197,12 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
         load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
 
         float p[NKT][4];
-        // bias row of this query (row 0 for the pad queries: any valid address, the result is never stored);
-        // key offsets past the padded row are clamped (those keys are masked below) — no per-tile branch
-        const float* brow = (MODE == 1 && bias) ? bias + ((int64_t)h * N + (qv ? nq : 0)) * G.g.bias_ld : nullptr;
-        const int kmax = G.g.bias_ld - 4;
+        // relative-position bias from the LDS table: byte offset = 4 * (lin(q) + tcst) - 4 * lin(key)
+        const bool tb = MODE == 1 && bias != nullptr;
+        const char* tp = reinterpret_cast<const char*>(tab_s) + (tb ? linb_s[qv ? nq : 0] + 4 * G.tcst : 0);
         const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
-        // bias loads run PD tiles ahead of their use (a rolling window of PD float4, not the whole row: the
-        // row in registers costs 56 VGPRs and an occupancy step); the compiler barrier below keeps hipcc from
-        // hoisting every load of the unrolled loop to the top again
-        constexpr int PD = NKT < 4 ? NKT : 4;
-        float4 bq[PD];
-        if (brow) {
-#pragma unroll
-            for (int t = 0; t < PD; ++t) bq[t] = *reinterpret_cast<const float4*>(brow + min(t * 16 + lg * 4, kmax));
-        }
+        float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -197,13 +212,9 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
             const int key0 = t * 16 + lg * 4;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (brow) {
-                bv = bq[t % PD];
-                asm volatile("" ::: "memory");
-                if (t + PD < NKT)
-                    bq[t % PD] = *reinterpret_cast<const float4*>(brow + min((t + PD) * 16 + lg * 4, kmax));
-            }
+            asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
+            const float4 bv = bnext;
+            if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
             const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
             float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
             if (MODE == 1 && rid) {                                   // wave-uniform: shifted block, region-id mask
@@ -275,7 +286,9 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
     }
 }
 
-// ------------------------------------------------------------------------- backward A: dQ, dbias, D
+// ------------------------------------------------------------------------- backward A: dQ, dS scratch, D
+// Window mode also writes dS (bf16) of every (window, head) to a scratch; dbias_table_kernel sums it over the
+// windows and scatters the sums into the table gradient.
 template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -288,20 +301,22 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NK * LDR;
     float* aux = reinterpret_cast<float*>(Vs + NK * LDR);
+    int* rid_s = reinterpret_cast<int*>(aux);
+    float* kadd = aux + NK;                                  // see attn_fwd_kernel
+    int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
+    int* linb_s = row_s + NK;
+    float* tab_s = reinterpret_cast<float*>(linb_s + NK);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
     const int N = G.g.N;
+    const bool tb = MODE == 1 && bias != nullptr;
 
-    int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
     token_rows<NK>(G, grp, row_s, tid);
     stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
-    int* rid_s = reinterpret_cast<int*>(aux);
-    // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
-    // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
-    float* kadd = aux + NK;
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
         if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
@@ -311,6 +326,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
 
     const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
+    const unsigned long long sd = DROP ? *seedp : 0ull;
     for (int qt = wave; qt < nqt; qt += WAVES) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
@@ -327,23 +343,23 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
         dsm = grp4_sum(dsm);
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + nq;
         const unsigned rowid = (unsigned)li;
-        const unsigned long long sd = DROP ? *seedp : 0ull;
         if (qv && lg == 0) dsum[li] = dsm;
         const float nL2 = qv ? -lse[li] * LOG2E : 0.f;
-        const float* brow = (MODE == 1 && bias) ? bias + ((int64_t)h * N + (qv ? nq : 0)) * G.g.bias_ld : nullptr;
-        const int kmax = G.g.bias_ld - 4;
-        constexpr int PD = NKT < 4 ? NKT : 4;               // rolling bias prefetch, see attn_fwd_kernel
-        float4 bq[PD];
-        if (brow) {
-#pragma unroll
-            for (int t = 0; t < PD; ++t) bq[t] = *reinterpret_cast<const float4*>(brow + min(t * 16 + lg * 4, kmax));
-        }
-        bf16_t* dsrow = (MODE == 1 && ds_out && qv) ? ds_out + (((int64_t)grp * G.g.nH + h) * N + nq) * G.g.bias_ld : nullptr;
+        const char* tp = reinterpret_cast<const char*>(tab_s) + (tb ? linb_s[qv ? nq : 0] + 4 * G.tcst : 0);
         const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
+        // dS scratch in MFMA-fragment order [group][head][q tile][key tile][lane][4]: every store instruction of a
+        // wave is one contiguous 512-B run (row-major rows would be 32-B pieces of 128-B lines)
+        bf16_t* dsfrag = (tb && ds_out)
+            ? ds_out + ((((int64_t)grp * G.g.nH + h) * nqt + qt) * NKT * 64 + lane) * 4 : nullptr;
 
         Frag8 dsf[NKT / 2];
+        float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
+            asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
+            const float4 bv = bnext;
+            if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
             f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
             Frag8 kf[KS], vf[KS];
             lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
@@ -354,13 +370,6 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
                 pacc = mfma16(vf[s], dof[s], pacc);
             }
             const int key0 = t * 16 + lg * 4;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (brow) {
-                bv = bq[t % PD];
-                asm volatile("" ::: "memory");
-                if (t + PD < NKT)
-                    bq[t % PD] = *reinterpret_cast<const float4*>(brow + min((t + PD) * 16 + lg * 4, kmax));
-            }
             const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
             float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
             if (MODE == 1 && rid) {
@@ -380,10 +389,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
             dsf[t >> 1].u[(t & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
-            // per-(window, head) dS goes to a bf16 scratch; dbias = sum over windows is a separate
-            // streaming reduction (dbias_reduce_kernel) instead of N*N atomics per block
-            if (dsrow && key0 < G.g.bias_ld)
-                *reinterpret_cast<uint2*>(dsrow + key0) =
+            if (dsfrag)
+                *reinterpret_cast<uint2*>(dsfrag + t * 256) =
                     make_uint2(dsf[t >> 1].u[(t & 1) * 2 + 0], dsf[t >> 1].u[(t & 1) * 2 + 1]);
         }
         f32x4_t qacc[NC];
@@ -416,7 +423,7 @@ template <int HD, int NKT, bool DROP, int MODE>
 __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
-    const float* __restrict__ biasT, const int* __restrict__ rid, const float* __restrict__ kmask,
+    const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, const unsigned long long* __restrict__ seedp, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -432,9 +439,13 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const int N = G.g.N;
 
     int* row_s = reinterpret_cast<int*>(aux + NK);
+    int* linb_s = row_s + NK;
+    float* tab_s = reinterpret_cast<float*>(linb_s + NK);
+    const bool tb = MODE == 1 && bias != nullptr;
     token_rows<NK>(G, grp, row_s, tid);
     stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid);
     stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid);
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     for (int n = tid; n < NK; n += THREADS) {
@@ -458,8 +469,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
         load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
         const int rk = (MODE == 1 && rid && kv) ? rid_s[nk] : 0;
         const float kmv = (MODE == 0 && kmask && kv) ? aux[nk] : 0.f;
-        const float* btrow = (MODE == 1 && biasT) ? biasT + ((int64_t)h * N + (kv ? nk : 0)) * G.g.bias_ld : nullptr;
-        const int qmax = G.g.bias_ld - 4;
+        const int ko = tb ? linb_s[kv ? nk : 0] - 4 * G.tcst : 0;     // slot(q, key) = lin(q) - (lin(key) - tcst)
 
         f32x4_t dvacc[NC], dkacc[NC];
 #pragma unroll
@@ -485,7 +495,14 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
                 float pv[4], dsv[4];
                 const int qn0 = qt * 16 + lg * 4;
                 float4 bv = make_float4(kmv, kmv, kmv, kmv);
-                if (btrow) bv = *reinterpret_cast<const float4*>(btrow + min(qn0, qmax));   // biasT[h][key][q..q+3]
+                if (tb) {
+                    const int4 qb = *reinterpret_cast<const int4*>(linb_s + qn0);
+                    const char* tp = reinterpret_cast<const char*>(tab_s) - ko;
+                    bv.x = *reinterpret_cast<const float*>(tp + qb.x);
+                    bv.y = *reinterpret_cast<const float*>(tp + qb.y);
+                    bv.z = *reinterpret_cast<const float*>(tp + qb.z);
+                    bv.w = *reinterpret_cast<const float*>(tp + qb.w);
+                }
                 float bb[4] = {bv.x, bv.y, bv.z, bv.w};
                 if (MODE == 1 && rid) {
                     const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
@@ -542,22 +559,32 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     }
 }
 
-// dbias[e] += sum_g ds[g][e]   (e over nH*N*bias_ld, 8 elements per thread, groups split over y)
-__global__ void __launch_bounds__(256) dbias_reduce_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dbias,
-                                                           int64_t E8, int groups) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= E8) return;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+// d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key].  The scratch is in the dQ kernel's fragment
+// order [group][head][q tile][key tile][lane][4]; one thread owns one (head, q tile, key tile, lane) = 4 scores, the
+// group loop is split over blockIdx.y; global atomics into the 2535-row table (a few per address).
+__global__ void __launch_bounds__(256) dbias_table_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dtable,
+                                                          int groups, int nkt, Geom G) {
+    const int nqt = (G.g.N + 15) >> 4;
+    const int64_t per_head = (int64_t)nqt * nkt * 64;
+    const int64_t E = (int64_t)G.g.nH * per_head;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int lane = (int)(e & 63);
+    const int t = (int)((e >> 6) % nkt), qt = (int)((e >> 6) / nkt % nqt), h = (int)(e / per_head);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int g = blockIdx.y; g < groups; g += gridDim.y) {
-        Frag8 v;
-        v.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)g * E8 + c) * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v.h[e]);
+        const uint2 v = *reinterpret_cast<const uint2*>(ds + ((int64_t)g * E + e) * 4);
+        acc[0] += bf2f((bf16_t)(v.x & 0xffff));
+        acc[1] += bf2f((bf16_t)(v.x >> 16));
+        acc[2] += bf2f((bf16_t)(v.y & 0xffff));
+        acc[3] += bf2f((bf16_t)(v.y >> 16));
     }
+    const int qn = qt * 16 + (lane & 15), key0 = t * 16 + (lane >> 4) * 4;
+    if (qn >= G.g.N) return;
+    const int lq = win_lin(G, qn) + G.tcst;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dbias + c * 8 + e, acc[e]);
+    for (int r = 0; r < 4; ++r)
+        if (key0 + r < G.g.N) atomicAdd(dtable + (int64_t)(lq - win_lin(G, key0 + r)) * G.g.nH + h, acc[r]);
 }
 
 // ------------------------------------------------------------------------- host side
@@ -575,7 +602,7 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (g->N <= 0 || g->nH <= 0 || g->groups <= 0) return false;
     if (g->hd != 16 && g->hd != 32 && g->hd != 64) return false;
     if ((g->ldq | g->ldk | g->ldv | g->ldo) & 7) return false;   // 16-byte row alignment
-    if (g->bias_ld & 15) return false;
+    G.ts_d = G.ts_h = G.tcst = G.tlen = G.tls = 0;
     if (g->mode == 1) {
         if (g->wd <= 0 || g->wh <= 0 || g->ww <= 0) return false;
         if (g->D % g->wd || g->H % g->wh || g->W % g->ww) return false;
@@ -585,6 +612,16 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
         G.nW = (g->D / g->wd) * G.nWh * G.nWw;
         if (g->groups % G.nW) return false;
         if (g->sd < 0 || g->sd >= g->D || g->sh < 0 || g->sh >= g->H || g->sw < 0 || g->sw >= g->W) return false;
+        if (g->bwd || g->bwh || g->bww) {                    // relative-position table of window (bwd, bwh, bww)
+            if (g->bwd <= 0 || g->bwh <= 0 || g->bww <= 0) return false;
+            G.ts_h = 2 * g->bww - 1;
+            G.ts_d = (2 * g->bwh - 1) * G.ts_h;
+            G.tcst = (g->bwd - 1) * G.ts_d + (g->bwh - 1) * G.ts_h + (g->bww - 1);
+            G.tlen = (2 * g->bwd - 1) * G.ts_d;
+            G.tls = (G.tlen + 3) / 4 * 4;
+            // every token id n < N, decomposed by the TABLE's window, must stay inside that window
+            if (g->N > g->bwd * g->bwh * g->bww) return false;
+        }
     } else if (g->mode != 0) {
         return false;
     }
@@ -594,11 +631,11 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
 constexpr size_t MAX_LDS = 160 * 1024;
 
 template <int HD, int NKT>
-size_t fwd_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
+size_t fwd_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
 template <int HD, int NKT>
-size_t dq_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 3 * (size_t)NKT * 16 * 4; }
+size_t dq_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
 template <int HD, int NKT>
-size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4; }
+size_t dkv_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
 
 // Three compiled variants per (HD, NKT): window (bias/rid, no dropout), sequence, sequence + dropout.
 #define CLV_PICK(KERNEL, ...)                                                                          \
@@ -608,31 +645,34 @@ size_t dkv_lds() { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NK
         else { KERNEL<HD, NKT, false, 0> __VA_ARGS__; }                                                \
     } while (0)
 
+// dynamic LDS above 64 KB must be opted into per kernel; the request varies with the table length, so opt in to
+// the whole 160 KB once and pass the actual size at launch
 template <int HD, int NKT>
-void set_attrs(size_t lds_f, size_t lds_a, size_t lds_b) {
+void set_attrs() {
     static bool done = false;
     if (done) return;
     done = true;
-#define CLV_ATTR(K, BYTES) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
-    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 1>), lds_f);
-    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 0>), lds_f);
-    CLV_ATTR((attn_fwd_kernel<HD, NKT, true, 0>), lds_f);
-    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 1>), lds_a);
-    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 0>), lds_a);
-    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, true, 0>), lds_a);
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 1>), lds_b);
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 0>), lds_b);
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, true, 0>), lds_b);
+#define CLV_ATTR(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS)
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 1>));
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, false, 0>));
+    CLV_ATTR((attn_fwd_kernel<HD, NKT, true, 0>));
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 1>));
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 0>));
+    CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, true, 0>));
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 1>));
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 0>));
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, true, 0>));
 #undef CLV_ATTR
 }
 
 template <int HD, int NKT>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
                const int32_t* rid, const float* kmask, const unsigned long long* seed, const Geom& G, hipStream_t st) {
-    const size_t lds = fwd_lds<HD, NKT>();
-    if (lds > MAX_LDS || dq_lds<HD, NKT>() > MAX_LDS || dkv_lds<HD, NKT>() > MAX_LDS) return CLV_ERR_UNSUPPORTED;
+    const int bl = bias ? G.tls : 0;
+    const size_t lds = fwd_lds<HD, NKT>(bl);
+    if (lds > MAX_LDS || dq_lds<HD, NKT>(bl) > MAX_LDS || dkv_lds<HD, NKT>(bl) > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
-    set_attrs<HD, NKT>(lds, dq_lds<HD, NKT>(), dkv_lds<HD, NKT>());
+    set_attrs<HD, NKT>();
     const int nblk = G.g.groups * G.g.nH;
     CLV_PICK(attn_fwd_kernel, <<<dim3(nblk), dim3(THREADS), lds, st>>>((const bf16_t*)q, (const bf16_t*)k,
              (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G));
@@ -641,37 +681,37 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-               const float* lse, const float* bias, const float* biasT, const int32_t* rid, const float* kmask, void* dq,
-               void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch, const unsigned long long* seed, int stages,
+               const float* lse, const float* bias, const int32_t* rid, const float* kmask, void* dq,
+               void* dk, void* dv, float* dbias, float* dsum, void* work, const unsigned long long* seed, int stages,
                const Geom& G, hipStream_t st) {
-    const size_t lds_a = dq_lds<HD, NKT>(), lds_b = dkv_lds<HD, NKT>();
+    const int bl = bias ? G.tls : 0;
+    const size_t lds_a = dq_lds<HD, NKT>(bl), lds_b = dkv_lds<HD, NKT>(bl);
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
-    set_attrs<HD, NKT>(fwd_lds<HD, NKT>(), lds_a, lds_b);
+    set_attrs<HD, NKT>();
     const int nblk = G.g.groups * G.g.nH;
-    bf16_t* dsp = (bf16_t*)(bias ? ds_scratch : nullptr);
     int rc = CLV_OK;
     if (stages & 1) {
         CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
-                 (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq, dsp, dsum,
-                 seed, G));
+                 (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq,
+                 (bf16_t*)(bias ? work : nullptr), dsum, seed, G));
         rc = clv_check_launch();
         if (rc) return rc;
     }
     if (bias && (stages & 2)) {
-        const int64_t E8 = (int64_t)G.g.nH * G.g.N * G.g.bias_ld / 8;
-        const int xb = (int)((E8 + 255) / 256);
+        const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
+        const int xb = (int)((E + 255) / 256);
         int splits = 1024 / (xb > 0 ? xb : 1);
         if (splits < 1) splits = 1;
         if (splits > G.g.groups) splits = G.g.groups;
-        hipLaunchKernelGGL(dbias_reduce_kernel, dim3(xb, splits), dim3(256), 0, st, (const bf16_t*)ds_scratch, dbias,
-                           E8, G.g.groups);
+        hipLaunchKernelGGL(dbias_table_kernel, dim3(xb, splits), dim3(256), 0, st, (const bf16_t*)work, dbias,
+                           G.g.groups, NKT, G);
         rc = clv_check_launch();
         if (rc) return rc;
     }
     if (stages & 4) {
         CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(THREADS), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
-                 (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, biasT, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
+                 (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
         rc = clv_check_launch();
     }
     return rc;
@@ -704,7 +744,7 @@ extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o
     if (!q || !k || !v || !o || !lse || !make_geom(geom, G)) return CLV_ERR_ARG;
     if (G.drop_thresh && !seed) return CLV_ERR_ARG;
     const unsigned long long* sp = (const unsigned long long*)seed;
-    if (bias && G.g.bias_ld < ((G.g.N + 15) / 16) * 16) return CLV_ERR_ARG;
+    if (bias && (G.g.mode != 1 || G.tlen == 0)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
@@ -713,21 +753,28 @@ extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o
     DISPATCH_NKT(64, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st)
 }
 
+extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0) return 0;
+    const int nkt = pick_nkt(G.g.N);
+    if (nkt < 0) return 0;
+    return (int64_t)G.g.groups * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 2;      // bf16 dS, 16 x 16 fragments
+}
+
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                            const float* lse, const float* bias, const float* biasT, const int32_t* rid,
-                            const float* kmask,
-                            void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
+                            const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                            void* dq, void* dk, void* dv, float* dbias, float* dsum, void* work,
                             const void* seed, int32_t stages, const ClvAttnGeom* geom, void* stream) {
     Geom G;
     const unsigned long long* sp = (const unsigned long long*)seed;
     if (stages == 0) stages = 7;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !dsum || !make_geom(geom, G)) return CLV_ERR_ARG;
-    if (bias && (G.g.bias_ld < ((G.g.N + 15) / 16) * 16 || !dbias || !ds_scratch || !biasT)) return CLV_ERR_ARG;
+    if (bias && (G.g.mode != 1 || G.tlen == 0 || !dbias || !work)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     if (G.drop_thresh && !seed) return CLV_ERR_ARG;
     const int nkt = pick_nkt(G.g.N);
     hipStream_t st = (hipStream_t)stream;
-    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st) }
-    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st) }
-    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, biasT, rid, kmask, dq, dk, dv, dbias, dsum, ds_scratch, sp, stages, G, st)
+    if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st) }
+    if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st) }
+    DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st)
 }

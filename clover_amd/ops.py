@@ -564,10 +564,12 @@ def gelu(x):
 
 # --------------------------------------------------------------------------- attention
 class _Attention(torch.autograd.Function):
-    """qkv: bf16 [..tokens.., 3*nH*hd] with q|k|v packed along the last dim."""
+    """qkv: bf16 [..tokens.., 3*nH*hd] with q|k|v packed along the last dim.  table (window mode): the module's
+    relative_position_bias_table fp32 [rows, nH], read into LDS by the kernels; its gradient (the per-window dS summed over the
+    windows and scattered to the table rows) goes straight into the engine's gradient slab when the parameter is engine-managed."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, rid, kmask, geom_kw, seed):
+    def forward(ctx, qkv, table, rid, kmask, geom_kw, seed):
         _need_gpu(qkv)
         assert qkv.dtype == BF16 and qkv.is_contiguous()
         g = ClvAttnGeom(**geom_kw)
@@ -576,39 +578,44 @@ class _Attention(torch.autograd.Function):
         assert qkv.shape[-1] == 3 * Cdim
         g.ldq = g.ldk = g.ldv = 3 * Cdim
         g.ldo = Cdim
-        g.bias_ld = bias.shape[-1] if bias is not None else 0
+        tab = None
+        if table is not None:
+            assert table.shape == ((2 * g.bwd - 1) * (2 * g.bwh - 1) * (2 * g.bww - 1), g.nH), table.shape
+            tab = _c(table.detach().float())
         o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=BF16)
         lse = torch.empty(g.groups * g.nH * g.N, device=qkv.device, dtype=torch.float32)
         base = qkv.data_ptr()
         with _Timed(_kname('attn_fwd_kernel', g), *_attn_work(g, False)):
             check(_lib.lib().clv_attn_fwd(C.c_void_p(base), C.c_void_p(base + 2 * Cdim),
-                                          C.c_void_p(base + 4 * Cdim), _ptr(o), _ptr(lse), _ptr(bias), _ptr(rid),
+                                          C.c_void_p(base + 4 * Cdim), _ptr(o), _ptr(lse), _ptr(tab), _ptr(rid),
                                           _ptr(kmask), _ptr(seed), C.byref(g), _stream()), 'clv_attn_fwd')
-        ctx.save_for_backward(qkv, o, lse, bias, rid, kmask, seed)
+        ctx.save_for_backward(qkv, o, lse, tab, rid, kmask, seed)
         ctx.geom = g
+        ctx.tref = table
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, bias, rid, kmask, seed = ctx.saved_tensors
+        qkv, o, lse, tab, rid, kmask, seed = ctx.saved_tensors
         g = ctx.geom
         Cdim = g.nH * g.hd
         doc = _c(do)
         if doc.dtype != BF16:
             doc = doc.to(BF16)
         dqkv = torch.empty_like(qkv)
-        dbias = torch.zeros_like(bias) if bias is not None else None
         dsum = torch.empty_like(lse)
-        ds_scratch = biasT = None
-        if bias is not None:
-            ds_scratch = torch.empty(g.groups * g.nH * g.N * g.bias_ld, device=qkv.device, dtype=BF16)
-            biasT = torch.zeros_like(bias)                 # [nH][key][query], same row stride
-            biasT[:, :, :g.N] = bias[:, :, :g.N].transpose(1, 2)
+        L = _lib.lib()
+        dtab = work = sink = None
+        if tab is not None:
+            sink = getattr(ctx.tref, '_clv_grad', None)
+            if sink is not None and (sink.dtype != torch.float32 or not sink.is_contiguous()):
+                sink = None
+            dtab = sink if sink is not None else torch.zeros_like(tab)
+            work = torch.empty(L.clv_attn_bwd_work_bytes(C.byref(g)), device=qkv.device, dtype=torch.uint8)
         b, d = qkv.data_ptr(), dqkv.data_ptr()
         args = (C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim), _ptr(o), _ptr(doc), _ptr(lse),
-                _ptr(bias), _ptr(biasT), _ptr(rid), _ptr(kmask), C.c_void_p(d), C.c_void_p(d + 2 * Cdim),
-                C.c_void_p(d + 4 * Cdim), _ptr(dbias), _ptr(dsum), _ptr(ds_scratch), _ptr(seed))
-        L = _lib.lib()
+                _ptr(tab), _ptr(rid), _ptr(kmask), C.c_void_p(d), C.c_void_p(d + 2 * Cdim),
+                C.c_void_p(d + 4 * Cdim), _ptr(dtab), _ptr(dsum), _ptr(work), _ptr(seed))
         if PROF is None:
             check(L.clv_attn_bwd(*args, 0, C.byref(g), _stream()), 'clv_attn_bwd')
         else:                                  # one event pair per device kernel (work split 2:3 of the 5 matmuls)
@@ -618,14 +625,21 @@ class _Attention(torch.autograd.Function):
             check(L.clv_attn_bwd(*args, 2, C.byref(g), _stream()), 'clv_attn_bwd')
             with _Timed(_kname('attn_bwd_dkv_kernel', g), fl * 0.6, by * 0.5):
                 check(L.clv_attn_bwd(*args, 4, C.byref(g), _stream()), 'clv_attn_bwd')
-        return dqkv, dbias, None, None, None, None
+        if sink is not None:
+            ctx.tref._clv_ready()
+            dtab = None
+        elif dtab is not None:
+            dtab = dtab.to(ctx.tref.dtype)
+        return dqkv, dtab, None, None, None, None
 
 
-def window_attention(qkv, bias, rid, window, shift, num_heads):
+def window_attention(qkv, table, rid, window, shift, num_heads, table_window=None):
     """3-D shifted-window MHA on the natural token layout.
 
-    qkv bf16 [B,D,H,W,3C]; bias fp32 [nH,N,Npad] (Npad multiple of 16) — the gathered
-    relative-position bias; rid int32 [nW,N] region ids (None = no shift mask).
+    qkv bf16 [B,D,H,W,3C]; table fp32 [rows, nH] = the module's relative_position_bias_table built for
+    `table_window` (default: `window`; pass the configured full window when `window` is a clipped one — the
+    reference then uses relative_position_index[:N,:N] of the full window, swin_transformer_3d.py:386);
+    rid int32 [nW,N] region ids (None = no shift mask).
     Returns o bf16 [B,D,H,W,C] already window-reversed and un-rolled.
     """
     B, D, H, W, C3 = qkv.shape
@@ -633,9 +647,11 @@ def window_attention(qkv, bias, rid, window, shift, num_heads):
     hd = Cdim // num_heads
     N = window[0] * window[1] * window[2]
     nW = (D // window[0]) * (H // window[1]) * (W // window[2])
+    tw = tuple(table_window or window) if table is not None else (0, 0, 0)
     kw = dict(mode=1, groups=B * nW, N=N, nH=num_heads, hd=hd, D=D, H=H, W=W, wd=window[0], wh=window[1],
-              ww=window[2], sd=shift[0], sh=shift[1], sw=shift[2], scale=float(hd) ** -0.5)
-    return _Attention.apply(qkv, bias, rid, None, kw, None)
+              ww=window[2], sd=shift[0], sh=shift[1], sw=shift[2], bwd=tw[0], bwh=tw[1], bww=tw[2],
+              scale=float(hd) ** -0.5)
+    return _Attention.apply(qkv, table, rid, None, kw, None)
 
 
 _DROPOUT_COUNTER = {}

@@ -40,7 +40,15 @@ int clv_abi_version(void);
  *   mode 0: full self-attention over [video ‖ text] / text with an additive key
  *           mask — transformers 4.6.1 BertSelfAttention as called from
  *           bert_from_hugface.py:30 and cross_transformer.py:109-110.
- * softmax( q·kᵀ·scale + bias[h] + (rid[i]!=rid[j] ? -100 : 0) + kmask[b][j] ) · v
+ * softmax( q·kᵀ·scale + bias[h][i][j] + (rid[i]!=rid[j] ? -100 : 0) + kmask[b][j] ) · v
+ *
+ * Relative-position bias (mode 1): the kernels take the TABLE, not a gathered [nH][N][N] tensor:
+ *   bias[h][i][j] = table[ lin(i) - lin(j) + c ][h],   lin(n) = (n / (bwh*bww)) * (2bwh-1)(2bww-1)
+ *                                                              + ((n / bww) % bwh) * (2bww-1) + n % bww
+ * which is relative_position_bias_table[relative_position_index[:N,:N]] of :343-360,386 for the window
+ * (bwd,bwh,bww) the table was built for (the module's full window_size; N may be a clipped window's
+ * token count).  The head's table lives in LDS (2535 entries for (8,7,7)); the backward sums the per-window dS
+ * over the windows and scatters the sums into d table — no gathered [nH][N][N] bias or bias gradient exists.
  */
 typedef struct ClvAttnGeom {
     int32_t mode;           /* 0 sequence, 1 shifted 3-D window */
@@ -52,32 +60,30 @@ typedef struct ClvAttnGeom {
     int32_t wd, wh, ww;     /* mode 1: effective window (get_window_size, :302-315) */
     int32_t sd, sh, sw;     /* mode 1: effective shift */
     int32_t ldq, ldk, ldv, ldo; /* row strides (elements) of q,k,v and o/do/dq.. */
-    int32_t bias_ld;        /* row stride of bias/dbias [nH][N][bias_ld] (multiple of 16), 0 = none */
+    int32_t bwd, bwh, bww;  /* window the bias table was built for: the table has (2bwd-1)(2bwh-1)(2bww-1) rows; 0,0,0 = none */
     float scale;            /* head_dim^-0.5 */
     float dropout_p;        /* dropout on the attention probabilities (HF attention_probs_dropout_prob), 0 = off */
 } ClvAttnGeom;
 
-/* lse: float [groups][nH][N].  bias: float or NULL.  rid: int32 [nW][N] region ids of
- * compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL.
+/* lse: float [groups][nH][N].  bias: the module's relative_position_bias_table, float [rows][nH], or NULL.  rid: int32 [nW][N] region
+ * ids of compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL.
  * seed: device uint64[1], read when dropout_p > 0; the mask is a counter-based hash of
  * (seed, group, head, query, key), so the backward regenerates it from the same seed. */
 int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const float* bias, const int32_t* rid, const float* kmask, const void* seed,
                  const ClvAttnGeom* geom_host, void* stream);
 
-/* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float, same shape as bias)
+/* dq/dk/dv use strides ldq/ldk/ldv; dout uses ldo.  dbias (float [rows][nH], the gradient of the table)
  * is ACCUMULATED into (caller zeroes).  dsum: float scratch [groups][nH][N].
- * ds_scratch: bf16 scratch [groups][nH][N][bias_ld] (per-window dS, reduced over windows
- * into dbias by a streaming kernel); biasT: the same bias with query/key swapped,
- * biasT[h][key][query] (row stride bias_ld) — the dK/dV kernel walks scores key-major; both
- * required iff bias != NULL. */
+ * work: scratch of clv_attn_bwd_work_bytes() bytes (the bf16 dS of every (group, head), summed over the groups
+ * and scattered into dbias by a second kernel), required iff bias != NULL. */
+int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom_host);
 int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                 const float* lse, const float* bias, const float* biasT, const int32_t* rid,
-                 const float* kmask,
-                 void* dq, void* dk, void* dv, float* dbias, float* dsum, void* ds_scratch,
+                 const float* lse, const float* bias, const int32_t* rid, const float* kmask,
+                 void* dq, void* dk, void* dv, float* dbias, float* dsum, void* work,
                  const void* seed, int32_t stages, const ClvAttnGeom* geom_host, void* stream);
-/* stages: 0 = everything; otherwise a bit mask 1 = dQ (+dS scratch, dsum) kernel, 2 = dbias reduction,
- * 4 = dK/dV kernel — lets a profiler bracket each kernel of the call with its own events. */
+/* stages: 0 = everything; otherwise a bit mask 1 = dQ (+ dS scratch, dsum) kernel, 2 = dS -> table-gradient
+ * reduction, 4 = dK/dV kernel — lets a profiler bracket each kernel of the call with its own events. */
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm over the last dim (every norm site: swin_transformer_3d.py:450,483,

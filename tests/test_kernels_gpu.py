@@ -121,7 +121,7 @@ WIN_CASES = [
 
 @pytest.mark.parametrize('case', WIN_CASES)
 def test_window_attention(case):
-    from clover_amd.backbones.swin_transformer_3d import window_geometry, gathered_bias
+    from clover_amd.backbones.swin_transformer_3d import window_geometry
     B, D, H, W, C, nH, shifted = case
     cfg_ws, cfg_ss = (8, 7, 7), ((4, 3, 3) if shifted else (0, 0, 0))
     qkv = rnd(B, D, H, W, 3 * C, seed=11).to(BF)
@@ -136,9 +136,7 @@ def test_window_attention(case):
     ws, ss, rid = window_geometry((D, H, W), cfg_ws, cfg_ss, DEV)
     qg = qkv.to(DEV).requires_grad_()
     tg = table.to(DEV).requires_grad_()
-    rpi_t = torch.from_numpy(rpi).to(DEV)
-    bias = gathered_bias(tg, rpi_t, ws[0] * ws[1] * ws[2])
-    o = ops().window_attention(qg, bias, rid, ws, ss, nH)
+    o = ops().window_attention(qg, tg, rid, ws, ss, nH, table_window=cfg_ws)
     o.backward(do.to(DEV))
     assert rel(o, o_ref) < 2e-2, rel(o, o_ref)
     assert rel(qg.grad, qr.grad) < 3e-2, rel(qg.grad, qr.grad)
