@@ -559,32 +559,65 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     }
 }
 
-// d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key].  The scratch is in the dQ kernel's fragment
-// order [group][head][q tile][key tile][lane][4]; one thread owns one (head, q tile, key tile, lane) = 4 scores, the
-// group loop is split over blockIdx.y; global atomics into the 2535-row table (a few per address).
-__global__ void __launch_bounds__(256) dbias_table_kernel(const bf16_t* __restrict__ ds, float* __restrict__ dtable,
-                                                          int groups, int nkt, Geom G) {
-    const int nqt = (G.g.N + 15) >> 4;
-    const int64_t per_head = (int64_t)nqt * nkt * 64;
-    const int64_t E = (int64_t)G.g.nH * per_head;
+// d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key], in three kernels and without atomics:
+//   sum     partial[s][h][q tile][key tile][lane][4] (fp32) = sum over group slice s of the dQ kernel's bf16 scratch
+//           (same fragment order; one thread = 4 scores; streaming, HBM-bound)
+//   fold    dense = sum of the slices' partials
+//   gather  one WAVE per (head, table row): its lanes share the <= N (query, key) pairs that map to the row
+//           (query coords = key coords + the row's offset), add the partial sums, wave-reduce, one writer per row
+__global__ void __launch_bounds__(256) dbias_sum_kernel(const bf16_t* __restrict__ ds, float4* __restrict__ partial,
+                                                        int groups, int64_t E2) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over nH * nqt * nkt * 32: 8 scores each
+    if (e >= E2) return;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int g = blockIdx.y; g < groups; g += gridDim.y) {
+        Frag8 v;
+        v.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)g * E2 + e) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += bf2f(v.h[i]);
+    }
+    float4* out = partial + ((int64_t)blockIdx.y * E2 + e) * 2;
+    out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// dense[e] = sum over the slices of partial[s][e]
+__global__ void __launch_bounds__(256) dbias_fold_kernel(const float4* __restrict__ partial, float4* __restrict__ dense,
+                                                         int nsplit, int64_t E) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    const int lane = (int)(e & 63);
-    const int t = (int)((e >> 6) % nkt), qt = (int)((e >> 6) / nkt % nqt), h = (int)(e / per_head);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int g = blockIdx.y; g < groups; g += gridDim.y) {
-        const uint2 v = *reinterpret_cast<const uint2*>(ds + ((int64_t)g * E + e) * 4);
-        acc[0] += bf2f((bf16_t)(v.x & 0xffff));
-        acc[1] += bf2f((bf16_t)(v.x >> 16));
-        acc[2] += bf2f((bf16_t)(v.y & 0xffff));
-        acc[3] += bf2f((bf16_t)(v.y >> 16));
+    float4 a = partial[e];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float4 b = partial[(int64_t)sp * E + e];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    const int qn = qt * 16 + (lane & 15), key0 = t * 16 + (lane >> 4) * 4;
-    if (qn >= G.g.N) return;
-    const int lq = win_lin(G, qn) + G.tcst;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (key0 + r < G.g.N) atomicAdd(dtable + (int64_t)(lq - win_lin(G, key0 + r)) * G.g.nH + h, acc[r]);
+    dense[e] = a;
+}
+
+__global__ void __launch_bounds__(256) dbias_gather_kernel(const float* __restrict__ dense, float* __restrict__ dtable,
+                                                           int nkt, Geom G) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;    // wave id over tlen * nH
+    if (w >= G.tlen * G.g.nH) return;
+    const int slot = w / G.g.nH, h = w - slot * G.g.nH;
+    // slot = (dz + bwd-1) * ts_d + (dy + bwh-1) * ts_h + (dx + bww-1):  query coords = key coords + (dz, dy, dx)
+    const int dz = slot / G.ts_d - (G.g.bwd - 1), rem = slot % G.ts_d;
+    const int dy = rem / G.ts_h - (G.g.bwh - 1), dx = rem % G.ts_h - (G.g.bww - 1);
+    const int nqt = (G.g.N + 15) >> 4, hw = G.g.bwh * G.g.bww;
+    const float* dh = dense + (int64_t)h * nqt * nkt * 256;
+    float a = 0.f;
+    for (int key = lane; key < G.g.N; key += 64) {
+        const int kz = key / hw, kr = key - kz * hw, ky = kr / G.g.bww, kx = kr - ky * G.g.bww;
+        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
+        if (qz < 0 || qz >= G.g.bwd || qy < 0 || qy >= G.g.bwh || qx < 0 || qx >= G.g.bww) continue;
+        const int qn = (qz * G.g.bwh + qy) * G.g.bww + qx;
+        if (qn >= G.g.N) continue;
+        // fragment address of (qn, key): q tile qn>>4, key tile key>>4, lane = (key&15)>>2 << 4 | qn&15, r = key&3
+        a += dh[(((int64_t)(qn >> 4) * nkt + (key >> 4)) * 64 + ((((key & 15) >> 2) << 4) | (qn & 15))) * 4 + (key & 3)];
+    }
+    a = wave_sum(a);
+    if (lane == 0) dtable[w] += a;
 }
 
 // ------------------------------------------------------------------------- host side
@@ -629,6 +662,14 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
 }
 
 constexpr size_t MAX_LDS = 160 * 1024;
+constexpr int DBIAS_SPLITS = 32;      // group slices of the dS reduction (partial sums, no atomics)
+
+// bytes of the bf16 dS scratch (16 x 16 fragments of every (group, head)), rounded so that the fp32 dense sums that
+// follow it in `work` stay 256-byte aligned
+inline int64_t ds_scratch_bytes(const Geom& G, int nkt) {
+    const int64_t b = (int64_t)G.g.groups * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 2;
+    return (b + 255) / 256 * 256;
+}
 
 template <int HD, int NKT>
 size_t fwd_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
@@ -700,12 +741,14 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     }
     if (bias && (stages & 2)) {
         const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
-        const int xb = (int)((E + 255) / 256);
-        int splits = 1024 / (xb > 0 ? xb : 1);
-        if (splits < 1) splits = 1;
-        if (splits > G.g.groups) splits = G.g.groups;
-        hipLaunchKernelGGL(dbias_table_kernel, dim3(xb, splits), dim3(256), 0, st, (const bf16_t*)work, dbias,
-                           G.g.groups, NKT, G);
+        float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT));
+        const int splits = G.g.groups < DBIAS_SPLITS ? G.g.groups : DBIAS_SPLITS;
+        float* dense = partial + (int64_t)splits * E * 4;
+        hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
+                           (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(dense), splits, E);
+        hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, dense, dbias, NKT, G);
         rc = clv_check_launch();
         if (rc) return rc;
     }
@@ -758,7 +801,7 @@ extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
     if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0) return 0;
     const int nkt = pick_nkt(G.g.N);
     if (nkt < 0) return 0;
-    return (int64_t)G.g.groups * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 2;      // bf16 dS, 16 x 16 fragments
+    return ds_scratch_bytes(G, nkt) + (int64_t)(DBIAS_SPLITS + 1) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;   // + fp32 partials, dense
 }
 
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,

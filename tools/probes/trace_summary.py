@@ -8,7 +8,7 @@ runs = []
 for r in rows:
     n = r['Kernel_Name']
     if pat not in n: continue
-    short = n.split('(')[0].replace('(anonymous namespace)::', '').replace('void ', '')[-40:]
+    short = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-44:]
     key = (short, r.get('Grid_Size_X', '?'))
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     if runs and runs[-1][0] == key: runs[-1][1].append(d)
