@@ -44,8 +44,26 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
-    const int n0 = blockIdx.y * TN;
-    const bool first_col = blockIdx.y == 0;
+    // 1-D grid of gx * ny workgroups; workgroup i runs on XCD i % 8.  The ny column tiles of one row slice get ids
+    // with the same i % 8 that are 8 apart, so they run on the same XCD at about the same time and the rows they
+    // all read (x, the residual) come from HBM once and from that L2 afterwards.
+    const int ny = (N + TN - 1) / TN;
+    const int gx = gridDim.x / ny;
+    int bx, by;
+    {
+        const int i = blockIdx.x, full = (gx / 8) * 8 * ny;           // ids covered by whole groups of 8 row slices
+        if (i < full) {
+            const int grp = i / (8 * ny), rem = i - grp * 8 * ny;
+            by = rem >> 3;
+            bx = grp * 8 + (rem & 7);
+        } else {                                                       // the gx % 8 leftover row slices: plain order
+            const int rem = i - full;
+            bx = (gx / 8) * 8 + rem / ny;
+            by = rem % ny;
+        }
+    }
+    const int n0 = by * TN;
+    const bool first_col = by == 0;
 
     // ---- weight tile -> LDS (rows >= N zero)
     for (int idx = tid; idx < TN * (K / 8); idx += RG_THREADS) {
@@ -65,7 +83,7 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     bf16_t* st0 = stage + (wave * NST) * 16 * LDO;
     bf16_t* st1 = st0 + 16 * LDO;
     const int64_t ntiles = (M + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * RG_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * RG_WAVES) {
+    for (int64_t tile = (int64_t)bx * RG_WAVES + wave; tile < ntiles; tile += (int64_t)gx * RG_WAVES) {
         const int64_t m0 = tile * 16;
         const int64_t row = m0 + lr;
         const bool rv = row < M;
@@ -186,7 +204,7 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
     int64_t gx = 1536 / ny;
     if (gx < 256) gx = 256;
     if (gx > row_blocks) gx = row_blocks;
-    rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)gx, ny), dim3(RG_THREADS), lds, st>>>(
+    rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)(gx * ny)), dim3(RG_THREADS), lds, st>>>(
         (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)sum_out, mean, rstd, (const bf16_t*)wt, bias,
         (const bf16_t*)pre_in, (bf16_t*)y, (bf16_t*)pre_out, M, N, ldx, ldy, eps);
     return clv_check_launch();
