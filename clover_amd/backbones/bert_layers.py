@@ -89,7 +89,9 @@ class BertEmbeddings(nn.Module):
     def forward(self, input_ids, past_key_values_length=0):
         L = input_ids.shape[1]
         pos = torch.arange(past_key_values_length, past_key_values_length + L, device=input_ids.device)
-        e = self.word_embeddings(input_ids) + self.token_type_embeddings.weight[0] + self.position_embeddings(pos)[None]
+        we = self.word_embeddings
+        word = ops.embedding(input_ids, we.weight, we.padding_idx) if input_ids.is_cuda else we(input_ids)
+        e = word + self.token_type_embeddings.weight[0] + self.position_embeddings(pos)[None]
         return self.dropout(self.LayerNorm(to_bf16(e)))
 
 

@@ -562,6 +562,39 @@ def gelu(x):
     return _Gelu.apply(x)
 
 
+# --------------------------------------------------------------------------- embedding
+class _Embedding(torch.autograd.Function):
+    """weight[ids] with the gradient scattered straight into the engine's gradient slab (index_add_ of the few
+    hundred looked-up rows) instead of a dense [vocab, H] zero-fill + scatter + fp32 add of 94 MB each.
+    Rows of padding_idx receive no gradient (as nn.Embedding)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.wref, ctx.pad = weight, padding_idx
+        return weight.detach()[ids]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        w = ctx.wref
+        sink = getattr(w, '_clv_grad', None)
+        flat = ids.reshape(-1)
+        d = dy.reshape(-1, dy.shape[-1])
+        if ctx.pad is not None:
+            d = d.masked_fill((flat == ctx.pad)[:, None], 0)
+        if sink is not None:
+            sink.index_add_(0, flat, d.to(sink.dtype))
+            w._clv_ready()
+            return None, None, None
+        return None, torch.zeros_like(w).index_add_(0, flat, d.to(w.dtype)), None
+
+
+def embedding(ids, weight, padding_idx=None):
+    """nn.Embedding forward + sink-aware backward."""
+    return _Embedding.apply(ids, weight, padding_idx)
+
+
 # --------------------------------------------------------------------------- attention
 class _Attention(torch.autograd.Function):
     """qkv: bf16 [..tokens.., 3*nH*hd] with q|k|v packed along the last dim.  table (window mode): the module's

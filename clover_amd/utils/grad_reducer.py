@@ -20,6 +20,12 @@ class BucketedGradReducer:
         self.buckets = []           # [flat_grad, start, end, n_params]
         self.handles = []
         self.pending = []
+        # A parameter may receive SEVERAL gradient contributions per backward (tied weights: BERT's word embedding
+        # is also the MLM decoder, mlm_itm_head.py:36-40).  The first backward only counts them (its buckets all go
+        # out in finish()); from then on a parameter reports ready on its LAST contribution.
+        self.expect = {}            # id(param) -> contributions per backward (known after the first finish())
+        self.seen = {}
+        self.calibrated = False
         self.comm_stream = None
         self.active = collectives_active()
         if not self.active:
@@ -48,6 +54,7 @@ class BucketedGradReducer:
     def reset(self):
         self.pending = [b[3] for b in self.buckets]
         self.handles = []
+        self.seen = {}
 
     def _launch(self, b):
         flat, s, e, _ = self.buckets[b]
@@ -62,6 +69,10 @@ class BucketedGradReducer:
         def hook(param):
             if not self.enabled:
                 return
+            k = id(param)
+            self.seen[k] = self.seen.get(k, 0) + 1
+            if not self.calibrated or self.seen[k] != self.expect.get(k, 1):
+                return
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 self._launch(b)
@@ -72,6 +83,9 @@ class BucketedGradReducer:
         received no gradient this step), then make the compute stream wait for the comm stream."""
         if not self.active:
             return
+        if not self.calibrated and self.enabled and self.seen:
+            self.expect = dict(self.seen)
+            self.calibrated = True
         for b, left in enumerate(self.pending):
             if left > 0:
                 self._launch(b)

@@ -94,8 +94,15 @@ def _w_reducer(rank, world, port, q):
         p.grad = flat[o:o + p.numel()].view_as(p)
     red = BucketedGradReducer([(flat, params, offs)], bucket_bytes=256)      # several small buckets
     x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
-    net(x).pow(2).sum().backward()
-    red.finish()
+
+    def loss_of(m, xx):
+        # the first layer's weight is used TWICE (tied, like BERT's word embedding / MLM decoder): its gradient
+        # arrives in two contributions and the bucket must wait for the second
+        return m(xx).pow(2).sum() + (xx @ m[0].weight.t()).tanh().sum()
+    for step in range(3):                       # step 0 calibrates the contribution counts, 1.. launch from hooks
+        flat.zero_()
+        loss_of(net, x).backward()
+        red.finish()
     mine = flat.clone()
     # reference: sum over ranks of single-rank grads
     tot = torch.zeros_like(flat)
@@ -103,7 +110,7 @@ def _w_reducer(rank, world, port, q):
         net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
         net2.load_state_dict(net.state_dict())
         xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + r))
-        net2(xr).pow(2).sum().backward()
+        loss_of(net2, xr).backward()
         for p, o in zip(reversed(list(net2.parameters())), offs):
             tot[o:o + p.numel()] += p.grad.reshape(-1)
     ok = torch.allclose(mine, tot, atol=1e-5) and len(red.buckets) > 1
