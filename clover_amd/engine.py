@@ -118,6 +118,7 @@ class CloverEngine:
         self.min_lr_ratio, self.warmup_ratio = min_lr_ratio, warmup_ratio
         self.step_count = 0
         self.graph = None
+        self.graph_bwd_video = None
         device = next(model.parameters()).device
         pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                    custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
@@ -202,6 +203,11 @@ class CloverEngine:
         self._static_demb.copy_(emb.grad)
         self._static_dmlm.copy_(mlm.grad)
         self.graph_bwd.replay()
+        if self.graph_bwd_video is not None:
+            # heads / fusion / text-encoder gradients are complete: put their buckets on the wire, then run the
+            # video encoder's backward underneath that traffic (step() -> reducer.finish() sends the rest)
+            self.reducer.launch_where(self._is_non_video)
+            self.graph_bwd_video.replay()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
 
     def capture(self, batch, warmup=2):
@@ -215,35 +221,53 @@ class CloverEngine:
         self._static_batch = {k: v.clone() for k, v in batch.items()}
         sb = self._static_batch
 
-        def encode():
-            return model.encode(sb['imgs'], **{k: sb[k] for k in aux})
+        cut_ok = self.reducer.active and hasattr(model, 'backbone')
+        video_ids = {id(q) for q in model.backbone.parameters()} if cut_ok else set()
+        self._is_non_video = lambda q: id(q) not in video_ids
+
+        def encode(cuts=None):
+            return model.encode(sb['imgs'], video_cut=cuts, **{k: sb[k] for k in aux})
+
+        def backward(emb, mlm, demb, dmlm, cuts):
+            """Backward in two pieces when the video encoder is cut off: everything else first (its gradient
+            buckets can then travel while the video encoder's backward runs), the video encoder second."""
+            torch.autograd.backward([emb, mlm], [demb, dmlm])
+            if cuts:
+                torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
         self.reducer.enabled = False           # no collective may be issued from inside a capture; in graph
-        self.reducer.reset()                   # mode finish() all-reduces every bucket after the replay
+        self.reducer.reset()                   # mode the engine launches the buckets between / after the replays
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                emb, mlm = encode()
-                torch.autograd.backward([emb, mlm], [torch.zeros_like(emb), torch.zeros_like(mlm)])
+                cuts = [] if cut_ok else None
+                emb, mlm = encode(cuts)
+                backward(emb, mlm, torch.zeros_like(emb), torch.zeros_like(mlm), cuts)
         torch.cuda.current_stream().wait_stream(side)
         # no autograd graph may survive into the capture: a live one pins the parameters'
         # AccumulateGrad nodes to the warm-up stream and their accumulation escapes the hipGraph
-        del emb, mlm
+        del emb, mlm, cuts
         for seg in self.segments:
             seg.flat_g.zero_()
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gb2 = torch.cuda.CUDAGraph() if cut_ok else None
         # thread_local: RCCL's watchdog thread (W > 1) keeps polling events while we capture
+        cuts = [] if cut_ok else None
         with torch.cuda.graph(gf, capture_error_mode='thread_local'):
-            emb, mlm = encode()
+            emb, mlm = encode(cuts)
         self._static_demb = torch.zeros_like(emb)
         self._static_dmlm = torch.zeros_like(mlm)
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
             torch.autograd.backward([emb, mlm], [self._static_demb, self._static_dmlm])
+        if cut_ok:
+            with torch.cuda.graph(gb2, pool=gf.pool(), capture_error_mode='thread_local'):
+                torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
         for seg in self.segments:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit
-        self.graph, self.graph_bwd = gf, gb
+        self.graph, self.graph_bwd, self.graph_bwd_video = gf, gb, gb2
         self._static_emb, self._static_mlm = emb, mlm
+        self._static_cuts = cuts
         return True
 
     def optimizer_step(self):

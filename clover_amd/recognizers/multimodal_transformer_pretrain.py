@@ -57,7 +57,8 @@ class CloverPretrain(BaseRecognizer):
     EMB_NAMES = ('visual_emb', 'text_emb', 'mask_word_emb', 'mask_visual_recon_emb', 'mask_visual_emb',
                  'mask_word_recon_emb')
 
-    def encode(self, imgs, token_ids=None, input_mask=None, mlm_label=None, v_token_mask=None, **kwargs):
+    def encode(self, imgs, token_ids=None, input_mask=None, mlm_label=None, v_token_mask=None, video_cut=None,
+               **kwargs):
         """Everything of the step that touches only THIS rank's samples: the three encoders, the heads
         and the MLM loss.  Returns (emb fp32 [B, 6, D] in EMB_NAMES order, mlm_loss).  No collective
         and no data-dependent shape inside — the engine captures it (and its backward) as hipGraphs."""
@@ -79,6 +80,13 @@ class CloverPretrain(BaseRecognizer):
 
         # ---- video encoder: clean (:91) + masked (:114) pass, channels-last [B,T',h,w,Cf]
         vis_clean, vis_masked = self.backbone.forward_pair(imgs, v_token_mask)
+        if video_cut is not None:
+            # engine graph mode: cut the autograd graph at the video encoder's output, so that its backward can run
+            # as a separate graph AFTER the gradient all-reduce of everything else has been put in flight.
+            # video_cut receives [(output, detached leaf standing in for it downstream), ...]
+            cuts = [(t, t.detach().requires_grad_()) for t in (vis_clean, vis_masked)]
+            video_cut.extend(cuts)
+            vis_clean, vis_masked = cuts[0][1], cuts[1][1]
         _, T, h, w, D = vis_clean.shape
 
         # ---- text encoder: un-masked caption (:97-101) + masked caption (:110-111)

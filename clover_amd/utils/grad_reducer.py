@@ -28,6 +28,7 @@ class BucketedGradReducer:
         self.calibrated = False
         self.comm_stream = None
         self.active = collectives_active()
+        self._bucket_params = []
         if not self.active:
             for _, params, _ in slabs:
                 for q in params:
@@ -41,6 +42,7 @@ class BucketedGradReducer:
                 end = offsets[i + 1]
                 if end - start >= cap or i == len(params) - 1:
                     self.buckets.append([flat, start, end, count])
+                    self._bucket_params.append(list(params[i + 1 - count:i + 1]))
                     b = len(self.buckets) - 1
                     for q in params[i + 1 - count:i + 1]:
                         hook = self._make_hook(b)
@@ -77,6 +79,19 @@ class BucketedGradReducer:
             if self.pending[b] == 0:
                 self._launch(b)
         return hook
+
+    def launch_where(self, ready):
+        """Launch (asynchronously, on the comm stream) every not-yet-launched bucket all of whose parameters satisfy
+        `ready(param)` — the engine's split-backward graph mode calls this between the two backward replays, so the
+        all-reduce of the text / fusion / head gradients overlaps the video encoder's backward."""
+        if not self.active:
+            return
+        if not hasattr(self, '_bucket_params'):
+            raise RuntimeError('launch_where needs the bucket -> parameter map')
+        for b, ps in enumerate(self._bucket_params):
+            if self.pending[b] > 0 and all(ready(q) for q in ps):
+                self._launch(b)
+                self.pending[b] = 0
 
     def finish(self):
         """Wait for every bucket (launching any whose hooks did not all fire, e.g. a parameter that
