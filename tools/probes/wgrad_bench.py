@@ -16,7 +16,7 @@ def timeit(fn, n=20):
 SHAPES = [(200704, 96, 96, 'pe/proj s0'), (200704, 288, 96, 'qkv s0'), (200704, 384, 96, 'fc1 s0'), (200704, 96, 384, 'fc2 s0'),
           (50176, 192, 384, 'merge s1'), (50176, 576, 192, 'qkv s1'), (50176, 192, 192, 'proj s1'), (50176, 768, 192, 'fc1 s1'), (50176, 192, 768, 'fc2 s1'),
           (12544, 384, 768, 'merge s2'), (12544, 1152, 384, 'qkv s2'), (12544, 384, 384, 'proj s2'), (12544, 1536, 384, 'fc1 s2'), (12544, 384, 1536, 'fc2 s2'),
-          (3136, 768, 768, 'proj s3'), (3136, 2304, 768, 'qkv s3'), (3136, 3072, 768, 'fc1 s3'), (256, 768, 768, 'bert qkv'), (256, 3072, 768, 'bert fc1'), (256, 768, 3072, 'bert fc2'), (2120, 768, 768, 'fusion')]
+          (3136, 768, 768, 'proj s3'), (3136, 2304, 768, 'qkv s3'), (3136, 3072, 768, 'fc1 s3'), (512, 768, 768, 'bert proj'), (512, 2304, 768, 'bert qkv'), (512, 3072, 768, 'bert fc1'), (512, 768, 3072, 'bert fc2'), (2120, 768, 768, 'fusion')]
 tot = 0
 for (M, N, K, name) in SHAPES:
     dy = torch.randn(M, N, device='cuda').to(torch.bfloat16); x = torch.randn(M, K, device='cuda').to(torch.bfloat16)
