@@ -297,6 +297,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
         print(json.dumps(res))
+    if args.tune_gemms and rank == 0:
+        from clover_amd.utils.gemm_tuning import save_results
+        save_results(args.tune_gemms)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -140,7 +140,8 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
                 check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
             check(L.clv_linear_wgrad(*args, 2, _stream()), 'clv_linear_wgrad')
         return (None, None) if sink else (dw, db)
-    dwb = torch.mm(dy2.t(), x2)
+    # library GEMM with fp32 output: accumulated in place into the gradient slab view (beta = 1) — no bf16 rounding
+    # of dW and no separate fp32 add
     db = None
     if want_bias:
         db = db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)
@@ -149,9 +150,9 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         else:
             db.add_(dy2.sum(0, dtype=torch.float32))
     if sink:
-        dw_out.add_(dwb)                                    # fp32 += bf16, one kernel
+        torch.addmm(dw_out, dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
         return None, None
-    return dwb.float(), db
+    return torch.mm(dy2.t(), x2, out_dtype=torch.float32), db
 
 
 def _rowgemm_fwd_ok(x, N, K):

@@ -33,3 +33,13 @@ def enable_tuned_gemms(path=None, tune_missing=False, out_path=None):
     path = path or DEFAULT_FILE
     ok = os.path.exists(path) and t.read_file(path)
     return len(t.get_results()) if ok else 0
+
+
+def save_results(path):
+    """Write the current selections (loaded + newly tuned) in TunableOp's CSV format."""
+    t = torch.cuda.tunable
+    lines = ['Validator,%s,%s' % (k, v) for k, v in t.get_validators()]
+    lines += ['%s,%s,%s,%s' % tuple(r) for r in t.get_results()]
+    with open(path, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return len(lines)
