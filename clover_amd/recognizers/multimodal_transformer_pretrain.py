@@ -78,6 +78,20 @@ class CloverPretrain(BaseRecognizer):
         mlm_label = mlm_label.reshape((-1,) + mlm_label.shape[2:])
         B = imgs.shape[0]
 
+        # ---- text encoder (:97-101, :110-111) on a SIDE stream: it is independent of the video encoder until the
+        # projection heads, and its ~250 kernels are tiny (16 x 32 tokens: 36..144 workgroups each), so they
+        # run in the shadow of the Swin kernels instead of serially after them.  Autograd replays each backward
+        # on its forward's stream, so the two backward passes overlap the same way; a hipGraph capture records
+        # the fork / join as graph edges.
+        input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
+        side = self._text_stream(imgs.device) if imgs.is_cuda and getattr(self, 'overlap_text', True) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
+                                              torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+
         # ---- video encoder: clean (:91) + masked (:114) pass, channels-last [B,T',h,w,Cf]
         vis_clean, vis_masked = self.backbone.forward_pair(imgs, v_token_mask)
         if video_cut is not None:
@@ -90,9 +104,12 @@ class CloverPretrain(BaseRecognizer):
         _, T, h, w, D = vis_clean.shape
 
         # ---- text encoder: un-masked caption (:97-101) + masked caption (:110-111)
-        input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
-        text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
-                                      torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+        if side is not None:
+            main.wait_stream(side)
+            text_out.record_stream(main)
+        else:
+            text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
+                                          torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
         text_out_no_mask, text_out_with_mask = text_out[:B], text_out[B:]
 
         # ---- contrastive projections (:102, :150, :159)
@@ -120,6 +137,13 @@ class CloverPretrain(BaseRecognizer):
         emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
                            mask_word_recon_emb], dim=1).float()
         return emb, mlm_loss
+
+    def _text_stream(self, device):
+        st = getattr(self, '_txt_stream', None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, '_txt_stream', st)
+        return st
 
     def contrastive_losses(self, emb, mlm_loss):
         """The cross-rank part of the step (:147-169): all-gather of the embeddings + the two
