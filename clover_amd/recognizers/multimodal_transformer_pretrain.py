@@ -91,6 +91,7 @@ class CloverPretrain(BaseRecognizer):
             with torch.cuda.stream(side):
                 text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
                                               torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+                txt_emb_both = self.ssl_head.forward_text(text_out)          # :102 / :159, also text-only
 
         # ---- video encoder: clean (:91) + masked (:114) pass, channels-last [B,T',h,w,Cf]
         vis_clean, vis_masked = self.backbone.forward_pair(imgs, v_token_mask)
@@ -107,15 +108,16 @@ class CloverPretrain(BaseRecognizer):
         if side is not None:
             main.wait_stream(side)
             text_out.record_stream(main)
+            txt_emb_both.record_stream(main)
         else:
             text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
                                           torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+            txt_emb_both = self.ssl_head.forward_text(text_out)
         text_out_no_mask, text_out_with_mask = text_out[:B], text_out[B:]
 
         # ---- contrastive projections (:102, :150, :159)
         vis_emb_both = self.ssl_head.forward_vision(torch.cat([vis_clean, vis_masked], 0), channels_last=True)
         visual_emb, mask_visual_emb = vis_emb_both[:B], vis_emb_both[B:]
-        txt_emb_both = self.ssl_head.forward_text(text_out)
         text_emb, mask_word_emb = txt_emb_both[:B], txt_emb_both[B:]
 
         # ---- fusion: v_fusion = (masked video, clean text) (:117); t_fusion = (clean video, masked text) (:119)

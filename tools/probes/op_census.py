@@ -17,12 +17,13 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     eng.step(batch)
     torch.cuda.synchronize()
-want = [a for a in sys.argv[1:] if a != '--all'] or ['aten::add_', 'aten::add', 'aten::zeros', 'aten::zero_', 'aten::fill_', 'aten::copy_', 'aten::mul', 'aten::zeros_like', 'aten::sum', 'aten::to', 'aten::_to_copy', 'aten::contiguous']
+want = [a for a in sys.argv[1:] if not a.startswith('--')] or ['aten::add_', 'aten::add', 'aten::zeros', 'aten::zero_', 'aten::fill_', 'aten::copy_', 'aten::mul', 'aten::zeros_like', 'aten::sum', 'aten::to', 'aten::_to_copy', 'aten::contiguous']
 cnt = collections.Counter(); tim = collections.Counter(); where = {}
 for e in prof.events():
     if (e.name in want or '--all' in sys.argv) and e.device_time > 0 and e.name.startswith('aten::'):
         st = [s for s in (e.stack or []) if 'clover_amd' in s or 'bench.py' in s]
         key = (e.name, str(e.input_shapes)[:70], (st[0].split('/')[-1][:60] if st else '?'))
         cnt[key] += 1; tim[key] += e.device_time
-for k, t in sorted(tim.items(), key=lambda kv: -kv[1])[:110]:
+order = sorted(tim.items(), key=lambda kv: -cnt[kv[0]]) if '--by-count' in sys.argv else sorted(tim.items(), key=lambda kv: -kv[1])
+for k, t in order[:110]:
     print(f'{t:8.0f} us {cnt[k]:4d}x  {k[0]:16s} {k[1]:70s} {k[2]}')
