@@ -201,8 +201,19 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
     }
     const int ny = (N + C::TN - 1) / C::TN;
     const int64_t row_blocks = ((M + 15) / 16 + RG_WAVES - 1) / RG_WAVES;
-    int64_t gx = 1536 / ny;
-    if (gx < 256) gx = 256;
+    // persistent workgroups, exactly as many as are resident at once (LDS-limited): every workgroup loads its weight
+    // tile (up to 100 KB) ONCE and then streams its share of the rows — with more workgroups than that the tile
+    // reload dominates (measured: 1536 workgroups of 2 row tiles per wave ran fc2 at a third of this)
+    int occ = (int)((160 * 1024) / lds);
+    if (occ < 1) occ = 1;
+    if (occ > 4) occ = 4;
+    int64_t gx = (256 * occ + ny - 1) / ny;
+    if (ny > 3 || EPI != EPI_NONE) {     // many column tiles (small weight tiles), or a VALU-heavy GELU epilogue that
+                                         // wants more waves in flight than tile reloads cost: finer row slices
+        gx = 1536 / ny;
+        if (gx < 256) gx = 256;
+    }
+    if (gx < 8) gx = 8;
     if (gx > row_blocks) gx = row_blocks;
     rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)(gx * ny)), dim3(RG_THREADS), lds, st>>>(
         (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)sum_out, mean, rstd, (const bf16_t*)wt, bias,
