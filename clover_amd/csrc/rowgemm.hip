@@ -72,12 +72,17 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
         if (n0 + r < N) v = *reinterpret_cast<const uint4*>(wt + (int64_t)(n0 + r) * K + c8 * 8);
         *reinterpret_cast<uint4*>(Ws + r * LDW + c8 * 8) = v;
     }
-    float bn[NT];
+    // The MFMAs below run with SWAPPED operands (D = W-rows x X-rows), so a lane ends up with 4 CONSECUTIVE output
+    // columns (nt*16 + lg*4 + r) of ONE row (lr): the epilogue then packs 4 bf16 into one 8-byte LDS access where the
+    // natural orientation needs four 2-byte ones.  bias per lane accordingly: 4 values per column tile.
+    float bn[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + nt * 16 + lr;
-        bn[nt] = (bias && n < N) ? bias[n] : 0.f;
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + nt * 16 + lg * 4 + r;
+            bn[nt][r] = (bias && n < N) ? bias[n] : 0.f;
+        }
     __syncthreads();
 
     bf16_t* st0 = stage + (wave * NST) * 16 * LDO;
@@ -153,20 +158,25 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
             for (int s = 0; s < KS; ++s) {
                 Frag8 b;
                 b.u4 = *reinterpret_cast<const uint4*>(Ws + (nt * 16 + lr) * LDW + s * 32 + lg * 8);
-                acc = mfma16(af[s], b, acc);
+                acc = mfma16(b, af[s], acc);               // swapped: acc[r] = Y[row lr][col nt*16 + lg*4 + r]
             }
+            const int off = lr * LDO + nt * 16 + lg * 4;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int off = (lg * 4 + r) * LDO + nt * 16 + lr;
-                float v = acc[r] + bn[nt];
-                if (EPI == EPI_GELU) {
-                    st1[off] = f2bf(v);                    // pre-activation (kept for the backward)
-                    v = gelu_erf(v);
-                } else if (EPI == EPI_GELU_BWD) {
-                    v *= gelu_erf_grad(bf2f(st1[off]));
-                }
-                st0[off] = f2bf(v);
+            for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[nt][r];
+            if (EPI == EPI_GELU) {
+                // pre-activation (kept for the backward)
+                *reinterpret_cast<uint2*>(st1 + off) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (EPI == EPI_GELU_BWD) {
+                const uint2 pz = *reinterpret_cast<const uint2*>(st1 + off);
+                v[0] *= gelu_erf_grad(bf2f((bf16_t)(pz.x & 0xffff)));
+                v[1] *= gelu_erf_grad(bf2f((bf16_t)(pz.x >> 16)));
+                v[2] *= gelu_erf_grad(bf2f((bf16_t)(pz.y & 0xffff)));
+                v[3] *= gelu_erf_grad(bf2f((bf16_t)(pz.y >> 16)));
             }
+            *reinterpret_cast<uint2*>(st0 + off) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
