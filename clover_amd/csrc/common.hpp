@@ -80,7 +80,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    ex = __expf(-0.5f * x * x);
+    ex = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2) as ONE v_exp_f32 (no range fix-ups)
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
