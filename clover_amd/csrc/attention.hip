@@ -30,6 +30,9 @@ struct Geom {
     // lin(n) = (n / (bwh*bww)) * ts_d + ((n / bww) % bwh) * ts_h + n % bww  — the reference's
     // relative_position_index[:N,:N] of the window the table was built for (swin_transformer_3d.py:343-360,386)
     int ts_d, ts_h, tcst, tlen, tls;     // tls: tlen rounded up to 4 (LDS / partial-table row stride)
+    // few (group, head) pairs (the fusion encoder: 16 x 12 = 192 on 256 CUs): tsplit workgroups per pair, each staging
+    // the pair's K / V (or Q / dO) and taking every tsplit-th set of 4 query (key) tiles
+    int tsplit;
 };
 
 __device__ __forceinline__ int win_lin(const Geom& G, int n) {
@@ -166,7 +169,8 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
 
     int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
@@ -189,7 +193,7 @@ __global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
 
     const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
-    for (int qt = wave; qt < nqt; qt += WAVES) {
+    for (int qt = wave + WAVES * part; qt < nqt; qt += WAVES * G.tsplit) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
         const int64_t qrow = row_s[qv ? nq : 0];
@@ -309,7 +313,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
     const bool tb = MODE == 1 && bias != nullptr;
 
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int qt = wave; qt < nqt; qt += WAVES) {
+    for (int qt = wave + WAVES * part; qt < nqt; qt += WAVES * G.tsplit) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
         const int64_t qrow = row_s[qv ? nq : 0];
@@ -435,7 +440,8 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp = bid / G.g.nH, h = bid - grp * G.g.nH;
+    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
 
     int* row_s = reinterpret_cast<int*>(aux + NK);
@@ -460,7 +466,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const int nkt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int kt = wave; kt < nkt; kt += WAVES) {
+    for (int kt = wave + WAVES * part; kt < nkt; kt += WAVES * G.tsplit) {
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
         const int64_t krow = row_s[kv ? nk : 0];
@@ -636,6 +642,11 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (g->hd != 16 && g->hd != 32 && g->hd != 64) return false;
     if ((g->ldq | g->ldk | g->ldv | g->ldo) & 7) return false;   // 16-byte row alignment
     G.ts_d = G.ts_h = G.tcst = G.tlen = G.tls = 0;
+    {
+        const int pairs = g->groups * g->nH, tiles = (g->N + 15) / 16;
+        G.tsplit = 1;
+        while (G.tsplit < 4 && pairs * G.tsplit < 384 && tiles >= 8 * G.tsplit) G.tsplit *= 2;
+    }
     if (g->mode == 1) {
         if (g->wd <= 0 || g->wh <= 0 || g->ww <= 0) return false;
         if (g->D % g->wd || g->H % g->wh || g->W % g->ww) return false;
@@ -714,7 +725,7 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     if (lds > MAX_LDS || dq_lds<HD, NKT>(bl) > MAX_LDS || dkv_lds<HD, NKT>(bl) > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
-    const int nblk = G.g.groups * G.g.nH;
+    const int nblk = G.g.groups * G.g.nH * G.tsplit;
     CLV_PICK(attn_fwd_kernel, <<<dim3(nblk), dim3(THREADS), lds, st>>>((const bf16_t*)q, (const bf16_t*)k,
              (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G));
     return clv_check_launch();
@@ -730,7 +741,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
-    const int nblk = G.g.groups * G.g.nH;
+    const int nblk = G.g.groups * G.g.nH * G.tsplit;
     int rc = CLV_OK;
     if (stages & 1) {
         CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
