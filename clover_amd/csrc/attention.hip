@@ -753,7 +753,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     if (bias && (stages & 2)) {
         const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
         float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT));
-        const int splits = G.g.groups < DBIAS_SPLITS ? G.g.groups : DBIAS_SPLITS;
+        // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
+        // bf16 scratch itself once a slice covers only 4 groups
+        int splits = G.g.groups / 16;
+        splits = splits < 1 ? 1 : (splits > DBIAS_SPLITS ? DBIAS_SPLITS : splits);
         float* dense = partial + (int64_t)splits * E * 4;
         hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
                            (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
