@@ -251,6 +251,7 @@ def main():
         # eager step is queued behind ~40 ms of filler GEMMs so that the host runs ahead and the step's
         # kernels execute back-to-back at full clocks, as they do inside the graph.
         engine.graph, g = None, engine.graph
+        model.overlap_text = False        # serial streams while single kernels are bracketed by events (as rocprof sees them)
         filler = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
         ops.PROF = {}
         prof_steps = 3
@@ -262,6 +263,7 @@ def main():
         del filler
         prof, ops.PROF = ops.PROF, None
         engine.graph = g
+        model.overlap_text = True
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
