@@ -8,6 +8,11 @@ from clover_amd.engine import CloverEngine
 from clover_amd.utils.gemm_tuning import enable_tuned_gemms
 enable_tuned_gemms()
 dev = torch.device('cuda', 0)
+import torch.distributed as dist
+if os.environ.get('CLOVER_FORCE_COLLECTIVES') == '1':
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
 torch.manual_seed(1234)
 model = clover_amd.build_model(bench.model_cfg('T', 8)).to(dev); model.train()
 batch = {k: v.to(dev) for k, v in bench.synthetic_batch(8, 8, 32, 1000).items()}
@@ -30,10 +35,17 @@ for _ in range(N):
     eng._static_demb.copy_(emb.grad); eng._static_dmlm.copy_(mlm.grad)
     e[2].record()
     eng.graph_bwd.replay()
+    if eng.graph_bwd_video is not None:
+        eng.reducer.launch_where(eng._is_non_video)
+        eng.graph_bwd_video.replay()
     e[3].record()
-    eng.reducer.finish(); eng.optimizer_step()
+    eng.reducer.finish()
+    e5 = ev(); e5.record()
+    eng.optimizer_step()
     e[4].record()
     torch.cuda.synchronize()
     for i in range(4): acc[i] += e[i].elapsed_time(e[i + 1])
+    fin = globals().get('fin', 0.0) + e[3].elapsed_time(e5); globals()['fin'] = fin
 print('forward graph %.2f ms | eager losses %.2f ms | backward graph %.2f ms | optimizer %.2f ms | total %.2f' % (
     acc[0] / N, acc[1] / N, acc[2] / N, acc[3] / N, sum(acc) / N))
+print('  of the optimizer phase, reducer.finish(): %.2f ms' % (fin / N))
