@@ -40,6 +40,8 @@ SIGNATURES = {
     'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, C.POINTER(ClvLnExtra), _p]),
+    'clv_ln_fold_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _p]),
+    'clv_ln_fold_bwd': (C.c_int, [_p] * 9 + [_i32, _i32, _p]),
     'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
     'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),

@@ -752,3 +752,84 @@ extern "C" int clv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, 
                        (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n8, n);
     return clv_check_launch();
 }
+
+// ------------------------------------------------------------------ LayerNorm affine folded into the next Linear
+// (xhat * gamma + beta) W^T + b  ==  xhat (W * gamma)^T + (b + W beta): the fused LN+projection kernels take the
+// standardised rows, so gamma / beta live in the weights.  One small kernel each way instead of ~16 elementwise /
+// mv / reduction launches of autograd-tracked torch ops per layer and step.
+namespace {
+
+// block = one output row n: wf[n][:] = bf16(w[n][:] * gamma), bf[n] = b[n] + sum_k w[n][k] beta[k]
+__global__ void __launch_bounds__(128) ln_fold_fwd_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ wf, float* __restrict__ bf, int K) {
+    __shared__ float red[2];
+    const int n = blockIdx.x;
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float v = w[(int64_t)n * K + k];
+        wf[(int64_t)n * K + k] = f2bf(v * gamma[k]);
+        dot += v * beta[k];
+    }
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) bf[n] = (b ? b[n] : 0.f) + red[0] + red[1];
+}
+
+// dW[n][k] += dwf[n][k] gamma[k] + dbf[n] beta[k];  db[n] += dbf[n]   (grid over N*K)
+__global__ void __launch_bounds__(256) ln_fold_bwd_w_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ dw,
+                                                            float* __restrict__ db, int N, int K) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * K) return;
+    const int n = e / K, k = e - n * K;
+    dw[e] += dwf[e] * gamma[k] + dbf[n] * beta[k];
+    if (db && k == 0) db[n] += dbf[n];
+}
+
+// dgamma[k] += sum_n dwf[n][k] w[n][k];  dbeta[k] += sum_n dbf[n] w[n][k]   (block = 64 columns x 4 row lanes)
+__global__ void __launch_bounds__(256) ln_fold_bwd_g_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf,
+                                                            const float* __restrict__ w, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int N, int K) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    float g = 0.f, bb = 0.f;
+    if (k < K)
+        for (int n = rl; n < N; n += 4) {
+            const float wv = w[(int64_t)n * K + k];
+            g += dwf[(int64_t)n * K + k] * wv;
+            bb += dbf[n] * wv;
+        }
+    sg[rl][kl] = g;
+    sb[rl][kl] = bb;
+    __syncthreads();
+    if (rl == 0 && k < K) {
+        dgamma[k] += sg[0][kl] + sg[1][kl] + sg[2][kl] + sg[3][kl];
+        dbeta[k] += sb[0][kl] + sb[1][kl] + sb[2][kl] + sb[3][kl];
+    }
+}
+
+}  // namespace
+
+extern "C" int clv_ln_fold_fwd(const float* w, const float* b, const float* gamma, const float* beta, void* wf,
+                               float* bf, int32_t N, int32_t K, void* stream) {
+    if (!w || !gamma || !beta || !wf || !bf || N <= 0 || K <= 0) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(ln_fold_fwd_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, w, b, gamma, beta, (bf16_t*)wf, bf,
+                       (int)K);
+    return clv_check_launch();
+}
+
+extern "C" int clv_ln_fold_bwd(const float* dwf, const float* dbf, const float* w, const float* gamma,
+                               const float* beta, float* dw, float* db, float* dgamma, float* dbeta, int32_t N,
+                               int32_t K, void* stream) {
+    if (!dwf || !dbf || !w || !gamma || !beta || !dw || !dgamma || !dbeta || N <= 0 || K <= 0) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_fold_bwd_w_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, dwf, dbf, gamma, beta, dw, db,
+                       (int)N, (int)K);
+    hipLaunchKernelGGL(ln_fold_bwd_g_kernel, dim3((K + 63) / 64), dim3(256), 0, st, dwf, dbf, w, dgamma, dbeta, (int)N,
+                       (int)K);
+    return clv_check_launch();
+}

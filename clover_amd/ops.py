@@ -262,32 +262,62 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
 
 
 def fold_layernorm(weight, bias, gamma, beta):
-    """LayerNorm's affine part folded into the following Linear (tiny autograd-tracked torch ops):
-    (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta)."""
-    wf = weight.float() * gamma.float()[None, :]
-    bf = torch.mv(weight.float(), beta.float())
-    if bias is not None:
-        bf = bf + bias.float()
+    """LayerNorm's affine part folded into the following Linear:
+    (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta).  -> (wf bf16 [N,K], bf fp32 [N]), one kernel."""
+    N, K = weight.shape
+    wf = torch.empty(N, K, device=weight.device, dtype=BF16)
+    bf = torch.empty(N, device=weight.device, dtype=torch.float32)
+    check(_lib.lib().clv_ln_fold_fwd(_ptr(_c(weight.detach().float())), _ptr(_c(bias.detach().float())) if bias is not None else None,
+                                     _ptr(_c(gamma.detach().float())), _ptr(_c(beta.detach().float())), _ptr(wf), _ptr(bf),
+                                     N, K, _stream()), 'clv_ln_fold_fwd')
     return wf, bf
 
 
+def _unfold_grads(dwf, dbf, weight, bias, gamma, beta):
+    """Backward of fold_layernorm: (d wf, d bf) -> gradients of (weight, bias, gamma, beta), accumulated straight into
+    the engine's slab views when all four are engine-managed (returns Nones), else returned."""
+    N, K = weight.shape
+    ps = (weight, bias, gamma, beta)
+    sinks = [getattr(q, '_clv_grad', None) if q is not None else None for q in ps]
+    use_sink = all(sk is not None and sk.dtype == torch.float32 for sk, q in zip(sinks, ps) if q is not None)
+    if use_sink:
+        dw, db, dg, dbt = sinks
+    else:
+        dw = torch.zeros(N, K, device=dwf.device, dtype=torch.float32)
+        db = torch.zeros(N, device=dwf.device, dtype=torch.float32) if bias is not None else None
+        dg = torch.zeros(K, device=dwf.device, dtype=torch.float32)
+        dbt = torch.zeros_like(dg)
+    check(_lib.lib().clv_ln_fold_bwd(_ptr(dwf), _ptr(dbf), _ptr(_c(weight.detach().float())),
+                                     _ptr(_c(gamma.detach().float())), _ptr(_c(beta.detach().float())), _ptr(dw), _ptr(db),
+                                     _ptr(dg), _ptr(dbt), N, K, _stream()), 'clv_ln_fold_bwd')
+    if use_sink:
+        for q in ps:
+            if q is not None:
+                q._clv_ready()
+        return None, None, None, None
+    return (dw.to(weight.dtype), db.to(bias.dtype) if bias is not None else None, dg.to(gamma.dtype),
+            dbt.to(beta.dtype))
+
+
 class _FusedLNLinear(torch.autograd.Function):
-    """(y, s) = (LN_noaffine(a [+ r]) Wf^T + bf,  a + r) in ONE row-streaming kernel: residual add,
-    LayerNorm statistics + standardisation and the projection (swin_transformer_3d.py:450 + :376)."""
+    """(y, s) = (Linear(LayerNorm(a [+ r])),  a + r) in ONE row-streaming kernel: residual add, LayerNorm statistics +
+    standardisation and the projection, the norm's affine part folded into the weights (swin_transformer_3d.py:450
+    + :376).  Takes the raw parameters; the fold and its backward are one small kernel each."""
 
     @staticmethod
-    def forward(ctx, a, r, wf, bf, eps):
-        _need_gpu(a, wf)
+    def forward(ctx, a, r, ln_weight, ln_bias, weight, bias, eps):
+        _need_gpu(a, weight)
         K = a.shape[-1]
-        N = wf.shape[0]
+        N = weight.shape[0]
         a2 = _c(a).view(-1, K)
         r2 = _c(r).view(-1, K) if r is not None else None
-        wt = wf.to(BF16)
+        wt, bf = fold_layernorm(weight, bias, ln_weight, ln_bias)
         out = rowgemm(a2, wt, bf, res=r2, standardise=True, eps=eps)
         xs = out['sum'] if r is not None else a2
         ctx.save_for_backward(xs, out['mean'], out['rstd'], wt)
         ctx.has_res = r is not None
         ctx.shape = a.shape
+        ctx.prefs = (weight, bias, ln_weight, ln_bias)
         y = out['y'].view(a.shape[:-1] + (N,))
         return y, (out['sum'].view(a.shape) if r is not None else None)
 
@@ -301,13 +331,14 @@ class _FusedLNLinear(torch.autograd.Function):
         dxhat = linear_dgrad(dy2, wt)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
         dwf, dbf = linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
-        return dx, (dx if ctx.has_res else None), dwf, dbf, None
+        weight, bias, gamma, beta = ctx.prefs
+        dw, db, dg, dbt = _unfold_grads(dwf, dbf, weight, bias, gamma, beta)
+        return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None
 
 
 def ln_linear(a, r, ln_weight, ln_bias, weight, bias, eps=1e-5):
     """y = Linear(LayerNorm(a [+ r])), s = a + r (None without r)."""
-    wf, bf = fold_layernorm(weight, bias, ln_weight, ln_bias)
-    return _FusedLNLinear.apply(a, r, wf, bf, eps)
+    return _FusedLNLinear.apply(a, r, ln_weight, ln_bias, weight, bias, eps)
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -317,12 +348,12 @@ class _FusedMLP(torch.autograd.Function):
     backward with the residual-path gradient folded in (swin_transformer_3d.py:482-483,262-268,503)."""
 
     @staticmethod
-    def forward(ctx, a, r, wf1, bf1, w2, b2, eps):
-        _need_gpu(a, wf1)
+    def forward(ctx, a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps):
+        _need_gpu(a, w1)
         K = a.shape[-1]
         a2 = _c(a).view(-1, K)
         r2 = _c(r).view(-1, K) if r is not None else None
-        wt1 = wf1.to(BF16)
+        wt1, bf1 = fold_layernorm(w1, b1, ln_weight, ln_bias)
         o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps)
         xs = o1['sum'] if r is not None else a2
         w2b = getattr(w2, '_clv_shadow', None)
@@ -338,6 +369,7 @@ class _FusedMLP(torch.autograd.Function):
         ctx.has_res = r is not None
         ctx.shape = a.shape
         ctx.w2ref, ctx.b2ref = w2, b2
+        ctx.prefs = (w1, b1, ln_weight, ln_bias)
         return out.view(a.shape), (o1['sum'].view(a.shape) if r is not None else None)
 
     @staticmethod
@@ -372,13 +404,14 @@ class _FusedMLP(torch.autograd.Function):
         dxhat = linear_dgrad(dpre, wt1)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
         dwf1, dbf1 = linear_wgrad(dpre, xs, True, xstats=(mean, rstd))
-        return dx, (dx if ctx.has_res else None), dwf1, dbf1, dw2, db2, None
+        w1, b1, gamma, beta = ctx.prefs
+        dw1, db1, dg, dbt = _unfold_grads(dwf1, dbf1, w1, b1, gamma, beta)
+        return dx, (dx if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None
 
 
 def fused_mlp(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps=1e-5):
     """out = fc2(GELU(fc1(LayerNorm(a [+ r])))), s = a + r."""
-    wf1, bf1 = fold_layernorm(w1, b1, ln_weight, ln_bias)
-    return _FusedMLP.apply(a, r, wf1, bf1, w2, b2, eps)
+    return _FusedMLP.apply(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps)
 
 
 def fused_block_supported(C_, hidden):

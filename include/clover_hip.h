@@ -120,6 +120,15 @@ int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const floa
                       const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma, float* dbeta,
                       float* partial, int64_t rows, int32_t C, int32_t is_f32, const ClvLnExtra* extra, void* stream);
 
+/* LayerNorm affine folded into the following Linear (the fused LN + projection kernels, clv_rowgemm with
+ * standardise = 1, consume standardised rows):  wf[n][k] = bf16(w[n][k] * gamma[k]),  bf[n] = b[n] + sum_k w[n][k] beta[k]
+ * (w float [N][K], b float [N] or NULL).  Backward: given d wf (float [N][K]) and d bf (float [N]),
+ * dw / db / dgamma / dbeta are ACCUMULATED into. */
+int clv_ln_fold_fwd(const float* w, const float* b, const float* gamma, const float* beta, void* wf, float* bf,
+                    int32_t N, int32_t K, void* stream);
+int clv_ln_fold_bwd(const float* dwf, const float* dbf, const float* w, const float* gamma, const float* beta,
+                    float* dw, float* db, float* dgamma, float* dbeta, int32_t N, int32_t K, void* stream);
+
 /* ------------------------------------------------------------------ GELU (erf)
  * nn.GELU / HF 'gelu' (swin_transformer_3d.py:264; BertIntermediate; ssl_head.py:53). */
 int clv_gelu_fwd(const void* x, void* y, int64_t n, int32_t is_f32, void* stream);
