@@ -240,6 +240,9 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+_NOAFFINE_CONST = {}
+
+
 def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
     """dx = LayerNorm-backward of dxhat w.r.t. x for the affine-free standardisation (+ dsum)."""
     rows, C_ = x.shape
@@ -247,8 +250,11 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
     nblk = L.clv_layernorm_bwd_blocks(rows, C_)
     dev = x.device
     partial = torch.empty(2 * nblk * C_, device=dev, dtype=torch.float32)
-    ones = torch.ones(C_, device=dev, dtype=torch.float32)
-    junk = torch.zeros(2 * C_, device=dev, dtype=torch.float32)
+    key = (C_, str(dev))
+    if key not in _NOAFFINE_CONST:          # gamma = 1 and a never-read dgamma / dbeta dump, allocated once
+        _NOAFFINE_CONST[key] = (torch.ones(C_, device=dev, dtype=torch.float32),
+                                torch.zeros(2 * C_, device=dev, dtype=torch.float32))
+    ones, junk = _NOAFFINE_CONST[key]
     dx = torch.empty_like(x)
     ds2 = None
     if dsum is not None:
