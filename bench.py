@@ -276,7 +276,7 @@ def main():
         pairs_s = gb * args.steps / dt
         gf = GF_PER_PAIR.get((args.variant, args.frames))
         res = {
-            'metric': 'video-text pairs/sec (8f x 224^2, 32-tok), full pre-training step',
+            'metric': f'video-text pairs/sec ({args.frames}f x 224^2, {args.tokens}-tok), full pre-training step',
             'value': round(pairs_s, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'hip_graph': graphed, 'tuned_gemm_shapes': tuned,

@@ -59,7 +59,7 @@ class _Timed:
 def _kname(kernel, g):
     """Device-kernel name as rocprofv3 prints it: template <HD, NKT, DROP, MODE> (attention.hip CLV_PICK)."""
     need = (g.N + 15) // 16
-    nkt = next(o for o in (2, 8, 14, 16, 28) if o >= need)
+    nkt = next((o for o in (2, 8, 14, 16, 28) if o >= need), need)       # > 28: the C call reports UNSUPPORTED
     drop = 'true' if (g.dropout_p > 0 and g.mode == 0) else 'false'
     return f'{kernel}<{g.hd}, {nkt}, {drop}, {g.mode}>'
 
