@@ -20,9 +20,10 @@ class BucketedGradReducer:
         self.buckets = []           # [flat_grad, start, end, n_params]
         self.handles = []
         self.pending = []
-        # A parameter may receive SEVERAL gradient contributions per backward (tied weights: BERT's word embedding
-        # is also the MLM decoder, mlm_itm_head.py:36-40).  The first backward only counts them (its buckets all go
-        # out in finish()); from then on a parameter reports ready on its LAST contribution.
+        # A parameter may receive SEVERAL gradient contributions per backward (any weight applied twice, e.g. a tied
+        # embedding; token_type_embeddings is indexed at two places in the fusion encoder, cross_transformer.py:84-94).
+        # The first backward only counts them (its buckets all go out in finish()); from then on a parameter reports
+        # ready on its LAST contribution.
         self.expect = {}            # id(param) -> contributions per backward (known after the first finish())
         self.seen = {}
         self.calibrated = False
