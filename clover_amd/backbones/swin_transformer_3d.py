@@ -384,28 +384,37 @@ class SwinTransformer3D(nn.Module):
                 for p in m.parameters():
                     p.requires_grad = False
 
-    def inflate_weights(self, state_dict):
-        """2D Swin -> 3D inflation of a checkpoint state_dict (reference :130-181)."""
-        state_dict = {k: v for k, v in state_dict.items()
-                      if 'relative_position_index' not in k and 'attn_mask' not in k}
-        w = state_dict['patch_embed.proj.weight']
-        state_dict['patch_embed.proj.weight'] = w.unsqueeze(2).repeat(1, 1, self.patch_size[0], 1, 1) / self.patch_size[0]
-        for k in [k for k in state_dict if 'relative_position_bias_table' in k]:
-            pre = state_dict[k]
-            cur = self.state_dict()[k]
+    def inflate_state_dict(self, state_dict):
+        """2D Swin -> 3D inflation of a checkpoint state_dict, exactly the reference's arithmetic (:130-181):
+        index / mask buffers dropped; patch_embed.proj.weight repeated along time and divided by patch_t; every
+        relative_position_bias_table bicubically resized to (2wh-1)(2ww-1) rows if needed and tiled (2wd-1) times
+        (a head-count mismatch is tiled unresized, as the reference does, and then fails the shape check of the load)."""
+        sd = {k: v for k, v in state_dict.items() if 'relative_position_index' not in k and 'attn_mask' not in k}
+        w = sd['patch_embed.proj.weight']
+        sd['patch_embed.proj.weight'] = w.unsqueeze(2).repeat(1, 1, self.patch_size[0], 1, 1) / self.patch_size[0]
+        own = self.state_dict()
+        for k in [k for k in sd if 'relative_position_bias_table' in k]:
+            pre = sd[k]
             L1, nH1 = pre.size()
-            _, nH2 = cur.size()
+            nH2 = own[k].size(1)
             L2 = (2 * self.window_size[1] - 1) * (2 * self.window_size[2] - 1)
             wd = self.window_size[0]
-            if nH1 != nH2:
-                continue
-            if L1 != L2:
+            if nH1 == nH2 and L1 != L2:
                 S1 = int(L1 ** 0.5)
                 pre = F.interpolate(pre.permute(1, 0).view(1, nH1, S1, S1),
                                     size=(2 * self.window_size[1] - 1, 2 * self.window_size[2] - 1), mode='bicubic')
                 pre = pre.view(nH2, L2).permute(1, 0)
-            state_dict[k] = pre.repeat(2 * wd - 1, 1)
-        return self.load_state_dict(state_dict, strict=False)
+            sd[k] = pre.repeat(2 * wd - 1, 1)
+        return sd
+
+    def inflate_weights(self, state_dict):
+        """Inflate and load (non-strict; entries whose shape does not fit are reported and skipped, as mmcv's
+        load_state_dict does).  -> (missing keys, unexpected keys, shape-mismatched keys)."""
+        sd = self.inflate_state_dict(state_dict)
+        own = self.state_dict()
+        bad = [k for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
+        res = self.load_state_dict({k: v for k, v in sd.items() if k not in bad}, strict=False)
+        return list(res.missing_keys), list(res.unexpected_keys), bad
 
     def init_weights(self, pretrained=None):
         def _init_weights(m):

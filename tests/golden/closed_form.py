@@ -145,3 +145,23 @@ def cf_batch(B, frames=4, size=112, L=16, vocab=1024, tag='b', n_pad=3):
     return dict(imgs=imgs, label=torch.zeros(B, dtype=torch.long), token_ids=token_ids,
                 segment_ids=torch.zeros_like(token_ids), input_mask=input_mask,
                 mlm_label=mlm_label, v_token_mask=vm)
+
+
+def inflate_checkpoint_2d():
+    """A synthetic 2-D Swin checkpoint (closed-form values) for the tiny backbone: same-size tables (13 x 13) in
+    stage 0, a 23 x 23 table (window 12) in stage 1 block 0 to exercise the bicubic resize, plus the keys the
+    inflation must drop.  Shared by make_goldens.py (fed to the reference) and tests/test_host_cpu.py."""
+    C = 48
+    sd = {
+        'patch_embed.proj.weight': cf_float('inflate.proj', (C, 3, 4, 4), 0.1),
+        'patch_embed.proj.bias': cf_float('inflate.projb', (C,), 0.1),
+        'layers.0.blocks.0.attn.relative_position_bias_table': cf_float('inflate.t00', (13 * 13, 3), 0.5),
+        'layers.0.blocks.1.attn.relative_position_bias_table': cf_float('inflate.t01', (13 * 13, 3), 0.5),
+        'layers.1.blocks.0.attn.relative_position_bias_table': cf_float('inflate.t10', (23 * 23, 6), 0.5),
+        'layers.1.blocks.1.attn.relative_position_bias_table': cf_float('inflate.t11', (13 * 13, 5), 0.5),   # nH mismatch: skipped
+        'layers.0.blocks.0.attn.relative_position_index': torch.zeros(49, 49, dtype=torch.long),
+        'layers.0.blocks.1.attn_mask': torch.zeros(4, 49, 49),
+        'layers.0.blocks.0.attn.qkv.weight': cf_float('inflate.qkv', (3 * C, C), 0.05),
+        'norm.weight': cf_float('inflate.norm', (2 * C,), 0.2) + 1.0,
+    }
+    return sd

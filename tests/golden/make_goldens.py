@@ -7,7 +7,7 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, dist.
+Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate.
 """
 import json
 import os
@@ -206,6 +206,29 @@ GRAD_KEYS = ['backbone.patch_embed.proj.weight', 'backbone.mask_token',
              'mlm_ssl_V_head.img_fc1.weight', 'mlm_ssl_T_head.fc2.bias']
 
 
+
+# --------------------------------------------------------------------------- #
+def gen_inflate():
+    """The reference's own SwinTransformer3D.inflate_weights (:130-181) on the synthetic 2-D checkpoint."""
+    H.install_shims()
+    import mmaction.models.backbones.swin_transformer_3d as R
+    captured = {}
+    R.load_state_dict = lambda module, sd, strict, logger: captured.update(sd)      # the (stubbed) mmcv loader
+    path = os.path.join(SCRATCH, 'swin2d_synth.pth')
+    os.makedirs(SCRATCH, exist_ok=True)
+    torch.save({'state_dict': cf.inflate_checkpoint_2d()}, path)
+    cfg = cf.tiny_model_cfg()['backbone']
+    bb = R.SwinTransformer3D(**{k: v for k, v in cfg.items() if k != 'type'})
+
+    class _Log:
+        def info(self, *a, **k): pass
+        def warning(self, *a, **k): pass
+    bb.pretrained = path
+    bb.inflate_weights(_Log())
+    out = {k: v.detach().cpu().numpy() for k, v in captured.items()}
+    out['__keys__'] = np.array(sorted(captured.keys()))
+    save('g_inflate.npz', out)
+
 def _step(m, batch):
     aux = {k: batch[k] for k in cf.AUX}
     losses = m(batch['imgs'], batch['label'], return_loss=True, **aux)
@@ -288,7 +311,7 @@ def gen_dist():
 
 
 SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
-            step=gen_step, dist=gen_dist)
+            step=gen_step, dist=gen_dist, inflate=gen_inflate)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SETS)

@@ -162,3 +162,27 @@ def test_lazy_log_vars_and_parse_losses():
     loss, log_vars = R()._parse_losses({'mlm_loss': torch.tensor(1.0), 'acc': torch.tensor(0.5),
                                         'x_loss': [torch.tensor([1.0, 3.0])]})
     assert float(loss) == 3.0 and log_vars['loss'] == 3.0 and log_vars['acc'] == 0.5     # 'acc' not summed
+
+
+def test_swin_2d_to_3d_inflation_matches_reference():
+    """SwinTransformer3D.inflate_weights vs the reference's own function run on the same synthetic 2-D
+    checkpoint (tests/golden/make_goldens.py::gen_inflate): patch-embed repeat / patch_t, table tiling (2wd-1),
+    bicubic 23x23 -> 13x13 resize, dropped buffers, head-count mismatch skipped at load."""
+    import clover_amd
+    from clover_amd.builder import build_backbone
+    g = gutil.load('g_inflate.npz')
+    cfg = cf.tiny_model_cfg()['backbone']
+    bb = build_backbone(dict(cfg))
+    sd = bb.inflate_state_dict(cf.inflate_checkpoint_2d())
+    assert sorted(sd) == sorted(str(k) for k in g['__keys__'])
+    for k in sd:
+        ref = g[k]
+        assert tuple(sd[k].shape) == ref.shape, k
+        assert np.abs(sd[k].numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
+    before = bb.layers[1].blocks[1].attn.relative_position_bias_table.detach().clone()
+    missing, unexpected, bad = bb.inflate_weights(cf.inflate_checkpoint_2d())
+    assert bad == ['layers.1.blocks.1.attn.relative_position_bias_table'] and not unexpected
+    assert torch.equal(bb.layers[1].blocks[1].attn.relative_position_bias_table, before)       # left untouched
+    assert torch.allclose(bb.layers[1].blocks[0].attn.relative_position_bias_table,
+                          torch.from_numpy(g['layers.1.blocks.0.attn.relative_position_bias_table']), atol=1e-6)
+    assert torch.allclose(bb.patch_embed.proj.weight, torch.from_numpy(g['patch_embed.proj.weight']), atol=1e-7)
