@@ -284,6 +284,22 @@ class CloverEngine:
         for seg in self.segments:
             seg.flat_g.zero_()
 
+    def optimizer_state(self):
+        """AdamW state for checkpoints: per segment the flat moments + names/offsets, and the step count."""
+        return dict(step=self.step_count,
+                    segments=[dict(names=list(sg.names), offsets=list(sg.offsets), weight_decay=sg.weight_decay,
+                                   exp_avg=sg.exp_avg.detach().cpu(), exp_avg_sq=sg.exp_avg_sq.detach().cpu())
+                              for sg in self.segments])
+
+    def load_optimizer_state(self, state):
+        self.step_count = int(state['step'])
+        for sg, st in zip(self.segments, state['segments']):
+            assert list(sg.names) == list(st['names']), 'optimizer state belongs to a different parameter layout'
+            sg.exp_avg.copy_(st['exp_avg'])
+            sg.exp_avg_sq.copy_(st['exp_avg_sq'])
+        for sg in self.segments:                         # params may have been reloaded: refresh the bf16 shadow
+            sg.shadow.copy_(sg.flat_p)
+
     def grad_norm(self):
         """Global gradient norm of the last step's (averaged) gradients — host sync, logging only."""
         return float(self.sumsq.sqrt().item()) / self.world

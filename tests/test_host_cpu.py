@@ -186,3 +186,79 @@ def test_swin_2d_to_3d_inflation_matches_reference():
     assert torch.allclose(bb.layers[1].blocks[0].attn.relative_position_bias_table,
                           torch.from_numpy(g['layers.1.blocks.0.attn.relative_position_bias_table']), atol=1e-6)
     assert torch.allclose(bb.patch_embed.proj.weight, torch.from_numpy(g['patch_embed.proj.weight']), atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- runner / config
+def test_config_base_merge_and_cfg_options(tmp_path):
+    from clover_amd.runner import Config, parse_cfg_options, scaled_lr
+    (tmp_path / 'base.py').write_text("model = dict(type='X', backbone=dict(depth=2, width=8), head=dict(a=1))\n"
+                                      "total_epochs = 3\nlog_config = dict(interval=10)\n")
+    (tmp_path / 'child.py').write_text("_base_ = ['base.py']\nvideos_per_gpu = 4\n"
+                                       "model = dict(backbone=dict(depth=4), head=dict(_delete_=True, b=2))\n"
+                                       "optimizer = dict(type='AdamW', base_lr=1e-4, weight_decay=0.1)\n")
+    cfg = Config.fromfile(str(tmp_path / 'child.py'))
+    assert cfg.model.type == 'X' and cfg.model.backbone == dict(depth=4, width=8)      # recursive merge
+    assert cfg.model.head == dict(b=2)                                                # _delete_ replaces
+    assert cfg.total_epochs == 3 and cfg.log_config.interval == 10
+    cfg.merge_from_dict(parse_cfg_options(['model.backbone.width=16', 'total_epochs=1', 'tag=run7', 'x.y=[1,2]']))
+    assert cfg.model.backbone.width == 16 and cfg.total_epochs == 1 and cfg.tag == 'run7' and cfg.x.y == [1, 2]
+    # linear scaling rule, tools/train.py:160-166: base_lr is popped, lr = base_lr * videos_per_gpu * world_size
+    assert abs(scaled_lr(cfg, 8) - 1e-4 * 4 * 8) < 1e-12 and 'base_lr' not in cfg.optimizer
+    assert scaled_lr(cfg, 2) == cfg.optimizer['lr']                                   # second call: nothing to scale
+
+
+class _FakeStepper(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.seen = []
+
+    def train_step(self, batch, optimizer):
+        self.seen.append(batch)
+        return dict(loss=torch.tensor(float(len(self.seen))), log_vars=dict(loss=float(len(self.seen))), num_samples=1)
+
+
+def test_runner_multi_loader_interleave_and_hooks(tmp_path):
+    """clover_runner.py:60-96: one step per loader per batch index; once the shorter loader runs out it is
+    restarted and from then on EVERY slot of a row draws from the restarted iterator (the longer loader's own batch
+    of that row is dropped) — reproduced, it decides which samples the reference trains on."""
+    from clover_amd.runner import CheckpointHook, CloverRunner, Hook, LogHook
+    A, B = [f'a{i}' for i in range(5)], [f'b{i}' for i in range(3)]
+    calls = []
+
+    class Spy(Hook):
+        def before_run(self, r): calls.append('before_run')
+        def before_train_epoch(self, r): calls.append('before_epoch')
+        def before_train_iter(self, r): calls.append('bi')
+        def after_train_iter(self, r): calls.append('ai')
+        def after_train_epoch(self, r): calls.append('after_epoch')
+        def after_run(self, r): calls.append('after_run')
+    m = _FakeStepper()
+    r = CloverRunner(m, max_epochs=1, work_dir=str(tmp_path))
+    log = LogHook(interval=1)
+    for h in (Spy(), log, CheckpointHook(str(tmp_path))):
+        r.register_hook(h)
+    r.run([A, B], [('train', 1)], 1)
+    assert m.seen == ['a0', 'b0', 'a1', 'b1', 'a2', 'b2', 'a3', 'b0', 'b1', 'b2']
+    assert r.iter == 5 and r.epoch == 1                      # :91 counts batch indices
+    assert calls == ['before_run', 'before_epoch'] + ['bi', 'ai'] * 10 + ['after_epoch', 'after_run']
+    assert [rec['loss'] for rec in log.records] == [float(i) for i in range(1, 11)]
+    # single loader mode (:17-35) and the checkpoint layout {'meta','state_dict','optimizer'?}
+    m2 = _FakeStepper()
+    r2 = CloverRunner(m2, max_epochs=2, work_dir=str(tmp_path))
+    r2.run([A], [('train', 1)])
+    assert m2.seen == A + A and r2.iter == 10 and r2.epoch == 2
+    ck = torch.load(str(tmp_path / 'epoch_1.pth'))
+    assert set(ck) >= {'meta', 'state_dict'} and ck['meta']['epoch'] == 1 and 'w' in ck['state_dict']
+    r3 = CloverRunner(_FakeStepper(), max_epochs=3)
+    r3.resume(str(tmp_path / 'epoch_1.pth'))
+    assert r3.epoch == 1 and r3.iter == 5
+
+
+def test_runner_short_loader_runs_dry_like_the_reference():
+    """With too short a second loader the restarted iterator is exhausted mid-epoch and `next()` raises — the
+    reference has no guard (clover_runner.py:80-82) and neither has the drop-in."""
+    from clover_amd.runner import CloverRunner
+    r = CloverRunner(_FakeStepper(), max_epochs=1)
+    with pytest.raises(StopIteration):
+        r.run([['a0', 'a1', 'a2'], ['b0']], [('train', 1)])
