@@ -7,7 +7,7 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate.
+Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test.
 """
 import json
 import os
@@ -264,6 +264,22 @@ def gen_step():
     save('g_step.npz', out)
 
 
+def gen_test():
+    """forward_test(separate_test=True) of the reference (:194-218): video / text embeddings for retrieval."""
+    m, _ = ref_model()
+    m.eval()
+    H.init_dist_single()
+    out = {}
+    for B in [1, 3]:
+        batch = cf.cf_batch(B, tag=f'test{B}')
+        with torch.no_grad():
+            v, t = m.forward_test(batch['imgs'], token_ids=batch['token_ids'], segment_ids=batch['segment_ids'],
+                                  input_mask=batch['input_mask'])
+        full(out, f'B{B}.visual_emb', v)
+        full(out, f'B{B}.text_emb', t)
+    save('g_test.npz', out)
+
+
 def _dist_worker(rank, W, port, ret):
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -311,7 +327,7 @@ def gen_dist():
 
 
 SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
-            step=gen_step, dist=gen_dist, inflate=gen_inflate)
+            step=gen_step, dist=gen_dist, inflate=gen_inflate, test=gen_test)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SETS)

@@ -108,6 +108,28 @@ def test_heads(model):
             assert abs(l['rank_t_tm_loss'].item() - float(g[f'nce.G{G}.rank_t_tm_loss'])) < 1e-3
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_forward_test_embeddings(model, B):
+    """``forward_test(separate_test=True)`` (multimodal_transformer_pretrain.py:194-218) — one Swin
+    pass + one BERT pass + the two projection heads — against the reference's own embeddings."""
+    g = gutil.load('g_test.npz')
+    batch = to_dev(cf.cf_batch(B, tag=f'test{B}'))
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            v, t = model.forward_test(batch['imgs'], token_ids=batch['token_ids'], segment_ids=batch['segment_ids'],
+                                      input_mask=batch['input_mask'])
+            v2, t2 = model(batch['imgs'], None, return_loss=False, token_ids=batch['token_ids'],
+                           segment_ids=batch['segment_ids'], input_mask=batch['input_mask'])
+    finally:
+        model.train(was_training)
+    assert v.shape == (B, 128) and t.shape == (B, 128) and v.dtype == torch.float32
+    assert rel(v, g[f'B{B}.visual_emb']) < 2e-2, rel(v, g[f'B{B}.visual_emb'])
+    assert rel(t, g[f'B{B}.text_emb']) < 2e-2, rel(t, g[f'B{B}.text_emb'])
+    assert torch.equal(v, v2) and torch.equal(t, t2)             # BaseRecognizer.forward(return_loss=False) route
+
+
 @pytest.mark.parametrize('B', [1, 2, 4])
 def test_step_losses_and_grads(model, B):
     """BASELINE config 1: full train_step; losses vs the reference's own numbers."""
