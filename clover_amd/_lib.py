@@ -56,6 +56,9 @@ SIGNATURES = {
     'clv_infonce_work_floats': (C.c_int64, [_i32, _i32]),
     'clv_infonce_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _f, _f, _p]),
     'clv_infonce_bwd': (C.c_int, [_p] * 10 + [_i32, _i32, _f, _f, _p]),
+    'clv_normsoftmax_work_floats': (C.c_int64, [_i32, _i32]),
+    'clv_normsoftmax_fwd': (C.c_int, [_p] * 5 + [_i32, _i32, _f, _f, _p]),
+    'clv_normsoftmax_bwd': (C.c_int, [_p] * 6 + [_i32, _i32, _f, _p]),
     'clv_sumsq': (C.c_int, [_p, _p, _i64, _p]),
     'clv_adamw_step': (C.c_int, [_p] * 6 + [_i64] + [_f] * 9 + [_p]),
 }

@@ -272,6 +272,104 @@ __global__ void __launch_bounds__(256) nce_norm_bwd_kernel(NceWork W, float* d0,
     for (int c = lane; c < Dm; c += 64) d[c] = clamped ? de[c] * inv : inv * (de[c] - en[c] * s);
 }
 
+
+// =========================================================================== NormSoftmaxLoss
+// (mmaction/models/losses/contrastive_loss.py:26-68): x = normalise(video) . normalise(text)^T / t,
+// loss = -mean_i diag(log_softmax(x, 1)) - mean_j diag(log_softmax(x^T, 1)).
+// work layout (floats):
+//   en [2][G][Dm], enT [Dm][2][G], den [2][G][Dm], invn [2][G], sim [G][G], dsim [G][G], dsimT [G][G],
+//   lser [G], lsec [G]
+struct NsWork {
+    float *en, *enT, *den, *invn, *sim, *dsim, *dsimT, *lser, *lsec;
+};
+__host__ __device__ inline int64_t ns_work_floats(int G, int Dm) {
+    return (int64_t)2 * G * Dm * 3 + (int64_t)2 * G + (int64_t)G * G * 3 + (int64_t)2 * G + 16;
+}
+__host__ __device__ inline NsWork ns_carve(float* w, int G, int Dm) {
+    NsWork W;
+    W.en = w; w += (int64_t)2 * G * Dm;
+    W.enT = w; w += (int64_t)2 * G * Dm;
+    W.den = w; w += (int64_t)2 * G * Dm;
+    W.invn = w; w += 2 * G;
+    W.sim = w; w += (int64_t)G * G;
+    W.dsim = w; w += (int64_t)G * G;
+    W.dsimT = w; w += (int64_t)G * G;
+    W.lser = w; w += G;
+    W.lsec = w;
+    return W;
+}
+
+// one wave per row: en = e / max(|e|, eps)  (F.normalize eps 1e-12 :51-52, sim_matrix eps 1e-8 :10-18)
+__global__ void __launch_bounds__(256) ns_normalize_kernel(const float* e0, const float* e1, NsWork W, int G, int Dm,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 2 * G) return;
+    const int k = row / G, i = row - k * G;
+    const float* e = (k == 0 ? e0 : e1) + (int64_t)i * Dm;
+    float s = 0.f;
+    for (int d = lane; d < Dm; d += 64) s += e[d] * e[d];
+    const float nrm = sqrtf(wave_sum(s));
+    const float inv = 1.0f / fmaxf(nrm, eps);
+    if (lane == 0) W.invn[row] = nrm >= eps ? inv : -inv;          // sign bit marks the clamped rows
+    for (int d = lane; d < Dm; d += 64) {
+        const float v = e[d] * inv;
+        W.en[(int64_t)row * Dm + d] = v;
+        W.enT[((int64_t)d * 2 + k) * G + i] = v;
+    }
+}
+
+// single block: G row + G column log-sum-exps (one thread each), then the loss.
+__global__ void __launch_bounds__(1024) ns_loss_kernel(NsWork W, const float* __restrict__ sim, float* __restrict__ out,
+                                                       int G) {
+    __shared__ float sh[16];
+    float part = 0.f;
+    for (int t = threadIdx.x; t < 2 * G; t += blockDim.x) {
+        const bool col = t >= G;
+        const int u = col ? t - G : t;
+        const int64_t base = col ? u : (int64_t)u * G, step = col ? G : 1;
+        float m = -INFINITY;
+        for (int j = 0; j < G; ++j) m = fmaxf(m, sim[base + j * step]);
+        float s = 0.f;
+        for (int j = 0; j < G; ++j) s += __expf(sim[base + j * step] - m);
+        const float lse = m + __logf(s);
+        (col ? W.lsec : W.lser)[u] = lse;
+        part += sim[(int64_t)u * G + u] - lse;
+    }
+    const float tot = block_reduce(part, sh, false);
+    if (threadIdx.x == 0) out[0] = -(tot / (float)G);
+}
+
+__global__ void __launch_bounds__(256) ns_dsim_kernel(NsWork W, const float* __restrict__ sim,
+                                                      const float* __restrict__ dout, float* __restrict__ dsim_out,
+                                                      int G) {
+    const int64_t total = (int64_t)G * G;
+    const float g = -dout[0] / (float)G;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / G), j = (int)(idx - (int64_t)i * G);
+        const float x = sim[idx];
+        const float d = g * ((i == j ? 2.f : 0.f) - __expf(x - W.lser[i]) - __expf(x - W.lsec[j]));
+        dsim_out[idx] = d;
+        if (dsim_out == W.dsim) W.dsimT[(int64_t)j * G + i] = d;
+    }
+}
+
+__global__ void __launch_bounds__(256) ns_norm_bwd_kernel(NsWork W, float* d0, float* d1, int G, int Dm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 2 * G) return;
+    const int k = row / G, i = row - k * G;
+    float* d = (k == 0 ? d0 : d1) + (int64_t)i * Dm;
+    const float* en = W.en + (int64_t)row * Dm;
+    const float* de = W.den + (int64_t)row * Dm;
+    float s = 0.f;
+    for (int c = lane; c < Dm; c += 64) s += en[c] * de[c];
+    s = wave_sum(s);
+    const float inv = W.invn[row];
+    const bool clamped = inv < 0.f;
+    for (int c = lane; c < Dm; c += 64) d[c] = clamped ? de[c] * -inv : inv * (de[c] - en[c] * s);
+}
+
 }  // namespace
 
 extern "C" int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
@@ -354,5 +452,50 @@ extern "C" int clv_infonce_bwd(const float* e0, const float* e1, const float* e2
                   (int64_t)G * Dm, it, st);
     if (rc) return rc;
     hipLaunchKernelGGL(nce_norm_bwd_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, W, d0, d1, d2, d3, (int)G, (int)Dm);
+    return clv_check_launch();
+}
+
+extern "C" int64_t clv_normsoftmax_work_floats(int32_t G, int32_t Dm) { return ns_work_floats(G, Dm > 0 ? Dm : 1); }
+
+extern "C" int clv_normsoftmax_fwd(const float* video, const float* text, const float* sim_mat, float* out,
+                                   float* work, int32_t G, int32_t Dm, float temperature, float eps, void* stream) {
+    if (!out || !work || G <= 0) return CLV_ERR_ARG;
+    if (!sim_mat && (!video || !text || Dm <= 0 || temperature <= 0.f || eps <= 0.f)) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NsWork W = ns_carve(work, G, Dm > 0 ? Dm : 1);
+    if (!sim_mat) {
+        hipLaunchKernelGGL(ns_normalize_kernel, dim3((2 * G + 3) / 4), dim3(256), 0, st, video, text, W, (int)G, (int)Dm,
+                           eps);
+        int rc = clv_check_launch();
+        if (rc) return rc;
+        rc = nce_gemm(W.en, W.en + (int64_t)G * Dm, W.sim, G, G, Dm, Dm, Dm, G, 1, 0, 0, 0, 1.0f / temperature, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(ns_loss_kernel, dim3(1), dim3(1024), 0, st, W, sim_mat ? sim_mat : (const float*)W.sim, out,
+                       (int)G);
+    return clv_check_launch();
+}
+
+extern "C" int clv_normsoftmax_bwd(const float* sim_mat, const float* dout, const float* work, float* dvideo,
+                                   float* dtext, float* dsim, int32_t G, int32_t Dm, float temperature,
+                                   void* stream) {
+    if (!dout || !work || G <= 0) return CLV_ERR_ARG;
+    if (sim_mat ? !dsim : (!dvideo || !dtext || Dm <= 0 || temperature <= 0.f)) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NsWork W = ns_carve(const_cast<float*>(work), G, Dm > 0 ? Dm : 1);
+    const int64_t total = (int64_t)G * G;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(ns_dsim_kernel, dim3(grid), dim3(256), 0, st, W, sim_mat ? sim_mat : (const float*)W.sim, dout,
+                       sim_mat ? dsim : W.dsim, (int)G);
+    int rc = clv_check_launch();
+    if (rc || sim_mat) return rc;
+    const float it = 1.0f / temperature;
+    // d en_v[i][d] = sum_j dsim[i][j] en_t[j][d] / t ;  d en_t[j][d] = sum_i dsim[i][j] en_v[i][d] / t
+    rc = nce_gemm(W.dsim, W.enT + G, W.den, G, Dm, G, G, 2 * G, Dm, 1, 0, 0, 0, it, st);
+    if (rc) return rc;
+    rc = nce_gemm(W.dsimT, W.enT, W.den + (int64_t)G * Dm, G, Dm, G, G, 2 * G, Dm, 1, 0, 0, 0, it, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ns_norm_bwd_kernel, dim3((2 * G + 3) / 4), dim3(256), 0, st, W, dvideo, dtext, (int)G, (int)Dm);
     return clv_check_launch();
 }

@@ -196,12 +196,13 @@ class CloverEngine:
                 v.copy_(batch[k], non_blocking=True)
         self.graph.replay()
         emb = self._static_emb.detach().requires_grad_()
-        mlm = self._static_mlm.detach().requires_grad_()
+        mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
         losses = self.model.contrastive_losses(emb, mlm)
         loss, log_vars = self.model._parse_losses(losses)
         loss.backward()
         self._static_demb.copy_(emb.grad)
-        self._static_dmlm.copy_(mlm.grad)
+        if mlm is not None:
+            self._static_dmlm.copy_(mlm.grad)
         self.graph_bwd.replay()
         if self.graph_bwd_video is not None:
             # heads / fusion / text-encoder gradients are complete: put their buckets on the wire, then run the
@@ -217,7 +218,10 @@ class CloverEngine:
         all-gather, InfoNCE/rank losses, logged-scalar all-reduce) stays eager between the two
         replays, so no RCCL call is ever captured and the same code path serves 1..8 GPUs."""
         model = self.model
-        aux = {k: None for k in ('token_ids', 'input_mask', 'mlm_label', 'v_token_mask')}
+        # the recognizer names the batch entries its rank-local part consumes (CloverPretrain: captions + both
+        # masks; CloverFinetune retrieval: captions only) and may return no rank-local loss (mlm is None)
+        aux = {k: None for k in getattr(model, 'CLV_ENCODE_KEYS', ('token_ids', 'input_mask', 'mlm_label',
+                                                                  'v_token_mask'))}
         self._static_batch = {k: v.clone() for k, v in batch.items()}
         sb = self._static_batch
 
@@ -231,7 +235,8 @@ class CloverEngine:
         def backward(emb, mlm, demb, dmlm, cuts):
             """Backward in two pieces when the video encoder is cut off: everything else first (its gradient
             buckets can then travel while the video encoder's backward runs), the video encoder second."""
-            torch.autograd.backward([emb, mlm], [demb, dmlm])
+            torch.autograd.backward([emb] + ([mlm] if mlm is not None else []),
+                                    [demb] + ([dmlm] if mlm is not None else []))
             if cuts:
                 torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
         self.reducer.enabled = False           # no collective may be issued from inside a capture; in graph
@@ -242,7 +247,7 @@ class CloverEngine:
             for _ in range(warmup):
                 cuts = [] if cut_ok else None
                 emb, mlm = encode(cuts)
-                backward(emb, mlm, torch.zeros_like(emb), torch.zeros_like(mlm), cuts)
+                backward(emb, mlm, torch.zeros_like(emb), torch.zeros_like(mlm) if mlm is not None else None, cuts)
         torch.cuda.current_stream().wait_stream(side)
         # no autograd graph may survive into the capture: a live one pins the parameters'
         # AccumulateGrad nodes to the warm-up stream and their accumulation escapes the hipGraph
@@ -257,9 +262,10 @@ class CloverEngine:
         with torch.cuda.graph(gf, capture_error_mode='thread_local'):
             emb, mlm = encode(cuts)
         self._static_demb = torch.zeros_like(emb)
-        self._static_dmlm = torch.zeros_like(mlm)
+        self._static_dmlm = torch.zeros_like(mlm) if mlm is not None else None
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
-            torch.autograd.backward([emb, mlm], [self._static_demb, self._static_dmlm])
+            backward_outs = [emb] + ([mlm] if mlm is not None else [])
+            torch.autograd.backward(backward_outs, [self._static_demb, self._static_dmlm][:len(backward_outs)])
         if cut_ok:
             with torch.cuda.graph(gb2, pool=gf.pool(), capture_error_mode='thread_local'):
                 torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
@@ -297,7 +303,12 @@ class CloverEngine:
             assert list(sg.names) == list(st['names']), 'optimizer state belongs to a different parameter layout'
             sg.exp_avg.copy_(st['exp_avg'])
             sg.exp_avg_sq.copy_(st['exp_avg_sq'])
-        for sg in self.segments:                         # params may have been reloaded: refresh the bf16 shadow
+        self.refresh_shadow()
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 compute copy from the fp32 slabs — after anything that writes parameters behind the
+        optimizer's back (``load_state_dict`` of a checkpoint: it copies into the slab views in place)."""
+        for sg in self.segments:
             sg.shadow.copy_(sg.flat_p)
 
     def grad_norm(self):

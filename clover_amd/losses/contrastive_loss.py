@@ -40,3 +40,33 @@ class ExclusiveNCEwithRankingLoss(nn.Module):
         if self.use_rank and self.use_rank_ttm:
             losses['rank_t_tm_loss'] = rank
         return losses
+
+
+@LOSSES.register_module()
+class NormSoftmaxLoss(nn.Module):
+    """The retrieval fine-tuning loss (mmaction/models/losses/contrastive_loss.py:26-68): all-gather video / text
+    embeddings (``GatherLoss``: the backward keeps the local slice only), normalise, similarity / temperature,
+    -mean diag(log_softmax) in both directions.  The arithmetic after the gather is the fused HIP path
+    ``clv_normsoftmax_fwd/bwd``."""
+
+    def __init__(self, temperature=0.07, cos_sim=False):
+        super().__init__()
+        self.t = temperature
+        self.use_cos_similarity = cos_sim
+        self.fp16_enabled = False
+        self.equal_batch = True                  # GatherLoss (:42-43) requires equal per-rank batches
+
+    @property
+    def rank(self):
+        return get_dist_info()[0]
+
+    @property
+    def world_size(self):
+        return get_dist_info()[1]
+
+    def forward(self, video_embd=None, text_embd=None, sim_mat=None):
+        if sim_mat is not None:                  # :55-56
+            return ops.norm_softmax_loss(sim_mat=sim_mat)
+        v, t = packed_all_gather([video_embd, text_embd], equal_sizes=self.equal_batch)
+        # F.normalize clamps the norm at 1e-12 (:51-52); the cos_sim variant (sim_matrix :10-18) at 1e-8
+        return ops.norm_softmax_loss(v, t, temperature=self.t, eps=1e-8 if self.use_cos_similarity else 1e-12)

@@ -949,6 +949,57 @@ def exclusive_infonce_rank(video, text, text_mask, text_recon, temperature=0.05,
     return _InfoNCE.apply(video, text, text_mask, text_recon, temperature, margin)
 
 
+class _NormSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, video, text, sim_mat, temperature, eps):
+        L = _lib.lib()
+        if sim_mat is not None:
+            _need_gpu(sim_mat)
+            x = _c(sim_mat.float())
+            G, Dm = x.shape[0], 0
+            if x.dim() != 2 or x.shape[1] != G:
+                raise ValueError('NormSoftmaxLoss: sim_mat must be square (the diagonals are the positives)')
+            v = t = None
+        else:
+            _need_gpu(video, text)
+            v, t = _c(video.float()), _c(text.float())
+            G, Dm = v.shape
+            if t.shape != v.shape:
+                raise ValueError(f'NormSoftmaxLoss: video {tuple(v.shape)} vs text {tuple(t.shape)}')
+            x = None
+        dev = (x if x is not None else v).device
+        work = torch.empty(L.clv_normsoftmax_work_floats(G, Dm), device=dev, dtype=torch.float32)
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        check(L.clv_normsoftmax_fwd(_ptr(v), _ptr(t), _ptr(x), _ptr(out), _ptr(work), G, Dm, float(temperature),
+                                    float(eps), _stream()), 'clv_normsoftmax_fwd')
+        ctx.save_for_backward(work, *([x] if x is not None else []))
+        ctx.cfg = (G, Dm, float(temperature), None if x is not None else (video.dtype, text.dtype),
+                   sim_mat.dtype if x is not None else None)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        work, *rest = ctx.saved_tensors
+        G, Dm, temp, dts, sdt = ctx.cfg
+        dout = _c(dloss.float().reshape(1))
+        L = _lib.lib()
+        if rest:
+            dsim = torch.empty_like(rest[0])
+            check(L.clv_normsoftmax_bwd(_ptr(rest[0]), _ptr(dout), _ptr(work), None, None, _ptr(dsim), G, Dm, temp,
+                                        _stream()), 'clv_normsoftmax_bwd')
+            return None, None, dsim.to(sdt), None, None
+        dv = torch.empty(G, Dm, device=work.device, dtype=torch.float32)
+        dt = torch.empty_like(dv)
+        check(L.clv_normsoftmax_bwd(None, _ptr(dout), _ptr(work), _ptr(dv), _ptr(dt), None, G, Dm, temp, _stream()),
+              'clv_normsoftmax_bwd')
+        return dv.to(dts[0]), dt.to(dts[1]), None, None, None
+
+
+def norm_softmax_loss(video=None, text=None, sim_mat=None, temperature=0.07, eps=1e-12):
+    """NormSoftmaxLoss (contrastive_loss.py:26-68) on already-gathered [G,Dm] embeddings or a [G,G] sim_mat."""
+    return _NormSoftmax.apply(video, text, sim_mat, temperature, eps)
+
+
 # --------------------------------------------------------------------------- optimizer primitives
 def sumsq_accumulate(flat_grad, acc):
     _need_gpu(flat_grad, acc)

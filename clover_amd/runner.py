@@ -268,6 +268,8 @@ class CloverRunner:
         sd = ckpt.get('state_dict', ckpt)
         sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}        # DDP prefix
         res = self.model.load_state_dict(sd, strict=strict)
+        if hasattr(self.stepper, 'refresh_shadow'):
+            self.stepper.refresh_shadow()                # the engine computes from a bf16 copy of the weights
         return ckpt, res
 
     def resume(self, path):

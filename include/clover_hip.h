@@ -223,6 +223,20 @@ int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const flo
                     const float* dout, const float* work, float* d0, float* d1, float* d2, float* d3,
                     int32_t G, int32_t Dm, float temperature, float margin, void* stream);
 
+/* NormSoftmaxLoss (mmaction/models/losses/contrastive_loss.py:26-68), the retrieval fine-tuning loss
+ * (multimodal_transformer_finetune.py:83-86): x = normalise(video) . normalise(text)^T / temperature,
+ * out[0] = -mean diag(log_softmax(x, 1)) - mean diag(log_softmax(x^T, 1)).  video/text float [G][Dm];
+ * eps = the norm clamp (1e-12 for F.normalize :51-52, 1e-8 for cos_sim :10-18).  When sim_mat (float
+ * [G][G]) is given it is used as x and video/text/Dm/temperature/eps are ignored (:55-56).
+ * work: float scratch >= clv_normsoftmax_work_floats(G, Dm). */
+int64_t clv_normsoftmax_work_floats(int32_t G, int32_t Dm);
+int clv_normsoftmax_fwd(const float* video, const float* text, const float* sim_mat, float* out, float* work,
+                        int32_t G, int32_t Dm, float temperature, float eps, void* stream);
+/* dout float [1]; `work` is the buffer the forward filled.  Without sim_mat: dvideo/dtext float [G][Dm]
+ * (dsim ignored); with sim_mat: dsim float [G][G] (dvideo/dtext ignored). */
+int clv_normsoftmax_bwd(const float* sim_mat, const float* dout, const float* work, float* dvideo, float* dtext,
+                        float* dsim, int32_t G, int32_t Dm, float temperature, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * Grad-norm (clip_grad_norm_, mmcv_Fp16OptimizerHook.py:127-137) + AdamW step on flat
  * buffers (optimizer cfg pretrain_webvid_cc3m.py:129-137).

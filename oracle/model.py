@@ -453,6 +453,61 @@ def forward_train(P, batch, cfg, gather=True):
     return losses
 
 
+# --------------------------------------------------------------------------- #
+# retrieval fine-tuning
+# --------------------------------------------------------------------------- #
+def norm_softmax_loss(video=None, text=None, sim_mat=None, temperature=0.07, cos_sim=False, gather=True):
+    """NormSoftmaxLoss.forward — contrastive_loss.py:39-68."""
+    if sim_mat is None:
+        if gather:
+            video, text = gather_rows(video), gather_rows(text)
+        if cos_sim:                                                   # sim_matrix :10-18, eps 1e-8
+            x = cos_norm(video) @ cos_norm(text).t() / temperature
+        else:                                                         # F.normalize :51-53, eps 1e-12
+            vn = video / video.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+            tn = text / text.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+            x = vn @ tn.t() / temperature
+    else:
+        x = sim_mat
+    idiag = torch.diag(F.log_softmax(x, dim=1))
+    jdiag = torch.diag(F.log_softmax(x.t(), dim=1))
+    return -(idiag.sum() / len(idiag)) - (jdiag.sum() / len(jdiag))
+
+
+def recall_metrics(video, text):
+    """recall_for_video_text_retrieval — core/evaluation/accuracy.py:430-462 (numpy; rows with zero norm
+    are left unscaled, mmaction/utils/numpy_norm.py:5-8).  Returns [R@1, R@5, R@10, MR, Recall@all]."""
+    def unit(a):
+        n = np.linalg.norm(a, axis=-1)
+        n[n == 0] = 1
+        return a / n[:, None]
+    scores = unit(np.asarray(text)) @ unit(np.asarray(video)).T
+    rank = np.where(np.argsort(-scores, axis=1) == np.arange(len(scores))[:, None])[1]
+    r = [100.0 * np.mean(rank == 0), 100.0 * np.mean(rank < 5), 100.0 * np.mean(rank < 10), np.median(rank) + 1]
+    return np.array(r + [r[0] + r[1] + r[2] - r[3]])
+
+
+def finetune_embeddings(P, batch, cfg):
+    """CloverFinetune retrieval encoders — multimodal_transformer_finetune.py:61-84 (train) and :128-148
+    (separate_test): (visual_emb, text_emb).  imgs [B, clips, 3, T, H, W]; several clips per sample are
+    averaged after the video encoder (:73-75)."""
+    imgs = batch['imgs'].reshape((-1,) + batch['imgs'].shape[2:])
+    B_text = batch['token_ids'].shape[0]
+    token_ids = batch['token_ids'].reshape((-1,) + batch['token_ids'].shape[2:])
+    tmask = batch['input_mask'].reshape((-1,) + batch['input_mask'].shape[2:])
+    visual_token = swin_forward(P, 'backbone.', imgs, cfg['backbone'])
+    if B_text != visual_token.shape[0]:
+        visual_token = visual_token.reshape((B_text, -1) + visual_token.shape[1:]).mean(dim=1)
+    text = bert_forward(P, 'text_backbone.', token_ids, tmask, cfg['bert'])
+    return nce_mm_forward_vision(P, 'ssl_head.', visual_token), nce_mm_forward_text(P, 'ssl_head.', text)
+
+
+def finetune_forward_train(P, batch, cfg, temperature=0.05, cos_sim=True, gather=True):
+    """CloverFinetune.forward_train(task='retrieval') — multimodal_transformer_finetune.py:59-86."""
+    v, t = finetune_embeddings(P, batch, cfg)
+    return {'retrieval_nce_loss': norm_softmax_loss(v, t, temperature=temperature, cos_sim=cos_sim, gather=gather)}
+
+
 def parse_losses(losses):
     """BaseRecognizer._parse_losses — recognizers/base.py:254-288 (single process:
     loss = sum of every key containing 'loss'; log_vars as python floats)."""

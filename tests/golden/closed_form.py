@@ -52,6 +52,19 @@ def tiny_model_cfg(drop=0.0):
         train_cfg=dict(aux_info=list(AUX)))
 
 
+def tiny_finetune_cfg(cos_sim=True, temperature=0.05):
+    """The retrieval fine-tuning model (configs/exp_local/finetune_msrvtt_retrieval.py:23-74) at the tiny widths
+    of ``tiny_model_cfg``: same encoders and ssl_head (so the same closed-form weights by name), NormSoftmaxLoss."""
+    base = tiny_model_cfg()
+    return dict(
+        type='CloverFinetune', freeze_stage=None, separate_test=True, backbone=base['backbone'],
+        freeze_text_backbone=None, text_vocab_size=1024, mm_backbone=base['mm_backbone'],
+        text_backbone=base['text_backbone'], cls_head=None, task='retrieval', ssl_head=base['ssl_head'],
+        itm_head=None, loss_type=dict(type='NormSoftmaxLoss', cos_sim=cos_sim, temperature=temperature),
+        train_cfg=dict(aux_info=['token_ids', 'segment_ids', 'input_mask']),
+        test_cfg=dict(feature_extraction=False))
+
+
 def oracle_cfg_from(model_cfg, bert_cfg=TINY_BERT):
     """The oracle's compact cfg derived from a reference-format model cfg."""
     bb = {k: v for k, v in model_cfg['backbone'].items()

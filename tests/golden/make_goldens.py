@@ -7,7 +7,7 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test.
+Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test, finetune.
 """
 import json
 import os
@@ -280,6 +280,98 @@ def gen_test():
     save('g_test.npz', out)
 
 
+FT_GRAD_KEYS = ['backbone.patch_embed.proj.weight', 'backbone.layers.0.blocks.1.attn.relative_position_bias_table',
+                'backbone.layers.1.blocks.1.attn.qkv.weight', 'text_backbone.bert.embeddings.word_embeddings.weight',
+                'text_backbone.bert.encoder.layer.1.attention.self.query.weight', 'ssl_head.img_projector.0.weight',
+                'ssl_head.text_projector.0.weight']
+
+
+def gen_finetune():
+    """the retrieval fine-tuning path of the reference —
+    NormSoftmaxLoss (losses/contrastive_loss.py:26-68), recall_for_video_text_retrieval
+    (core/evaluation/accuracy.py:430-462) and CloverFinetune(task='retrieval')
+    (recognizers/multimodal_transformer_finetune.py:59-86, :128-148)."""
+    H.init_dist_single()
+    m_cfg = cf.tiny_finetune_cfg()
+    H.make_bert_dir(SCRATCH, hidden=cf.TINY_BERT['hidden_size'], layers=cf.TINY_BERT['num_hidden_layers'],
+                    heads=cf.TINY_BERT['num_attention_heads'], inter=cf.TINY_BERT['intermediate_size'],
+                    vocab=cf.TINY_BERT['vocab_size'], max_pos=cf.TINY_BERT['max_position_embeddings'])
+    m = H.build_reference_model(m_cfg, SCRATCH)
+    manifest = {k: list(v.shape) for k, v in m.state_dict().items()}
+    missing, unexpected = m.load_state_dict(cf.cf_state(manifest), strict=False)
+    assert all('relative_position_index' in k for k in missing) and not unexpected
+    m.eval()
+    out = {}
+
+    # ---- the loss alone, on closed-form embeddings (values + input gradients)
+    from mmaction.models.losses.contrastive_loss import NormSoftmaxLoss
+    for cos in (False, True):
+        for G in (1, 2, 4, 8, 33):
+            for Dm in (128, 50):
+                tag = f'loss.cos{int(cos)}.G{G}.D{Dm}'
+                v = cf.cf_float(tag + '.v', (G, Dm), 1.3).requires_grad_()
+                t = cf.cf_float(tag + '.t', (G, Dm), 0.9, 0.1).requires_grad_()
+                loss = NormSoftmaxLoss(temperature=0.07 if not cos else 0.05, cos_sim=cos)(v, t)
+                loss.backward()
+                out[tag] = np.float64(loss.item())
+                full(out, tag + '.dv', v.grad)
+                full(out, tag + '.dt', t.grad)
+    # zero-norm row: F.normalize / sim_matrix clamp the norm instead of dividing by zero
+    for cos in (False, True):
+        v = cf.cf_float('loss.zero.v', (4, 32), 1.0)
+        v[2] = 0
+        v.requires_grad_()
+        t = cf.cf_float('loss.zero.t', (4, 32), 1.0).requires_grad_()
+        loss = NormSoftmaxLoss(temperature=0.07, cos_sim=cos)(v, t)
+        loss.backward()
+        out[f'loss.zero.cos{int(cos)}'] = np.float64(loss.item())
+        full(out, f'loss.zero.cos{int(cos)}.dt', t.grad)
+    x = cf.cf_float('loss.sim', (6, 6), 9.0).requires_grad_()
+    loss = NormSoftmaxLoss()(sim_mat=x)
+    loss.backward()
+    out['loss.sim'] = np.float64(loss.item())
+    full(out, 'loss.sim.dx', x.grad)
+
+    # ---- retrieval metrics
+    from mmaction.core.evaluation.accuracy import recall_for_video_text_retrieval
+    for N, D in ((1, 8), (7, 16), (50, 32), (200, 64)):
+        ve = cf.cf_float(f'recall.N{N}.v', (N, D), 1.0).numpy()
+        te = (0.35 * ve + cf.cf_float(f'recall.N{N}.t', (N, D), 1.0).numpy()).astype(np.float32)
+        if N == 7:
+            te[3] = 0                       # zero row: normalize_fn leaves it untouched
+        r = recall_for_video_text_retrieval(ve, te)
+        out[f'recall.N{N}'] = np.array([r['Recall@1'], r['Recall@5'], r['Recall@10'], r['MR'], r['Recall@all']],
+                                       dtype=np.float64)
+    sc = cf.cf_float('recall.scores', (12, 12), 1.0).numpy()
+    r = recall_for_video_text_retrieval(input_scores=sc)
+    out['recall.scores'] = np.array([r['Recall@1'], r['Recall@5'], r['Recall@10'], r['MR'], r['Recall@all']])
+
+    # ---- the model: training step (loss + gradients) and separate_test inference (one clip and two clips/sample)
+    aux = ['token_ids', 'segment_ids', 'input_mask']
+    for B in (2, 4):
+        batch = cf.cf_batch(B, tag=f'ft{B}')
+        m.zero_grad()
+        losses = m(batch['imgs'], batch['label'], return_loss=True, **{k: batch[k] for k in aux})
+        loss, lv = m._parse_losses(losses)
+        loss.backward()
+        for k, v in lv.items():
+            out[f'train.B{B}.{k}'] = np.float64(v)
+        named = dict(m.named_parameters())
+        for k in FT_GRAD_KEYS:
+            pack(out, f'train.B{B}.grad.{k}', named[k].grad)
+        out[f'train.B{B}.n_unused'] = np.int64(sum(p.grad is None for p in named.values()))
+    batch = cf.cf_batch(4, tag='ft_test')
+    with torch.no_grad():
+        v, t = m.forward_test(batch['imgs'], **{k: batch[k] for k in aux})
+        full(out, 'test.clips1.visual_emb', v)
+        full(out, 'test.clips1.text_emb', t)
+        imgs2 = batch['imgs'].reshape((2, 2) + tuple(batch['imgs'].shape[2:]))
+        v, t = m.forward_test(imgs2, **{k: batch[k][:2] for k in aux})
+        full(out, 'test.clips2.visual_emb', v)
+        full(out, 'test.clips2.text_emb', t)
+    save('g_finetune.npz', out)
+
+
 def _dist_worker(rank, W, port, ret):
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -327,7 +419,7 @@ def gen_dist():
 
 
 SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
-            step=gen_step, dist=gen_dist, inflate=gen_inflate, test=gen_test)
+            step=gen_step, dist=gen_dist, inflate=gen_inflate, test=gen_test, finetune=gen_finetune)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SETS)

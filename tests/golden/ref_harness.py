@@ -147,8 +147,14 @@ def install_shims():
             return f
         return deco
     import logging
+    # mmaction/utils/__init__.py pulls mmcv-only modules; numpy_norm.py (normalize_fn, used by the retrieval
+    # metrics) is self-contained and is loaded from the reference file itself
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mmaction.utils.numpy_norm', R + '/utils/numpy_norm.py')
+    numpy_norm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(numpy_norm)
     _mod('mmaction.utils', get_root_logger=lambda *a, **k: logging.getLogger('ref'),
-         import_module_error_func=import_module_error_func)
+         import_module_error_func=import_module_error_func, normalize_fn=numpy_norm.normalize_fn)
 
     # transformers 4.6.1 extended-mask semantics (install.sh:25 pins 4.6.1)
     from transformers.modeling_utils import ModuleUtilsMixin
@@ -205,6 +211,7 @@ def build_reference_model(cfg_dict, scratch):
         import mmaction.models.losses.focal_loss  # noqa: F401
         import mmaction.models.losses.cross_entropy_loss  # noqa: F401
         import mmaction.models.recognizers.multimodal_transformer_pretrain  # noqa: F401
+        import mmaction.models.recognizers.multimodal_transformer_finetune  # noqa: F401
         from mmaction.models.builder import build_model
         model = build_model(cfg_dict)
     finally:

@@ -97,6 +97,51 @@ def test_graph_capture_equals_eager_and_loss_decreases():
     assert traj['graph'][-1] < traj['graph'][0] - 0.5          # the step actually trains
 
 
+def make_finetune_model():
+    import clover_amd
+    m = clover_amd.build_model(cf.tiny_finetune_cfg())
+    sd = {k: v for k, v in cf.cf_state(gutil.manifest()).items() if k in m.state_dict()}
+    m.load_state_dict(sd, strict=False)
+    return m.to(DEV).eval()
+
+
+def test_finetune_engine_graph_equals_eager_and_trains(monkeypatch):
+    """the retrieval fine-tuning recognizer through the same engine — eager steps, hipGraph steps
+    (no rank-local loss: the backward graph has one root), and the 1-rank RCCL path with the video-encoder cut."""
+    import os
+    import torch.distributed as dist
+    from clover_amd.engine import CloverEngine
+    b = batch(4, 'fteng')
+
+    def run(mode):
+        m = make_finetune_model()
+        eng = CloverEngine(m, b, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, bucket_mb=1)
+        # the fusion encoder (built, never run by the retrieval task), the mask token, BERT's pooler: as in the reference
+        assert len(eng.unused_names) == int(gutil.load('g_finetune.npz')['train.B4.n_unused'])
+        assert any(n.startswith('multimodal_backbone.') for n in eng.unused_names)
+        eng.step(b)
+        if mode != 'eager':
+            assert eng.capture(b)
+        return [eng.step(b)['log_vars']['loss'] for _ in range(6)], eng
+
+    eager, _ = run('eager')
+    graph, eng = run('graph')
+    assert eng.graph_bwd_video is None
+    monkeypatch.setenv('CLOVER_FORCE_COLLECTIVES', '1')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29563')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        rccl, eng = run('rccl')
+        assert eng.reducer.active and eng.graph_bwd_video is not None
+    finally:
+        dist.destroy_process_group()
+    print(eager, graph, rccl)
+    for a, g, r in zip(eager, graph, rccl):
+        assert abs(a - g) < 0.05 * max(1.0, abs(a)) and abs(a - r) < 0.05 * max(1.0, abs(a)), (eager, graph, rccl)
+    assert graph[-1] < graph[0] - 0.2
+
+
 def test_rccl_code_path_on_one_gpu(monkeypatch):
     """The N>1 code path (packed RCCL all-gather with local-slice backward, logged-scalar all-reduce,
     bucketed gradient all-reduce on the side stream, hipGraph mode) on a real 1-rank RCCL group:
@@ -125,3 +170,50 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
         dist.destroy_process_group()
     for a, g in zip(ref, got):
         assert abs(a - g) < 0.02 * max(1.0, abs(a)), (ref, got)
+
+
+def test_checkpoint_roundtrip_through_engine(tmp_path):
+    """save from a trained engine, `load_from` into a fresh one (weights only) and `resume` into another
+    (weights + AdamW moments + counters): the loaded engines must compute from the loaded weights (the bf16 compute
+    copy is re-derived), and the resumed one must continue the trajectory; a pre-training checkpoint loads into
+    the fine-tuning recognizer with only the pre-training heads left over."""
+    from clover_amd.engine import CloverEngine
+    from clover_amd.runner import CloverRunner
+    b = batch(2, 'ckpt')
+    kw = dict(lr=2e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+    e1 = CloverEngine(make_model(), b, **kw)
+    for _ in range(3):
+        e1.step(b)
+    r1 = CloverRunner(e1, work_dir=str(tmp_path), max_epochs=1)
+    r1.save_checkpoint(str(tmp_path), 'a.pth')
+    nxt = [e1.step(b)['log_vars']['loss'] for _ in range(2)]
+
+    m2 = make_model()
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.mul_(0.5)                                   # start from different weights: the load must matter
+    e2 = CloverEngine(m2, b, **kw)
+    CloverRunner(e2, work_dir=str(tmp_path)).load_checkpoint(str(tmp_path / 'a.pth'))
+    for sg in e2.segments:
+        assert torch.equal(sg.shadow, sg.flat_p.to(torch.bfloat16))
+    l2 = e2.step(b)['log_vars']['loss']
+    assert abs(l2 - nxt[0]) < 2e-2 * max(1.0, abs(nxt[0])), (l2, nxt)       # same weights -> same loss
+
+    e3 = CloverEngine(make_model(), b, **kw)
+    r3 = CloverRunner(e3, work_dir=str(tmp_path))
+    r3.resume(str(tmp_path / 'a.pth'))
+    assert e3.step_count == 3
+    got = [e3.step(b)['log_vars']['loss'] for _ in range(2)]
+    for a, g in zip(nxt, got):
+        assert abs(a - g) < 2e-2 * max(1.0, abs(a)), (nxt, got)
+
+    ft = make_finetune_model()
+    eft = CloverEngine(ft, b, lr=2e-4, weight_decay=0.0, grad_clip=5.0, max_iters=10 ** 9)
+    _, res = CloverRunner(eft, work_dir=str(tmp_path)).load_checkpoint(str(tmp_path / 'a.pth'))
+    assert not [k for k in res.missing_keys if 'relative_position_index' not in k]
+    assert res.unexpected_keys and all(k.startswith(('mlm_head.', 'mlm_ssl_V_head.', 'mlm_ssl_T_head.'))
+                                       for k in res.unexpected_keys)
+    p1, pf = dict(e1.model.named_parameters()), dict(ft.named_parameters())
+    # e1 has moved on by two steps since the save; the text encoder moved by at most 2 * lr per weight
+    k = 'text_backbone.bert.encoder.layer.1.attention.self.query.weight'
+    assert (p1[k] - pf[k]).abs().max().item() <= 2.5 * 2e-4

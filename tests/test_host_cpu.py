@@ -262,3 +262,38 @@ def test_runner_short_loader_runs_dry_like_the_reference():
     r = CloverRunner(_FakeStepper(), max_epochs=1)
     with pytest.raises(StopIteration):
         r.run([['a0', 'a1', 'a2'], ['b0']], [('train', 1)])
+
+
+# ----------------------------------------------------------------------------- retrieval metrics
+def test_recall_for_video_text_retrieval_goldens():
+    """clover_amd.evaluation against the reference's own metric values (g_finetune.npz; accuracy.py:430-462)."""
+    from clover_amd.evaluation import normalize_fn, recall_for_video_text_retrieval
+    g = gutil.load('g_finetune.npz')
+    keys = ['Recall@1', 'Recall@5', 'Recall@10', 'MR', 'Recall@all']
+    for N, D in ((1, 8), (7, 16), (50, 32), (200, 64)):
+        ve = cf.cf_float(f'recall.N{N}.v', (N, D), 1.0).numpy()
+        te = (0.35 * ve + cf.cf_float(f'recall.N{N}.t', (N, D), 1.0).numpy()).astype(np.float32)
+        if N == 7:
+            te[3] = 0
+        m = recall_for_video_text_retrieval(ve, te)
+        np.testing.assert_allclose([m[k] for k in keys], g[f'recall.N{N}'], rtol=0, atol=1e-9)
+        mt = recall_for_video_text_retrieval(torch.from_numpy(ve), torch.from_numpy(te))      # tensors accepted
+        assert mt == m
+    sc = cf.cf_float('recall.scores', (12, 12), 1.0).numpy()
+    m = recall_for_video_text_retrieval(input_scores=sc)
+    np.testing.assert_allclose([m[k] for k in keys], g['recall.scores'], rtol=0, atol=1e-9)
+    z = normalize_fn(np.array([[3.0, 4.0], [0.0, 0.0]]))
+    assert np.array_equal(z, np.array([[0.6, 0.8], [0.0, 0.0]]))
+
+
+def test_finetune_registered_and_refuses_without_gpu():
+    """CloverFinetune / NormSoftmaxLoss are registry entries with the reference's constructor kwargs; the loss has
+    no CPU path."""
+    import clover_amd
+    from clover_amd.builder import LOSSES, RECOGNIZERS
+    assert 'CloverFinetune' in RECOGNIZERS.module_dict and 'NormSoftmaxLoss' in LOSSES.module_dict
+    m = clover_amd.build_model(cf.tiny_finetune_cfg())
+    assert m.task == 'retrieval' and m.loss_func.use_cos_similarity and m.loss_func.t == 0.05
+    assert not any(k.startswith(('mlm_head', 'mlm_ssl')) for k in m.state_dict())
+    with pytest.raises(RuntimeError):
+        m.loss_func(torch.randn(4, 8), torch.randn(4, 8))

@@ -233,6 +233,55 @@ def test_infonce(G):
             assert rel(eg[k].grad, er[k].grad) < 2e-3, (k, rel(eg[k].grad, er[k].grad))
 
 
+def test_norm_softmax_loss_goldens():
+    """clv_normsoftmax_fwd/bwd against the reference's own NormSoftmaxLoss numbers (g_finetune.npz): both norm
+    clamps, ragged widths, a zero-norm row, the sim_mat entry."""
+    import closed_form as cf
+    import gutil
+    g = gutil.load('g_finetune.npz')
+    for cos in (False, True):
+        for G in (1, 2, 4, 8, 33):
+            for Dm in (128, 50):
+                tag = f'loss.cos{int(cos)}.G{G}.D{Dm}'
+                v = cf.cf_float(tag + '.v', (G, Dm), 1.3).to(DEV).requires_grad_()
+                t = cf.cf_float(tag + '.t', (G, Dm), 0.9, 0.1).to(DEV).requires_grad_()
+                loss = ops().norm_softmax_loss(v, t, temperature=0.05 if cos else 0.07, eps=1e-8 if cos else 1e-12)
+                loss.backward()
+                ref = float(g[tag])
+                assert abs(loss.item() - ref) < 2e-4 * max(1, abs(ref)), (tag, loss.item(), ref)
+                assert rel(v.grad, torch.from_numpy(g[tag + '.dv'])) < 2e-3, tag
+                assert rel(t.grad, torch.from_numpy(g[tag + '.dt'])) < 2e-3, tag
+        v = cf.cf_float('loss.zero.v', (4, 32), 1.0)
+        v[2] = 0
+        t = cf.cf_float('loss.zero.t', (4, 32), 1.0).to(DEV).requires_grad_()
+        vg = v.to(DEV).requires_grad_()
+        loss = ops().norm_softmax_loss(vg, t, temperature=0.07, eps=1e-8 if cos else 1e-12)
+        loss.backward()
+        assert abs(loss.item() - float(g[f'loss.zero.cos{int(cos)}'])) < 2e-4
+        assert rel(t.grad, torch.from_numpy(g[f'loss.zero.cos{int(cos)}.dt'])) < 2e-3
+        assert torch.isfinite(vg.grad).all()
+    x = cf.cf_float('loss.sim', (6, 6), 9.0).to(DEV).requires_grad_()
+    loss = ops().norm_softmax_loss(sim_mat=x)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss.sim'])) < 2e-4 * abs(float(g['loss.sim']))
+    assert rel(x.grad, torch.from_numpy(g['loss.sim.dx'])) < 2e-3
+
+
+@pytest.mark.parametrize('G,Dm', [(128, 768), (1000, 768)])
+def test_norm_softmax_loss_large(G, Dm):
+    """Fine-tuning sizes (16 videos x 8 ranks; a 1000-pair MSRVTT evaluation split) against the oracle."""
+    v, t = rnd(G, Dm, seed=71), rnd(G, Dm, seed=72)
+    t = 0.5 * v + t
+    vr, tr = v.clone().requires_grad_(), t.clone().requires_grad_()
+    lref = om.norm_softmax_loss(vr, tr, temperature=0.05, cos_sim=True, gather=False)
+    lref.backward()
+    vg, tg = v.to(DEV).requires_grad_(), t.to(DEV).requires_grad_()
+    loss = ops().norm_softmax_loss(vg, tg, temperature=0.05, eps=1e-8)
+    loss.backward()
+    assert abs(loss.item() - lref.item()) < 2e-4 * max(1, abs(lref.item())), (loss.item(), lref.item())
+    assert rel(vg.grad, vr.grad) < 2e-3 and rel(tg.grad, tr.grad) < 2e-3
+
+
 # ----------------------------------------------------------------------------- optimizer
 def test_adamw_and_clip():
     n = 100003

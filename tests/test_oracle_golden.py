@@ -135,3 +135,71 @@ def test_step_config1(P, ocfg, B):
         gutil.assert_packed(g, f'B{B}.grad.{k}', Pg[k].grad, rtol=5e-3, atol=1e-6)  # fp32 summation-order noise through the /0.05 logits
     unused = sorted(k for k, p in Pg.items() if p.grad is None)
     assert unused == gutil.unused_params()
+
+
+# ------------------------------------------------------------------ retrieval fine-tuning
+def _recall_inputs(N, D):
+    ve = cf.cf_float(f'recall.N{N}.v', (N, D), 1.0).numpy()
+    te = (0.35 * ve + cf.cf_float(f'recall.N{N}.t', (N, D), 1.0).numpy()).astype(np.float32)
+    if N == 7:
+        te[3] = 0
+    return ve, te
+
+
+def test_norm_softmax_loss_and_recall():
+    g = gutil.load('g_finetune.npz')
+    for cos in (False, True):
+        for G in (1, 2, 4, 8, 33):
+            for Dm in (128, 50):
+                tag = f'loss.cos{int(cos)}.G{G}.D{Dm}'
+                v = cf.cf_float(tag + '.v', (G, Dm), 1.3).requires_grad_()
+                t = cf.cf_float(tag + '.t', (G, Dm), 0.9, 0.1).requires_grad_()
+                loss = om.norm_softmax_loss(v, t, temperature=0.05 if cos else 0.07, cos_sim=cos, gather=False)
+                loss.backward()
+                gutil.assert_close(loss, g[tag], atol=2e-5, name=tag)
+                gutil.assert_close(v.grad, g[tag + '.dv'], rtol=2e-4, atol=1e-6, name=tag + '.dv')
+                gutil.assert_close(t.grad, g[tag + '.dt'], rtol=2e-4, atol=1e-6, name=tag + '.dt')
+        v = cf.cf_float('loss.zero.v', (4, 32), 1.0)
+        v[2] = 0
+        t = cf.cf_float('loss.zero.t', (4, 32), 1.0).requires_grad_()
+        loss = om.norm_softmax_loss(v, t, temperature=0.07, cos_sim=cos, gather=False)
+        loss.backward()
+        gutil.assert_close(loss, g[f'loss.zero.cos{int(cos)}'], name='zero row')
+        gutil.assert_close(t.grad, g[f'loss.zero.cos{int(cos)}.dt'], rtol=2e-4, atol=1e-6, name='zero row dt')
+    x = cf.cf_float('loss.sim', (6, 6), 9.0).requires_grad_()
+    loss = om.norm_softmax_loss(sim_mat=x)
+    loss.backward()
+    gutil.assert_close(loss, g['loss.sim'])
+    gutil.assert_close(x.grad, g['loss.sim.dx'], rtol=2e-4, atol=1e-6)
+    for N, D in ((1, 8), (7, 16), (50, 32), (200, 64)):
+        np.testing.assert_allclose(om.recall_metrics(*_recall_inputs(N, D)), g[f'recall.N{N}'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('B', [2, 4])
+def test_finetune_retrieval_step(P, ocfg, B):
+    g = gutil.load('g_finetune.npz')
+    Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
+    losses = om.finetune_forward_train(Pg, cf.cf_batch(B, tag=f'ft{B}'), ocfg, gather=False)
+    loss, lv = om.parse_losses(losses)
+    for k in ['retrieval_nce_loss', 'loss']:
+        ref = float(g[f'train.B{B}.{k}'])
+        assert abs(lv[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, lv[k], ref)
+    loss.backward()
+    for k in [n[len(f'train.B{B}.grad.'):-4] for n in g.files if n.startswith(f'train.B{B}.grad.') and n.endswith('.sub')]:
+        gutil.assert_packed(g, f'train.B{B}.grad.{k}', Pg[k].grad, rtol=5e-3, atol=1e-6)
+
+
+def test_finetune_separate_test(P, ocfg):
+    g = gutil.load('g_finetune.npz')
+    batch = cf.cf_batch(4, tag='ft_test')
+    with torch.no_grad():
+        v, t = om.finetune_embeddings(P, batch, ocfg)
+        gutil.assert_close(v, g['test.clips1.visual_emb'], rtol=2e-4, name='visual_emb')
+        gutil.assert_close(t, g['test.clips1.text_emb'], rtol=2e-4, name='text_emb')
+        b2 = dict(batch)
+        b2['imgs'] = batch['imgs'].reshape((2, 2) + tuple(batch['imgs'].shape[2:]))
+        for k in ('token_ids', 'input_mask'):
+            b2[k] = batch[k][:2]
+        v, t = om.finetune_embeddings(P, b2, ocfg)
+        gutil.assert_close(v, g['test.clips2.visual_emb'], rtol=2e-4, name='visual_emb clips2')
+        gutil.assert_close(t, g['test.clips2.text_emb'], rtol=2e-4, name='text_emb clips2')

@@ -153,3 +153,72 @@ def test_step_losses_and_grads(model, B):
         assert e < grad_tol(k), (k, e)
     unused = sorted(k for k, p in named.items() if p.grad is None)
     assert unused == gutil.unused_params()
+
+
+# ----------------------------------------------------------------------------- retrieval fine-tuning
+@pytest.fixture(scope='module')
+def ft_model():
+    import clover_amd
+    m = clover_amd.build_model(cf.tiny_finetune_cfg())
+    sd = {k: v for k, v in cf.cf_state(gutil.manifest()).items() if k in m.state_dict()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert all('relative_position_index' in k for k in missing) and not unexpected
+    return m.to(DEV).eval()
+
+
+FT_AUX = ['token_ids', 'segment_ids', 'input_mask']
+
+
+@pytest.mark.parametrize('B', [2, 4])
+def test_finetune_retrieval_step(ft_model, B):
+    """CloverFinetune(task='retrieval').train_step (multimodal_transformer_finetune.py:59-86) against the
+    reference's own loss and gradients; the oracle on the same inputs as a second witness."""
+    from oracle import model as om
+    g = gutil.load('g_finetune.npz')
+    batch = to_dev(cf.cf_batch(B, tag=f'ft{B}'))
+    ft_model.zero_grad(set_to_none=True)
+    out = ft_model.train_step({k: batch[k] for k in ['imgs', 'label'] + FT_AUX}, None)
+    assert out['num_samples'] == B
+    lv = out['log_vars']
+    assert set(lv) == {'retrieval_nce_loss', 'loss'}
+    ref = float(g[f'train.B{B}.loss'])
+    assert abs(lv['loss'] - ref) <= 3e-2, (lv['loss'], ref)            # cosine logits / 0.05: the nce tolerance
+    P = cf.cf_state(gutil.manifest())
+    o = om.finetune_forward_train(P, cf.cf_batch(B, tag=f'ft{B}'), cf.oracle_cfg_from(cf.tiny_model_cfg()),
+                                  gather=False)['retrieval_nce_loss'].item()
+    assert abs(lv['loss'] - o) <= 3e-2, (lv['loss'], o)
+    out['loss'].backward()
+    named = dict(ft_model.named_parameters())
+    worst = {}
+    for k in [n[len(f'train.B{B}.grad.'):-4] for n in g.files if n.startswith(f'train.B{B}.grad.') and n.endswith('.sub')]:
+        worst[k] = rel_packed(g, f'train.B{B}.grad.{k}', named[k].grad)
+    print('finetune grad rel errors', B, worst)
+    for k, e in worst.items():
+        assert e < 1e-1, (k, e)                                       # every gradient here is contrastive-only
+    assert sum(p.grad is None for p in named.values()) == int(g[f'train.B{B}.n_unused'])
+
+
+def test_finetune_separate_test(ft_model):
+    """forward_test(separate_test=True) (:128-148), one clip and two clips per sample, plus the retrieval metrics
+    of the embeddings (accuracy.py:430-462) through clover_amd.evaluation."""
+    from clover_amd.evaluation import recall_for_video_text_retrieval
+    g = gutil.load('g_finetune.npz')
+    batch = to_dev(cf.cf_batch(4, tag='ft_test'))
+    with torch.no_grad():
+        v, t = ft_model(batch['imgs'], None, return_loss=False, **{k: batch[k] for k in FT_AUX})
+        imgs2 = batch['imgs'].reshape((2, 2) + tuple(batch['imgs'].shape[2:]))
+        v2, t2 = ft_model.forward_test(imgs2, **{k: batch[k][:2] for k in FT_AUX})
+    assert rel(v, g['test.clips1.visual_emb']) < 2e-2 and rel(t, g['test.clips1.text_emb']) < 2e-2
+    assert rel(v2, g['test.clips2.visual_emb']) < 2e-2 and rel(t2, g['test.clips2.text_emb']) < 2e-2
+    m = recall_for_video_text_retrieval(v, t)
+    mr = recall_for_video_text_retrieval(g['test.clips1.visual_emb'], g['test.clips1.text_emb'])
+    assert m == mr
+
+
+def test_finetune_other_tasks_refuse():
+    import clover_amd
+    for task in ('video_qa', 'FIB', None):
+        cfg = cf.tiny_finetune_cfg()
+        cfg['task'] = task
+        with pytest.raises(NotImplementedError):
+            clover_amd.build_model(cfg)
