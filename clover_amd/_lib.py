@@ -37,6 +37,8 @@ SIGNATURES = {
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_attn_bwd_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),
+    'clv_softmax_rows_fwd': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _f, _f, _p]),
+    'clv_softmax_rows_bwd': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _f, _f, _p]),
     'clv_layernorm_fwd': (C.c_int, [_p] * 8 + [_i64, _i32, _f, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_layernorm_bwd_blocks': (C.c_int, [_i64, _i32]),
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, C.POINTER(ClvLnExtra), _p]),

@@ -50,17 +50,6 @@ __device__ __forceinline__ void load_bias_table(const Geom& G, const float* tabl
     for (int n = tid; n < NK; n += nthreads) linb_s[n] = (n < G.g.N) ? 4 * win_lin(G, n) : 0;
 }
 
-// Counter-based dropout mask: a pure function of (seed, (group, head, query) row id, key), so the
-// backward kernels regenerate exactly the forward's mask.  Returns 1/(1-p) (kept) or 0 (dropped).
-__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned rowid, unsigned key, unsigned thresh,
-                                            float inv_keep) {
-    unsigned x = (rowid * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (unsigned)seed;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    x += (unsigned)(seed >> 32);
-    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
-    return (x >= thresh) ? inv_keep : 0.f;
-}
-
 __device__ __forceinline__ int64_t tok_row(const Geom& G, int grp, int n) {
     if (G.g.mode == 0) return (int64_t)grp * G.g.N + n;
     const int b = grp / G.nW, wi = grp - b * G.nW;

@@ -73,6 +73,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Counter-based dropout mask: a pure function of (seed, (group, head, query) row id, key), so the
+// backward kernels regenerate exactly the forward's mask.  Returns 1/(1-p) (kept) or 0 (dropped).
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned rowid, unsigned key, unsigned thresh,
+                                            float inv_keep) {
+    unsigned x = (rowid * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (unsigned)seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += (unsigned)(seed >> 32);
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    return (x >= thresh) ? inv_keep : 0.f;
+}
+
 // erf-GELU with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution):
 // 1 rcp + 1 exp + ~10 fma instead of libm's erff — matters where GELU sits in a GEMM epilogue.
 // Phi(x) = 0.5 (1 + erf(x / sqrt2)); with z = |x| / sqrt2:  erf(z) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p z),

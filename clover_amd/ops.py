@@ -788,11 +788,62 @@ def next_dropout_seed(device):
     return seed
 
 
+SEQ_FUSED_MAX_KEYS = 448          # K / V of one (sample, head) must fit LDS in the fused kernels (28 key tiles)
+
+
+class _LongSeqAttention(torch.autograd.Function):
+    """Self-attention for sequences beyond the fused kernels' LDS budget: batched library GEMMs for Q.K^T / P.V and
+    their gradients, the HIP row-softmax kernels (mask + softmax + dropout, and the backward) between them."""
+
+    @staticmethod
+    def forward(ctx, qkv, kmask, num_heads, dropout_p, seed):
+        _need_gpu(qkv)
+        assert qkv.dtype == BF16
+        B, S, C3 = qkv.shape
+        Cdim = C3 // 3
+        hd = Cdim // num_heads
+        q, k, v = (qkv[..., i * Cdim:(i + 1) * Cdim].view(B, S, num_heads, hd).permute(0, 2, 1, 3) for i in range(3))
+        scores = torch.matmul(q, k.transpose(-1, -2))                         # [B, nH, S, S] bf16
+        p = torch.empty_like(scores)
+        pd = torch.empty_like(scores) if dropout_p > 0 else None
+        km = _c(kmask.float()) if kmask is not None else None
+        scale = float(hd) ** -0.5
+        check(_lib.lib().clv_softmax_rows_fwd(_ptr(scores), _ptr(km), _ptr(p), _ptr(pd), _ptr(seed),
+                                              B * num_heads * S, S, S, num_heads * S, scale, float(dropout_p),
+                                              _stream()), 'clv_softmax_rows_fwd')
+        o = torch.matmul(pd if pd is not None else p, v)                      # [B, nH, S, hd]
+        ctx.save_for_backward(qkv, p, pd, seed)
+        ctx.cfg = (num_heads, hd, scale, float(dropout_p))
+        return o.permute(0, 2, 1, 3).reshape(B, S, Cdim)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, p, pd, seed = ctx.saved_tensors
+        num_heads, hd, scale, dropout_p = ctx.cfg
+        B, S, C3 = qkv.shape
+        Cdim = C3 // 3
+        q, k, v = (qkv[..., i * Cdim:(i + 1) * Cdim].view(B, S, num_heads, hd).permute(0, 2, 1, 3) for i in range(3))
+        doh = do.to(BF16).view(B, S, num_heads, hd).permute(0, 2, 1, 3)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = (dqkv[..., i * Cdim:(i + 1) * Cdim].view(B, S, num_heads, hd).permute(0, 2, 1, 3) for i in range(3))
+        dv.copy_(torch.matmul((pd if pd is not None else p).transpose(-1, -2), doh))
+        ds = torch.matmul(doh, v.transpose(-1, -2))                           # dPd, turned into dS in place
+        check(_lib.lib().clv_softmax_rows_bwd(_ptr(p), _ptr(ds), _ptr(ds), _ptr(seed), B * num_heads * S, S, S,
+                                              scale, dropout_p, _stream()), 'clv_softmax_rows_bwd')
+        dq.copy_(torch.matmul(ds, k))
+        dk.copy_(torch.matmul(ds.transpose(-1, -2), q))
+        return dqkv, None, None, None, None
+
+
 def seq_attention(qkv, kmask, num_heads, dropout_p=0.0):
     """BERT self-attention. qkv bf16 [B,S,3H]; kmask fp32 [B,S] additive ((1-m)*-10000) or None;
-    dropout_p: dropout on the attention probabilities (HF attention_probs_dropout_prob)."""
+    dropout_p: dropout on the attention probabilities (HF attention_probs_dropout_prob).
+    Up to 448 tokens: the fused LDS-resident kernels; longer sequences: the unfused GEMM + row-softmax path."""
     B, S, C3 = qkv.shape
     hd = C3 // 3 // num_heads
+    if S > SEQ_FUSED_MAX_KEYS:
+        seed = next_dropout_seed(qkv.device) if dropout_p > 0 else None
+        return _LongSeqAttention.apply(qkv, kmask, num_heads, float(dropout_p), seed)
     kw = dict(mode=0, groups=B, N=S, nH=num_heads, hd=hd, scale=float(hd) ** -0.5, dropout_p=float(dropout_p))
     seed = next_dropout_seed(qkv.device) if dropout_p > 0 else None
     return _Attention.apply(qkv, None, None, kmask, kw, seed)

@@ -82,6 +82,19 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const float* lse, const float* bias, const int32_t* rid, const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* work,
                  const void* seed, int32_t stages, const ClvAttnGeom* geom_host, void* stream);
+
+/* ---- unfused attention for long sequences (N > 448 keys: K/V of one (group, head) no longer fit LDS in the
+ * kernels above; the fusion encoder at 32 frames has 16*49 + 32 = 816 tokens).  Q.K^T, P.V and their gradients are
+ * batched library GEMMs; these two kernels are what sits between them (HF BertSelfAttention, transformers 4.6.1
+ * modeling_bert.py, reached through cross_transformer.py:95-108): one wave per row.
+ * fwd: p[r][j] = softmax_j(scores[r][j]*scale + kmask[r / rows_per_group][j]); pd = p * keep/(1-p_drop) with the
+ *      same counter-based mask as clv_attn_* (row id r, key j).  scores/p/pd bf16 [rows][ld], S <= 2048 keys;
+ *      kmask float [groups][S] or NULL; pd / seed may be NULL when dropout_p == 0.
+ * bwd: ds = p * (dp - sum_j p_j dp_j) * scale with dp = dpd * keep/(1-p_drop); ds may alias dpd. */
+int clv_softmax_rows_fwd(const void* scores, const float* kmask, void* p, void* pd, const void* seed, int64_t rows,
+                         int32_t S, int32_t ld, int32_t rows_per_group, float scale, float dropout_p, void* stream);
+int clv_softmax_rows_bwd(const void* p, const void* dpd, void* ds, const void* seed, int64_t rows, int32_t S,
+                         int32_t ld, float scale, float dropout_p, void* stream);
 /* stages: 0 = everything; otherwise a bit mask 1 = dQ (+ dS scratch, dsum) kernel, 2 = dS -> table-gradient
  * reduction, 4 = dK/dV kernel — lets a profiler bracket each kernel of the call with its own events. */
 
