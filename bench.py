@@ -43,7 +43,7 @@ def model_cfg(variant='T', frames=8):
         freeze_text_backbone=None, text_vocab_size=30522,
         mm_backbone=dict(type='CrossModalTransformerFromPretrained', use_text_cls=True, use_prompt=False,
                          pretrained_model='bert-base-uncased', num_hidden_layers=3, img_in_size=cf, hidden_size=768,
-                         num_frames=frames // 2, spacial_tokens=49, token_types=2, layer_norm_eps=1e-12,
+                         num_frames=max(1, (frames + 1) // 2), spacial_tokens=49, token_types=2, layer_norm_eps=1e-12,
                          word_pos_start=False, bert_config=dict(BERT_BASE)),
         text_backbone=dict(type='BertFromPretrained', num_hidden_layers=12, bert_config=dict(BERT_BASE)),
         cls_head=None,

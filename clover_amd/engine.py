@@ -119,6 +119,8 @@ class CloverEngine:
         self.step_count = 0
         self.graph = None
         self.graph_bwd_video = None
+        self._captures = {}                    # batch-shape signature -> the captured graphs + their static tensors
+        self._active_sig = None
         device = next(model.parameters()).device
         pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                    custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
@@ -179,6 +181,14 @@ class CloverEngine:
     def step(self, batch):
         """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
         if self.graph is not None:
+            sig = self._signature(batch)
+            if sig != self._active_sig:
+                # a different batch geometry (the reference alternates 8-frame video and 1-frame image batches,
+                # clover_runner.py:76-93): one set of graphs per geometry, captured on first sight
+                if sig in self._captures:
+                    self._activate(sig)
+                else:
+                    self.capture(batch)
             out = self._graphed_forward_backward(batch)
         else:
             out = self.model.train_step(batch, None)
@@ -188,6 +198,18 @@ class CloverEngine:
         return out
 
     # ------------------------------------------------------------------ hipGraph mode
+    _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', '_static_batch', '_static_emb', '_static_mlm',
+                       '_static_demb', '_static_dmlm', '_static_cuts')
+
+    @staticmethod
+    def _signature(batch):
+        return tuple((k, tuple(v.shape)) for k, v in sorted(batch.items()))
+
+    def _activate(self, sig):
+        for f, v in zip(self._CAPTURE_FIELDS, self._captures[sig]):
+            setattr(self, f, v)
+        self._active_sig = sig
+
     def _graphed_forward_backward(self, batch):
         """encode (hipGraph) -> gather + contrastive losses (eager: it holds the step's only forward
         collective) -> backward of the losses (eager, a handful of kernels) -> encode backward (hipGraph)."""
@@ -274,6 +296,8 @@ class CloverEngine:
         self.graph, self.graph_bwd, self.graph_bwd_video = gf, gb, gb2
         self._static_emb, self._static_mlm = emb, mlm
         self._static_cuts = cuts
+        self._active_sig = self._signature(batch)
+        self._captures[self._active_sig] = tuple(getattr(self, f) for f in self._CAPTURE_FIELDS)
         return True
 
     def optimizer_step(self):

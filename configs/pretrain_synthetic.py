@@ -1,6 +1,6 @@
 # BASELINE config 2 (VideoSwin-T + BERT-base + 3-layer fusion, all five losses) in the reference's config format
-# (configs/exp_local/pretrain_webvid_cc3m.py:22-141); the two training sets are synthetic (video-like and
-# image-like batch streams), everything else keeps the reference's keys and values.
+# (configs/exp_local/pretrain_webvid_cc3m.py:22-141); the two training sets are synthetic (an 8-frame video stream and a
+# 1-frame image stream, as WebVid + CC3M; the engine keeps one set of hipGraphs per batch geometry), everything else keeps the reference's keys and values.
 _base_ = ['_base_default_runtime.py']
 videos_per_gpu = 8
 base_lr = 5e-5 / 1024
@@ -8,7 +8,7 @@ weight_decay = 0.005
 import bench as _bench                                   # noqa: E402  (repo root is on sys.path under tools/train.py)
 model = _bench.model_cfg('T', 8)
 data = dict(videos_per_gpu=videos_per_gpu,
-            synthetic=[dict(length=20, frames=8, tokens=32), dict(length=12, frames=8, tokens=32)])
+            synthetic=[dict(length=20, frames=8, tokens=32), dict(length=12, frames=1, tokens=32)])
 optimizer = dict(type='AdamW', base_lr=base_lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=weight_decay,
                  paramwise_cfg=dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                     custom_keys={'absolute_pos_embed': dict(decay_mult=0.),

@@ -97,6 +97,55 @@ def test_graph_capture_equals_eager_and_loss_decreases():
     assert traj['graph'][-1] < traj['graph'][0] - 0.5          # the step actually trains
 
 
+def test_graphs_per_batch_geometry():
+    """The reference alternates video (many-frame) and image (1-frame, padded to 2) batches (clover_runner.py:76-93):
+    the engine keeps one set of hipGraphs per batch geometry, captured on first sight, and the alternating
+    trajectory equals the eager one."""
+    from clover_amd.engine import CloverEngine
+    vid = batch(2, 'geo_v')
+    img = {k: v.to(DEV) for k, v in cf.cf_batch(2, frames=1, tag='geo_i').items()}
+    traj = {}
+    for mode in ('eager', 'graph'):
+        eng = CloverEngine(make_model(), vid, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+        eng.step(vid)
+        if mode == 'graph':
+            assert eng.capture(vid)
+        losses = []
+        for _ in range(3):
+            losses.append(eng.step(vid)['log_vars']['loss'])
+            losses.append(eng.step(img)['log_vars']['loss'])
+        traj[mode] = losses
+        if mode == 'graph':
+            assert len(eng._captures) == 2
+            # the lazily captured second geometry must deliver EVERY parameter's gradient inside its graphs
+            # (including the ones that go through autograd's AccumulateGrad rather than a kernel-side sink)
+            for b in (img, vid):
+                for seg in eng.segments:
+                    seg.flat_g.zero_()
+                if eng._signature(b) != eng._active_sig:
+                    eng._activate(eng._signature(b))
+                eng._graphed_forward_backward(b)
+                torch.cuda.synchronize()
+                got = [seg.flat_g.clone() for seg in eng.segments]
+                for seg in eng.segments:
+                    seg.flat_g.zero_()
+                eng.model.train_step(b, None)['loss'].backward()
+                torch.cuda.synchronize()
+                for seg, g in zip(eng.segments, got):
+                    for name, p_, off in zip(seg.names, seg.params, seg.offsets):
+                        a, r = g[off:off + p_.numel()], seg.flat_g[off:off + p_.numel()]
+                        scale = r.abs().max().item()
+                        if scale > 0:
+                            assert (a - r).abs().max().item() <= 3e-2 * scale + 1e-6, (name, scale)
+                        else:
+                            assert a.abs().max().item() == 0, name
+                for seg in eng.segments:
+                    seg.flat_g.zero_()
+    print(traj)
+    for a, g in zip(traj['eager'], traj['graph']):
+        assert abs(a - g) < 0.05 * max(1.0, abs(a)), traj
+
+
 def make_finetune_model():
     import clover_amd
     m = clover_amd.build_model(cf.tiny_finetune_cfg())
