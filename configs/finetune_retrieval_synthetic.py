@@ -16,7 +16,9 @@ model = dict(type='CloverFinetune', freeze_stage=None, separate_test=True, backb
              train_cfg=dict(aux_info=['token_ids', 'segment_ids', 'input_mask']),
              test_cfg=dict(feature_extraction=False))
 del _pre
-data = dict(videos_per_gpu=videos_per_gpu, synthetic=[dict(length=20, frames=num_frames, tokens=32)])
+data = dict(videos_per_gpu=videos_per_gpu, synthetic=[dict(length=20, frames=num_frames, tokens=32)],
+            synthetic_test=dict(pairs=200, frames=num_frames, tokens=32))          # tools/test.py
+evaluation = dict(interval=1, metrics=['recall_for_video_text_retrieval'], gpu_collect=True)
 optimizer = dict(type='AdamW', base_lr=base_lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=weight_decay,
                  paramwise_cfg=dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                     custom_keys={'absolute_pos_embed': dict(decay_mult=0.),

@@ -8,7 +8,9 @@ weight_decay = 0.005
 import bench as _bench                                   # noqa: E402  (repo root is on sys.path under tools/train.py)
 model = _bench.model_cfg('T', 8)
 data = dict(videos_per_gpu=videos_per_gpu,
-            synthetic=[dict(length=20, frames=8, tokens=32), dict(length=12, frames=1, tokens=32)])
+            # lengths: the reference's interleave (clover_runner.py:76-93) needs long <= 1.5 * short, else its restarted
+            # iterator runs dry mid-epoch (StopIteration there and here)
+            synthetic=[dict(length=16, frames=8, tokens=32), dict(length=12, frames=1, tokens=32)])
 optimizer = dict(type='AdamW', base_lr=base_lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=weight_decay,
                  paramwise_cfg=dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                     custom_keys={'absolute_pos_embed': dict(decay_mult=0.),

@@ -178,3 +178,63 @@ def test_oracle_distributed_matches_reference_goldens(W):
     n1 = g['W1.grad.backbone.patch_embed.proj.weight.stats'][1]
     n2 = g['W2.grad.backbone.patch_embed.proj.weight.stats'][1]
     assert n2 < 0.9 * n1
+
+
+# ----------------------------------------------------------------------------- retrieval evaluation collection
+class _FakeRetrievalModel(torch.nn.Module):
+    """Stands in for forward_test(separate_test=True): embeddings are a fixed function of the sample index carried in
+    the clip, with `clips` clips per sample (averaged by the collector) — only the collection logic is under test."""
+
+    def forward(self, return_loss=False, imgs=None, token_ids=None, **kw):
+        v = imgs.reshape(-1, imgs.shape[-1]).float()                 # [B * clips, D]
+        t = token_ids.float()                                        # [B, D]
+        return v, t
+
+
+def _retrieval_loader(rank, world, N, D, clips, batch):
+    import closed_form as cf
+    V = cf.cf_float('rt.v', (N, D), 1.0)
+    T = (0.6 * V + cf.cf_float('rt.t', (N, D), 1.0))
+    mine = list(range(rank, N, world))
+    if rank == world - 1 and N % world:                                  # sampler-style padding: a repeated sample
+        mine.append(0)
+    out = []
+    for s in range(0, len(mine), batch):
+        idx = mine[s:s + batch]
+        # clips differ by +-delta so that their mean is the sample's embedding
+        d = torch.linspace(-1, 1, clips)[None, :, None] if clips > 1 else torch.zeros(1, 1, 1)
+        out.append(dict(imgs=V[idx][:, None, :] + d, token_ids=T[idx], index=torch.tensor(idx)))
+    return out, V, T
+
+
+def _w_retrieval(rank, world, port, q, N, clips):
+    _init(rank, world, port)
+    from clover_amd.evaluation import evaluate_retrieval, multi_gpu_test_retrieval, recall_for_video_text_retrieval
+    loader, V, T = _retrieval_loader(rank, world, N, 16, clips, 3)
+    res = multi_gpu_test_retrieval(_FakeRetrievalModel(), loader)
+    ok_order = np.array_equal(res['index'], np.arange(N))
+    ok_v = np.allclose(res['video_embd'], V.numpy(), atol=1e-6) and np.allclose(res['text_embd'], T.numpy(), atol=1e-6)
+    m = evaluate_retrieval(res, ['recall_for_video_text_retrieval'])
+    ok_m = m == recall_for_video_text_retrieval(V.numpy(), T.numpy())
+    q.put((rank, ok_order, ok_v, ok_m, m['Recall@1']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('N,clips', [(11, 1), (8, 3)])
+def test_retrieval_collection_world2(N, clips):
+    """my_eval_hook.py:20-100 — every rank embeds its shard; all ranks end with the whole test set in dataset order,
+    sampler padding de-duplicated, multiple clips per sample averaged; metrics equal the single-process ones."""
+    res = _run(_w_retrieval, 2, 29571 + N, N, clips)
+    for r in res:
+        assert all(r[1:4]), r
+    assert res[0][4] == res[1][4] and res[0][4] > 30.0               # correlated pairs: far above chance
+
+
+def test_retrieval_collection_single_process():
+    from clover_amd.evaluation import evaluate_retrieval, multi_gpu_test_retrieval
+    loader, V, T = _retrieval_loader(0, 1, 9, 16, 2, 4)
+    res = multi_gpu_test_retrieval(_FakeRetrievalModel(), loader)
+    assert np.array_equal(res['index'], np.arange(9)) and np.allclose(res['video_embd'], V.numpy(), atol=1e-6)
+    with pytest.raises(KeyError):
+        evaluate_retrieval(res, ['top_k_accuracy'])
