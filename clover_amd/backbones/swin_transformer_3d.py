@@ -481,6 +481,11 @@ class SwinTransformer3D(nn.Module):
         y = self._stages(torch.cat([clean, masked], dim=0))
         return y[:B], y[B:]
 
+    def forward_both(self, x, mask):
+        """As ``forward_pair`` but returns the one [2B,T',h,w,Cf] tensor (clean clips first, masked clips second)."""
+        clean, masked = self.patch_embed.tokens(x, self.mask_token, mask)
+        return self._stages(torch.cat([clean, masked], dim=0))
+
     def forward(self, x, mask=None):
         """Reference contract: [B,3,T,H,W] -> [B,Cf,T',h,w]; with ``mask`` -> (x, w)."""
         y = self.forward_tokens(x, mask).permute(0, 4, 1, 2, 3)

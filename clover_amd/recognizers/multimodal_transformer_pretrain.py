@@ -4,7 +4,7 @@ kwargs, same ``losses`` keys.
 
 MI355X-first scheduling of the SAME arithmetic (every encoder is sample-independent —
 LayerNorm only — so batching passes along dim 0 changes no value):
-  * clean + masked video passes (:91,114)  -> one 2B-clip Swin pass (``forward_pair``)
+  * clean + masked video passes (:91,114)  -> one 2B-clip Swin pass (``forward_both``)
   * un-masked + masked caption passes (:99,110) -> one 2B BERT pass
   * v_fusion + t_fusion (:117,119)          -> one 2B fusion pass
   * MLM head only on the t_fusion half; all B*L rows go through the decoder and the fused
@@ -83,51 +83,53 @@ class CloverPretrain(BaseRecognizer):
         # run in the shadow of the Swin kernels instead of serially after them.  Autograd replays each backward
         # on its forward's stream, so the two backward passes overlap the same way; a hipGraph capture records
         # the fork / join as graph edges.
+        # Batch layout of the doubled passes (no cat / slice copies anywhere downstream):
+        #   video  y        = [clean clips (:91)      ; masked clips (:114)]
+        #   text   text_out = [masked caption (:110)  ; un-masked caption (:99)]
+        # so that row block 0 of the fusion pass is t_fusion = (clean video, masked text) (:119) and row block 1 is
+        # v_fusion = (masked video, clean text) (:117) with both inputs used exactly as the encoders produced them.
         input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
+        text_ids2 = torch.cat([token_ids, input_ssl_ids], 0)
+        text_mask2 = torch.cat([text_input_mask, text_input_mask], 0)
         side = self._text_stream(imgs.device) if imgs.is_cuda and getattr(self, 'overlap_text', True) else None
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
-                                              torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
-                txt_emb_both = self.ssl_head.forward_text(text_out)          # :102 / :159, also text-only
+                text_out = self.text_backbone(text_ids2, text_mask2)['last_hidden_state']
+                txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
 
-        # ---- video encoder: clean (:91) + masked (:114) pass, channels-last [B,T',h,w,Cf]
-        vis_clean, vis_masked = self.backbone.forward_pair(imgs, v_token_mask)
+        # ---- video encoder: clean (:91) + masked (:114) pass as one 2B-clip pass, channels-last [2B,T',h,w,Cf]
+        vis_both = self.backbone.forward_both(imgs, v_token_mask)
         if video_cut is not None:
             # engine graph mode: cut the autograd graph at the video encoder's output, so that its backward can run
             # as a separate graph AFTER the gradient all-reduce of everything else has been put in flight.
             # video_cut receives [(output, detached leaf standing in for it downstream), ...]
-            cuts = [(t, t.detach().requires_grad_()) for t in (vis_clean, vis_masked)]
-            video_cut.extend(cuts)
-            vis_clean, vis_masked = cuts[0][1], cuts[1][1]
-        _, T, h, w, D = vis_clean.shape
+            cut = (vis_both, vis_both.detach().requires_grad_())
+            video_cut.append(cut)
+            vis_both = cut[1]
+        _, T, h, w, D = vis_both.shape
 
-        # ---- text encoder: un-masked caption (:97-101) + masked caption (:110-111)
+        # ---- text encoder: masked caption (:110-111) + un-masked caption (:97-101)
         if side is not None:
             main.wait_stream(side)
             text_out.record_stream(main)
             txt_emb_both.record_stream(main)
         else:
-            text_out = self.text_backbone(torch.cat([input_ssl_ids, token_ids], 0),
-                                          torch.cat([text_input_mask, text_input_mask], 0))['last_hidden_state']
+            text_out = self.text_backbone(text_ids2, text_mask2)['last_hidden_state']
             txt_emb_both = self.ssl_head.forward_text(text_out)
-        text_out_no_mask, text_out_with_mask = text_out[:B], text_out[B:]
 
-        # ---- contrastive projections (:102, :150, :159)
-        vis_emb_both = self.ssl_head.forward_vision(torch.cat([vis_clean, vis_masked], 0), channels_last=True)
-        visual_emb, mask_visual_emb = vis_emb_both[:B], vis_emb_both[B:]
-        text_emb, mask_word_emb = txt_emb_both[:B], txt_emb_both[B:]
+        # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack
+        vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
+        visual_emb, mask_visual_emb = vis_emb_both.view(2, B, -1).unbind(0)
+        mask_word_emb, text_emb = txt_emb_both.view(2, B, -1).unbind(0)
 
-        # ---- fusion: v_fusion = (masked video, clean text) (:117); t_fusion = (clean video, masked text) (:119)
-        fusion_vis = torch.cat([vis_masked, vis_clean], 0).reshape(2 * B, T, h * w, D)
-        fusion_txt = torch.cat([text_out_no_mask, text_out_with_mask], 0)
-        fusion = self.multimodal_backbone(visual_token=fusion_vis,
-                                          text_input_mask=torch.cat([text_input_mask, text_input_mask], 0),
-                                          text_input_embeds=fusion_txt)
+        # ---- fusion: block 0 = t_fusion (clean video, masked text) (:119); block 1 = v_fusion (masked video,
+        # clean text) (:117)
+        fusion = self.multimodal_backbone(visual_token=vis_both.reshape(2 * B, T, h * w, D),
+                                          text_input_mask=text_mask2, text_input_embeds=text_out)
         t_all = fusion['t_last_hidden_state']
-        v_fusion_t, t_last_hidden_state = t_all[:B], t_all[B:]
+        t_last_hidden_state, v_fusion_t = t_all.unflatten(0, (2, B)).unbind(0)
 
         # ---- MLM (:129-143): all B*L rows through the decoder, the fused focal kernel skips label == -100
         score = self.mlm_head(t_last_hidden_state)
