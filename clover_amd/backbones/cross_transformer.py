@@ -63,9 +63,11 @@ class CrossModalTransformerFromPretrained(nn.Module):
             text_embeddings = text_embeddings.view(B, -1, text_embeddings.shape[-1])
             text_input_mask = text_input_mask.view(B, -1)
         tt = self.token_type_embeddings.weight
-        text_embeddings = to_bf16(text_embeddings.float() + tt[1])
+        # the two embedding additions as single bf16 kernels (the sums are rounded to bf16 either way; the addends'
+        # own rounding is 2^-9 of a ~0.02-sized embedding)
+        text_embeddings = to_bf16(text_embeddings) + to_bf16(tt[1])
         pos = (self.vis_space_pos + self.vis_tempor_pos[:, :T, :, :]).reshape(1, T * S, D) + tt[0]
-        visual = self.norm(to_bf16(visual_token.reshape(B, T * S, D).float() + pos))
+        visual = self.norm(to_bf16(visual_token.reshape(B, T * S, D)) + to_bf16(pos))
         if self.use_prompt:
             visual = torch.cat([visual, to_bf16(self.prompt_token).expand(B, -1, -1),
                                 to_bf16(self.all_cls_token).expand(B, -1, -1)], dim=1)

@@ -122,12 +122,12 @@ __host__ __device__ inline NceWork nce_carve(float* w, int G, int Dm) {
 
 // one wave per row: en = e / max(|e|, 1e-8)   (cos_norm, contrastive_loss.py:20-25)
 __global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, const float* e1, const float* e2,
-                                                            const float* e3, NceWork W, int G, int Dm) {
+                                                            const float* e3, NceWork W, int G, int Dm, int ld) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 4 * G) return;
     const int k = row / G, i = row - k * G;
-    const float* e = (k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3) + (int64_t)i * Dm;
+    const float* e = (k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3) + (int64_t)i * ld;
     float s = 0.f;
     for (int d = lane; d < Dm; d += 64) s += e[d] * e[d];
     const float nrm = sqrtf(wave_sum(s));
@@ -256,12 +256,12 @@ __global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* _
 
 // d e = invn * (d en - en * <en, d en>)   (valid while |e| >= eps; below eps: d e = d en * invn)
 __global__ void __launch_bounds__(256) nce_norm_bwd_kernel(NceWork W, float* d0, float* d1, float* d2, float* d3,
-                                                           int G, int Dm) {
+                                                           int G, int Dm, int ldd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 4 * G) return;
     const int k = row / G, i = row - k * G;
-    float* d = (k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3) + (int64_t)i * Dm;
+    float* d = (k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3) + (int64_t)i * ldd;
     const float* en = W.en + (int64_t)row * Dm;
     const float* de = W.den + (int64_t)row * Dm;
     float s = 0.f;
@@ -416,11 +416,14 @@ static int nce_gemm(const float* A, const float* B, float* C, int M, int N, int 
 }
 
 extern "C" int clv_infonce_fwd(const float* e0, const float* e1, const float* e2, const float* e3, float* out,
-                               float* work, int32_t G, int32_t Dm, float temperature, float margin, void* stream) {
-    if (!e0 || !e1 || !e2 || !e3 || !out || !work || G <= 0 || Dm <= 0 || temperature <= 0.f) return CLV_ERR_ARG;
+                               float* work, int32_t G, int32_t Dm, int32_t ld, float temperature, float margin,
+                               void* stream) {
+    if (!e0 || !e1 || !e2 || !e3 || !out || !work || G <= 0 || Dm <= 0 || ld < Dm || temperature <= 0.f)
+        return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     NceWork W = nce_carve(work, G, Dm);
-    hipLaunchKernelGGL(nce_normalize_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, e0, e1, e2, e3, W, (int)G, (int)Dm);
+    hipLaunchKernelGGL(nce_normalize_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, e0, e1, e2, e3, W, (int)G, (int)Dm,
+                       (int)ld);
     int rc = clv_check_launch();
     if (rc) return rc;
     // sim[k] = en0 . en_{k+1}^T / temperature
@@ -433,8 +436,8 @@ extern "C" int clv_infonce_fwd(const float* e0, const float* e1, const float* e2
 
 extern "C" int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const float* e3, const float* dout,
                                const float* work, float* d0, float* d1, float* d2, float* d3, int32_t G, int32_t Dm,
-                               float temperature, float margin, void* stream) {
-    if (!e0 || !e1 || !e2 || !e3 || !dout || !work || !d0 || !d1 || !d2 || !d3 || G <= 0 || Dm <= 0) return CLV_ERR_ARG;
+                               int32_t ldd, float temperature, float margin, void* stream) {
+    if (!dout || !work || !d0 || !d1 || !d2 || !d3 || G <= 0 || Dm <= 0 || ldd < Dm) return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     NceWork W = nce_carve(const_cast<float*>(work), G, Dm);
     int64_t total = (int64_t)3 * G * G;
@@ -451,7 +454,8 @@ extern "C" int clv_infonce_bwd(const float* e0, const float* e1, const float* e2
     rc = nce_gemm(W.dsimT, W.enT, W.den + (int64_t)G * Dm, G, Dm, G, G, 4 * G, Dm, 3, (int64_t)G * G, 0,
                   (int64_t)G * Dm, it, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(nce_norm_bwd_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, W, d0, d1, d2, d3, (int)G, (int)Dm);
+    hipLaunchKernelGGL(nce_norm_bwd_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, W, d0, d1, d2, d3, (int)G, (int)Dm,
+                       (int)ldd);
     return clv_check_launch();
 }
 

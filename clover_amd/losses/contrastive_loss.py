@@ -36,10 +36,19 @@ class ExclusiveNCEwithRankingLoss(nn.Module):
         v, t, tm, tr = packed_all_gather([video_embd, text_embd, text_mask_embd, text_recon_embd],
                                          equal_sizes=self.equal_batch)
         nce, rank = ops.exclusive_infonce_rank(v, t, tm, tr, self.t, self.margin_ttm)
+        return self._pack_losses(nce, rank)
+
+    def _pack_losses(self, nce, rank):
         losses = {'nce_loss': nce}
         if self.use_rank and self.use_rank_ttm:
             losses['rank_t_tm_loss'] = rank
         return losses
+
+    def forward_gathered(self, gathered, slots):
+        """The loss on slots (video, text, text_mask, text_recon) of an ALREADY gathered fp32 [G, k, D] tensor: the
+        recognizer gathers all its embeddings with one collective and evaluates both directions on it."""
+        nce, rank = ops.exclusive_infonce_rank_packed(gathered, slots, self.t, self.margin_ttm)
+        return self._pack_losses(nce, rank)
 
 
 @LOSSES.register_module()

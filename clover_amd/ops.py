@@ -977,7 +977,7 @@ class _InfoNCE(torch.autograd.Function):
         L = _lib.lib()
         work = torch.empty(L.clv_infonce_work_floats(G, Dm), device=e0.device, dtype=torch.float32)
         out = torch.empty(2, device=e0.device, dtype=torch.float32)
-        check(L.clv_infonce_fwd(_ptr(es[0]), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]), _ptr(out), _ptr(work), G, Dm,
+        check(L.clv_infonce_fwd(_ptr(es[0]), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]), _ptr(out), _ptr(work), G, Dm, Dm,
                                 float(temperature), float(margin), _stream()), 'clv_infonce_fwd')
         ctx.save_for_backward(*es, work)
         ctx.cfg = (G, Dm, float(temperature), float(margin), [e.dtype for e in (e0, e1, e2, e3)])
@@ -990,9 +990,50 @@ class _InfoNCE(torch.autograd.Function):
         dout = torch.stack([dnce.float().reshape(()), drank.float().reshape(())]).contiguous()
         ds = [torch.empty_like(e0) for _ in range(4)]
         check(_lib.lib().clv_infonce_bwd(_ptr(e0), _ptr(e1), _ptr(e2), _ptr(e3), _ptr(dout), _ptr(work), _ptr(ds[0]),
-                                         _ptr(ds[1]), _ptr(ds[2]), _ptr(ds[3]), G, Dm, temp, margin, _stream()),
+                                         _ptr(ds[1]), _ptr(ds[2]), _ptr(ds[3]), G, Dm, Dm, temp, margin, _stream()),
               'clv_infonce_bwd')
         return ds[0].to(dts[0]), ds[1].to(dts[1]), ds[2].to(dts[2]), ds[3].to(dts[3]), None, None
+
+
+class _InfoNCEPacked(torch.autograd.Function):
+    """The same loss on four slots of ONE packed fp32 [G, k, Dm] tensor (the layout the feature all-gather
+    delivers): the kernels read the slots in place (row stride k*Dm) and write the gradient straight into the
+    matching slots of a [G, k, Dm] gradient — no per-embedding copies either way."""
+
+    @staticmethod
+    def forward(ctx, packed, slots, temperature, margin):
+        _need_gpu(packed)
+        assert packed.dtype == torch.float32 and packed.dim() == 3 and packed.is_contiguous() and len(slots) == 4
+        G, k, Dm = packed.shape
+        L = _lib.lib()
+        work = torch.empty(L.clv_infonce_work_floats(G, Dm), device=packed.device, dtype=torch.float32)
+        out = torch.empty(2, device=packed.device, dtype=torch.float32)
+        base = packed.data_ptr()
+        es = [C.c_void_p(base + 4 * Dm * int(sl)) for sl in slots]
+        check(L.clv_infonce_fwd(*es, _ptr(out), _ptr(work), G, Dm, k * Dm, float(temperature), float(margin),
+                                _stream()), 'clv_infonce_fwd')
+        ctx.save_for_backward(work)
+        ctx.cfg = (G, k, Dm, tuple(int(sl) for sl in slots), float(temperature), float(margin))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, dnce, drank):
+        work, = ctx.saved_tensors
+        G, k, Dm, slots, temp, margin = ctx.cfg
+        dout = torch.stack([dnce.float().reshape(()), drank.float().reshape(())]).contiguous()
+        dp = torch.zeros(G, k, Dm, device=work.device, dtype=torch.float32)
+        base = dp.data_ptr()
+        ds = [C.c_void_p(base + 4 * Dm * sl) for sl in slots]
+        check(_lib.lib().clv_infonce_bwd(None, None, None, None, _ptr(dout), _ptr(work), *ds, G, Dm, k * Dm, temp,
+                                         margin, _stream()), 'clv_infonce_bwd')
+        return dp, None, None, None
+
+
+def exclusive_infonce_rank_packed(packed, slots, temperature=0.05, margin=5.0):
+    """(nce_loss, rank_t_tm_loss) with (video, text, text_mask, text_recon) = packed[:, slots[i]]; packed fp32
+    [G, k, Dm] already gathered.  Slots must be distinct."""
+    assert len(set(int(s) for s in slots)) == 4
+    return _InfoNCEPacked.apply(packed, tuple(slots), temperature, margin)
 
 
 def exclusive_infonce_rank(video, text, text_mask, text_recon, temperature=0.05, margin=5.0):

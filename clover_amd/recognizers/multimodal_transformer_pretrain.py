@@ -150,13 +150,15 @@ class CloverPretrain(BaseRecognizer):
         return st
 
     def contrastive_losses(self, emb, mlm_loss):
-        """The cross-rank part of the step (:147-169): all-gather of the embeddings + the two
-        exclusive-InfoNCE / ranking evaluations.  emb [B, 6, D] in EMB_NAMES order."""
-        visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb, mask_word_recon_emb = \
-            emb.unbind(dim=1)
+        """The cross-rank part of the step (:147-169): ONE all-gather of the six embeddings (backward = the local
+        slice, gather_loss.py:64-72), then the two exclusive-InfoNCE / ranking evaluations read their four slots
+        of the gathered [G, 6, D] tensor in place.  emb [B, 6, D] in EMB_NAMES order."""
+        from ..utils.gather_loss import gather_rows
+        g = gather_rows(emb.float(), equal_sizes=self.ssl_loss.equal_batch).contiguous()
+        V, T, MW, MVR, MV, MWR = range(6)                      # EMB_NAMES order
         losses = dict(mlm_loss=mlm_loss)
-        losses.update(self.ssl_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb))       # :151
-        l2 = self.ssl_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon_emb)                 # :161
+        losses.update(self.ssl_loss.forward_gathered(g, (V, T, MW, MVR)))                              # :151
+        l2 = self.ssl_loss.forward_gathered(g, (T, V, MV, MWR))                                        # :161
         l2['v_nce_loss'] = l2.pop('nce_loss')
         if self.ssl_loss.use_rank:
             l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')

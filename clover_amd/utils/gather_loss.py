@@ -81,3 +81,11 @@ def packed_all_gather(tensors, equal_sizes=True):
     packed = torch.stack([t.float() for t in tensors], dim=1)
     g = VariedShapeGatherLoss.apply(packed, rank, ws, equal_sizes)
     return [g[:, i] for i in range(len(tensors))]
+
+
+def gather_rows(t, equal_sizes=True):
+    """All-gather one tensor along dim 0 in rank order (backward: the local slice); identity on a 1-rank job."""
+    rank, ws = _world()
+    if not collectives_active():
+        return t
+    return VariedShapeGatherLoss.apply(t.contiguous(), rank, ws, equal_sizes)

@@ -225,16 +225,18 @@ int clv_focal_ce_bwd(const void* logits, int32_t is_bf16, const int64_t* labels,
  * (mmaction/models/losses/contrastive_loss.py:112-161): cos_norm of the four gathered
  * embeddings, three G×G similarity matmuls / temperature, the three exclusive [G,3G] row
  * log-softmaxes, the [3G,G] column log-softmax, diagonals, MarginRankingLoss(margin).
- * e0..e3 float [G][Dm] (video, text, text_mask, text_recon).  out float [2] =
+ * e0..e3 float [G][Dm] with row stride ld floats (video, text, text_mask, text_recon) — ld > Dm lets
+ * the four be slots of one packed [G][k][Dm] tensor, as the all-gather delivers them.  out float [2] =
  * {nce_loss, rank_t_tm_loss}.  work: float scratch, >= clv_infonce_work_floats(G, Dm). */
 int64_t clv_infonce_work_floats(int32_t G, int32_t Dm);
 int clv_infonce_fwd(const float* e0, const float* e1, const float* e2, const float* e3, float* out,
-                    float* work, int32_t G, int32_t Dm, float temperature, float margin, void* stream);
-/* dout float [2] = upstream grads of {nce, rank}; d0..d3 float [G][Dm].  `work` must be the
- * buffer the matching forward filled. */
+                    float* work, int32_t G, int32_t Dm, int32_t ld, float temperature, float margin,
+                    void* stream);
+/* dout float [2] = upstream grads of {nce, rank}; d0..d3 float [G][Dm] with row stride ldd.  `work`
+ * must be the buffer the matching forward filled (e0..e3 are not re-read and may be NULL). */
 int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const float* e3,
                     const float* dout, const float* work, float* d0, float* d1, float* d2, float* d3,
-                    int32_t G, int32_t Dm, float temperature, float margin, void* stream);
+                    int32_t G, int32_t Dm, int32_t ldd, float temperature, float margin, void* stream);
 
 /* NormSoftmaxLoss (mmaction/models/losses/contrastive_loss.py:26-68), the retrieval fine-tuning loss
  * (multimodal_transformer_finetune.py:83-86): x = normalise(video) . normalise(text)^T / temperature,

@@ -233,6 +233,27 @@ def test_infonce(G):
             assert rel(eg[k].grad, er[k].grad) < 2e-3, (k, rel(eg[k].grad, er[k].grad))
 
 
+@pytest.mark.parametrize('G', [2, 8, 64])
+def test_infonce_packed_slots(G):
+    """The packed entry (four slots of one gathered [G, 6, Dm] tensor, strided reads / strided gradient writes)
+    equals the four-tensor entry, for both slot orders the step uses."""
+    Dm = 768
+    packed = rnd(G, 6, Dm, seed=81)
+    packed[:, 1] = packed[:, 0] * 0.7 + packed[:, 1] * 0.5
+    for slots in [(0, 1, 2, 3), (1, 0, 4, 5)]:
+        pg = packed.to(DEV).requires_grad_()
+        nce, rank = ops().exclusive_infonce_rank_packed(pg, slots, 0.05, 5.0)
+        (nce * 1.3 + rank * 0.7).backward()
+        es = [packed[:, s].clone().to(DEV).requires_grad_() for s in slots]
+        nce2, rank2 = ops().exclusive_infonce_rank(*es, 0.05, 5.0)
+        (nce2 * 1.3 + rank2 * 0.7).backward()
+        assert nce.item() == nce2.item() and rank.item() == rank2.item()
+        for k, s_ in enumerate(slots):
+            assert torch.equal(pg.grad[:, s_], es[k].grad)
+        unused = [u for u in range(6) if u not in slots]
+        assert pg.grad[:, unused].abs().max().item() == 0.0
+
+
 def test_norm_softmax_loss_goldens():
     """clv_normsoftmax_fwd/bwd against the reference's own NormSoftmaxLoss numbers (g_finetune.npz): both norm
     clamps, ragged widths, a zero-norm row, the sim_mat entry."""
