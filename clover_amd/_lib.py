@@ -28,7 +28,7 @@ _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 class ClvLnExtra(C.Structure):
     """Mirror of ``struct ClvLnExtra`` (include/clover_hip.h)."""
     _fields_ = [('xscale', _p), ('rows_per_sample', _i32), ('drop_p', _f), ('seed', _p), ('dy2', _p), ('dres', _p),
-                ('x_is_sum', _i32)]
+                ('x_is_sum', _i32), ('gather_c', _i32), ('gather_h2', _i32), ('gather_w2', _i32)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares

@@ -236,7 +236,7 @@ class SwinTransformerBlock3D(nn.Module):
         a = self.drop_path(at.proj(o))
         m, s1 = ops.fused_mlp(a, s0, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
                               self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps)
-        return s1, self.drop_path(m), None
+        return s1, m, self._dp_scale(m)        # the consumer applies / folds the factor (next LayerNorm or merge)
 
     def forward(self, x, mask_matrix=None):
         """x bf16 [B,D,H,W,C].  ``mask_matrix`` is accepted for signature compatibility and unused:
@@ -267,6 +267,15 @@ class PatchMerging(nn.Module):
     def forward(self, x):
         return self.reduction(self.norm(self.merge_gather(x)))
 
+    def forward_pending(self, s, m, sc):
+        """Downsample the stream s + sc * m (the last block's pending residual) without materialising it: gather,
+        residual add and DropPath factor all ride in the LayerNorm kernel (ops.merge_layer_norm)."""
+        B, D, H, W, C = s.shape
+        if not s.is_cuda or H % 2 or W % 2 or C % 8 or not isinstance(self.norm, LayerNorm):
+            return self.forward(s + DropPath.apply_scale(m, sc))
+        y = ops.merge_layer_norm(m, self.norm.weight, self.norm.bias, self.norm.eps, residual=s, x_scale=sc)
+        return self.reduction(y)
+
 
 class BasicLayer(nn.Module):
     def __init__(self, dim, depth, num_heads, window_size=(1, 7, 7), mlp_ratio=4., qkv_bias=False, qk_scale=None,
@@ -288,6 +297,8 @@ class BasicLayer(nn.Module):
     def forward(self, x):
         """x bf16 channels-last [B,D,H,W,C] -> [B,D,H',W',C'] (the reference takes/returns B C D H W)."""
         s, m, sc = self.forward_pending(x)
+        if self.downsample is not None and hasattr(self.downsample, 'forward_pending'):
+            return self.downsample.forward_pending(s, m, sc)
         x = s + DropPath.apply_scale(m, sc)
         if self.downsample is not None:
             x = self.downsample(x)

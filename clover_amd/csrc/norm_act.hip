@@ -265,7 +265,21 @@ struct LnX {
     float inv_keep;
     const unsigned long long* seed;
     int on_load;                         // backward: 1 = x is the raw operand (re-apply), 0 = x already holds t
+    // PatchMerging gather (swin_transformer_3d.py:531-539): the row of width C = 4*gC is the concatenation of the
+    // gC-wide source rows (2h+hp, 2w+wp) with channel block q = 2*wp + hp; x / res / dx / dres are then the
+    // UN-gathered [.., 2*gH2, 2*gW2, gC] tensors and the kernels address them through src_off().  gC = 0: off.
+    int gC, gH2, gW2;
 };
+
+// element offset in the un-gathered tensor of column c (a multiple of 8; gC % 8 == 0) of gathered row `row`
+__device__ __forceinline__ int64_t ln_src_off(const LnX& xf, int64_t row, int c, int C) {
+    if (!xf.gC) return row * C + c;
+    const int q = c / xf.gC;
+    const int64_t w2 = row % xf.gW2, t = row / xf.gW2;
+    const int64_t h2 = t % xf.gH2, bd = t / xf.gH2;
+    const int64_t src = (bd * (2 * xf.gH2) + 2 * h2 + (q & 1)) * (2 * xf.gW2) + 2 * w2 + (q >> 1);
+    return src * xf.gC + (c - q * xf.gC);
+}
 
 __device__ __forceinline__ float ln_keep(unsigned long long seed, unsigned row, unsigned col, unsigned thresh,
                                          float inv_keep) {
@@ -326,7 +340,8 @@ __device__ __forceinline__ void lnv_load(float (&t)[ITERS][8], float (&m)[ITERS]
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t[i][e] = 0.f; m[i][e] = 1.f; }
         if (c < C) {
-            IO8<T>::ld(x + row * C + c, t[i]);
+            const int64_t off = XF ? ln_src_off(xf, row, c, C) : row * C + c;
+            IO8<T>::ld(x + off, t[i]);
             if (XF) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -338,7 +353,7 @@ __device__ __forceinline__ void lnv_load(float (&t)[ITERS][8], float (&m)[ITERS]
             }
             if (res) {
                 float r[8];
-                IO8<T>::ld(res + row * C + c, r);
+                IO8<T>::ld(res + off, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[i][e] += r[e];
             }
@@ -478,12 +493,13 @@ __global__ void __launch_bounds__(LN_THREADS) lnv_bwd_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += a[e];
                 }
-                if (dres) IO8<T>::st(dres + row * C + c, o);
+                const int64_t off = XF ? ln_src_off(xf, row, c, C) : row * C + c;
+                if (dres) IO8<T>::st(dres + off, o);
                 if (XF) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] *= m[i][e];
                 }
-                IO8<T>::st(dx + row * C + c, o);
+                IO8<T>::st(dx + off, o);
             }
         }
     }
@@ -566,8 +582,13 @@ inline int lnv_blocks(int64_t rows, int group) {
     LNV_CASE(64, 6, KERNEL, TY, XF, GRID, __VA_ARGS__)
 
 inline bool make_lnx(const ClvLnExtra* ex, LnX& xf) {
-    xf = LnX{nullptr, 1, 0u, 1.f, nullptr, 0};
+    xf = LnX{nullptr, 1, 0u, 1.f, nullptr, 0, 0, 0, 0};
     if (!ex) return false;
+    if (ex->gather_c > 0) {
+        xf.gC = ex->gather_c;
+        xf.gH2 = ex->gather_h2;
+        xf.gW2 = ex->gather_w2;
+    }
     xf.xscale = ex->xscale;
     xf.rows_per_sample = ex->rows_per_sample > 0 ? ex->rows_per_sample : 1;
     if (ex->drop_p > 0.f) {
@@ -576,7 +597,7 @@ inline bool make_lnx(const ClvLnExtra* ex, LnX& xf) {
         xf.seed = (const unsigned long long*)ex->seed;
     }
     xf.on_load = ex->x_is_sum ? 0 : 1;
-    return xf.xscale != nullptr || xf.thresh != 0;
+    return xf.xscale != nullptr || xf.thresh != 0 || xf.gC != 0;
 }
 
 // --------------------------------------------------------------------------- GELU
@@ -644,6 +665,9 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
     LnX xf;
     const bool XF = make_lnx(extra, xf);
     if (xf.thresh && !xf.seed) return CLV_ERR_ARG;
+    if (xf.gC && (xf.gC * 4 != C || (xf.gC & 7) || xf.gH2 <= 0 || xf.gW2 <= 0 || rows % ((int64_t)xf.gH2 * xf.gW2) ||
+                  sum_out || xf.thresh))
+        return CLV_ERR_ARG;
     LnvCfg cfg;
     if (lnv_config(C, cfg)) {
         const int grid = lnv_blocks(rows, cfg.group);
@@ -689,6 +713,9 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
     LnX xf;
     const bool XF = make_lnx(extra, xf);
     if (xf.thresh && !xf.seed) return CLV_ERR_ARG;
+    if (xf.gC && (xf.gC * 4 != C || (xf.gC & 7) || xf.gH2 <= 0 || xf.gW2 <= 0 || rows % ((int64_t)xf.gH2 * xf.gW2) ||
+                  dsum || xf.thresh || !xf.on_load))
+        return CLV_ERR_ARG;
     const void* dy2 = extra ? extra->dy2 : nullptr;
     void* dres = extra ? extra->dres : nullptr;
     const int grid = clv_layernorm_bwd_blocks(rows, C);

@@ -460,7 +460,7 @@ def _ln_extra(xscale, rows_per_sample, drop_p, seed, dy2=None, dres=None, x_is_s
     if xscale is None and not drop_p and dy2 is None and dres is None:
         return None
     return _lib.ClvLnExtra(_ptr(xscale), int(rows_per_sample), float(drop_p or 0.0), _ptr(seed), _ptr(dy2),
-                           _ptr(dres), int(x_is_sum))
+                           _ptr(dres), int(x_is_sum), 0, 0, 0)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -569,6 +569,74 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_sca
     y, s, y2 = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum), x_scale, float(x_dropout_p), bool(fork))
     out = (y,) + ((s,) if return_sum else ()) + ((y2,) if fork else ())
     return out if len(out) > 1 else y
+
+
+class _MergeLayerNorm(torch.autograd.Function):
+    """PatchMerging's gather + LayerNorm (swin_transformer_3d.py:531-541) as ONE kernel each way, with the pending
+    residual of the stage's last block folded in: y = LN(gather(xscale[b] * x + res)) over rows of 4C, where
+    gather concatenates the (2h, 2w), (2h+1, 2w), (2h, 2w+1), (2h+1, 2w+1) neighbours.  x / res stay in their
+    natural [B, D, H, W, C] layout — the kernels address the four source rows themselves, forward (loads) and
+    backward (each gradient element is written exactly once) — so neither the strided gather copy, nor the residual
+    add, nor the DropPath multiply runs as a kernel."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, xscale):
+        _need_gpu(x, gamma)
+        B, D, H, W, Cs = x.shape
+        assert H % 2 == 0 and W % 2 == 0 and Cs % 8 == 0
+        x2 = _c(x if x.dtype == BF16 else x.to(BF16))
+        r2 = _c(res if res.dtype == BF16 else res.to(BF16)) if res is not None else None
+        g, b = _c(gamma.float()), _c(beta.float())
+        H2, W2 = H // 2, W // 2
+        rows = B * D * H2 * W2
+        y = torch.empty(B, D, H2, W2, 4 * Cs, device=x.device, dtype=BF16)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        xs = _c(xscale.reshape(-1).float()) if xscale is not None else None
+        assert xs is None or xs.numel() == B
+        ex = _lib.ClvLnExtra(_ptr(xs), D * H2 * W2, 0.0, None, None, None, 0, Cs, H2, W2)
+        check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), None, _ptr(mean), _ptr(rstd),
+                                           rows, 4 * Cs, float(eps), 0, C.byref(ex), _stream()), 'clv_layernorm_fwd')
+        ctx.save_for_backward(x2, r2, g, mean, rstd, xs)
+        ctx.geom = (B, D, H2, W2, Cs)
+        ctx.gref, ctx.bref, ctx.gdtype = gamma, beta, gamma.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, g, mean, rstd, xs = ctx.saved_tensors
+        B, D, H2, W2, Cs = ctx.geom
+        rows, C_ = B * D * H2 * W2, 4 * Cs
+        dy2 = _c(dy if dy.dtype == BF16 else dy.to(BF16))
+        L = _lib.lib()
+        nblk = L.clv_layernorm_bwd_blocks(rows, C_)
+        partial = torch.empty(2 * nblk * C_, device=x2.device, dtype=torch.float32)
+        dx = torch.empty_like(x2)
+        dres = torch.empty_like(x2) if (xs is not None and r2 is not None) else None
+        gsink = getattr(ctx.gref, '_clv_grad', None)
+        bsink = getattr(ctx.bref, '_clv_grad', None)
+        sink = gsink is not None and bsink is not None and gsink.dtype == torch.float32
+        if sink:
+            dg, db = gsink, bsink
+        else:
+            dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
+            db = torch.zeros_like(dg)
+        ex = _lib.ClvLnExtra(_ptr(xs), D * H2 * W2, 0.0, None, None, _ptr(dres), 0, Cs, H2, W2)
+        check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), None, _ptr(dx),
+                                  _ptr(dg), _ptr(db), _ptr(partial), rows, C_, 0, C.byref(ex), _stream()),
+              'clv_layernorm_bwd')
+        drv = None if r2 is None else (dres if dres is not None else dx)
+        if sink:
+            ctx.gref._clv_ready()
+            ctx.bref._clv_ready()
+            return dx, drv, None, None, None, None
+        return dx, drv, dg.to(ctx.gdtype), db.to(ctx.gdtype), None, None
+
+
+def merge_layer_norm(x, weight, bias, eps=1e-5, residual=None, x_scale=None):
+    """LayerNorm(PatchMerging-gather(x_scale[b] * x + residual)): x, residual bf16 [B, D, H, W, C] (H, W even, C % 8 == 0)
+    -> bf16 [B, D, H/2, W/2, 4C] in the reference's concat order."""
+    return _MergeLayerNorm.apply(x, residual, weight, bias, eps, x_scale)
 
 
 # --------------------------------------------------------------------------- GELU

@@ -121,6 +121,11 @@ typedef struct ClvLnExtra {
     const void* dy2;           /* backward: second upstream gradient (same type as dy), or NULL */
     void* dres;                /* backward: gradient wrt res when it differs from dx, or NULL */
     int32_t x_is_sum;
+    /* PatchMerging (swin_transformer_3d.py:531-539) folded into the LayerNorm that follows it: with gather_c > 0 the
+     * normalised row of width C = 4*gather_c is [x(2h,2w) | x(2h+1,2w) | x(2h,2w+1) | x(2h+1,2w+1)] of the UN-gathered
+     * x / res [.., 2*gather_h2, 2*gather_w2, gather_c]; rows = .. * gather_h2 * gather_w2; y stays [rows][C]; the
+     * backward writes dx / dres in the un-gathered layout (every element exactly once).  No sum_out / dsum / dropout. */
+    int32_t gather_c, gather_h2, gather_w2;
 } ClvLnExtra;
 int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                       void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,

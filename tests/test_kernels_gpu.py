@@ -143,6 +143,45 @@ def test_window_attention(case):
     assert rel(tg.grad, tr.grad) < 3e-2, rel(tg.grad, tr.grad)
 
 
+@pytest.mark.parametrize('B,D,H,W,C', [(2, 4, 56, 56, 96), (2, 2, 28, 28, 192), (3, 4, 14, 14, 384), (1, 1, 2, 2, 8),
+                                       (2, 3, 6, 10, 128)])
+@pytest.mark.parametrize('with_res,with_scale', [(True, True), (True, False), (False, False), (False, True)])
+def test_merge_layer_norm(B, D, H, W, C, with_res, with_scale):
+    """PatchMerging gather + LayerNorm (+ pending residual, + DropPath factor) in one kernel each way, against
+    the oracle's gather (swin_transformer_3d.py:531-539 order) followed by torch LayerNorm."""
+    x = rnd(B, D, H, W, C, seed=141).to(BF)
+    r = rnd(B, D, H, W, C, seed=142).to(BF) if with_res else None
+    sc = torch.tensor([0.0, 1.25, 1.25][:B] if B <= 3 else [1.25] * B) if with_scale else None
+    g = 1 + 0.1 * rnd(4 * C, seed=143)
+    b = 0.1 * rnd(4 * C, seed=144)
+    dy = rnd(B, D, H // 2, W // 2, 4 * C, seed=145).to(BF)
+
+    xr = x.float().requires_grad_()
+    rr = r.float().requires_grad_() if with_res else None
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    t = xr * (sc.view(B, 1, 1, 1, 1) if with_scale else 1.0)
+    if with_res:
+        t = t + rr
+    gathered = torch.cat([t[:, :, 0::2, 0::2], t[:, :, 1::2, 0::2], t[:, :, 0::2, 1::2], t[:, :, 1::2, 1::2]], -1)
+    assert np.array_equal(gathered.detach().numpy(), ix.patch_merging_gather(t.detach().numpy()))   # the oracle's order
+    y_ref = F.layer_norm(gathered, (4 * C,), gr, br, 1e-5)
+    y_ref.backward(dy.float())
+
+    xg = x.to(DEV).requires_grad_()
+    rg = r.to(DEV).requires_grad_() if with_res else None
+    gg, bg = g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops().merge_layer_norm(xg, gg, bg, 1e-5, residual=rg, x_scale=sc.to(DEV) if with_scale else None)
+    y.backward(dy.to(DEV))
+    assert y.shape == y_ref.shape
+    assert rel(y, y_ref) < 2e-2, rel(y, y_ref)
+    assert rel(xg.grad, xr.grad) < 2e-2, rel(xg.grad, xr.grad)
+    if with_res:
+        assert rel(rg.grad, rr.grad) < 2e-2
+    assert rel(gg.grad, gr.grad) < 2e-2 and rel(bg.grad, br.grad) < 2e-2
+    if with_scale:
+        assert xg.grad[0].abs().max().item() == 0.0          # dropped path: no gradient into the branch
+
+
 # ----------------------------------------------------------------------------- sequence attention
 @pytest.mark.parametrize('B,S,nH,hd', [(3, 16, 2, 64), (2, 32, 12, 64), (2, 228, 12, 64), (2, 40, 4, 32), (1, 408, 2, 64)])
 def test_seq_attention(B, S, nH, hd):
