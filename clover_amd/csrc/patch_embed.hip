@@ -186,6 +186,52 @@ bool make_shape(PEShape& S, int B, int T, int H, int W, int mh, int mw) {
     return true;
 }
 
+// Backward of the mask-token blend (swin_transformer_3d.py:222-230): out_masked = y (1 - w) + mask_token w and
+// out_clean = y, so  dy = d_clean + d_masked (1 - w)  and  d mask_token = sum over tokens of d_masked w
+// (w in {0,1} per token, from the [B][mh][mw] video mask).  One pass: each thread owns 8 channels of a row
+// stripe; the mask-token sum is folded per block through LDS and added with one atomic per channel.
+template <int CV>
+__global__ void __launch_bounds__(256) blend_bwd_kernel(const bf16_t* __restrict__ dclean,
+                                                        const bf16_t* __restrict__ dmasked,
+                                                        const int64_t* __restrict__ vmask, bf16_t* __restrict__ dy,
+                                                        float* __restrict__ dmt, PEShape S) {
+    constexpr int CH = CV / 8;                    // 16-byte chunks per row
+    constexpr int RPB = 256 / CH;                 // rows per block pass
+    __shared__ float red[RPB][CV];
+    const int t = threadIdx.x, rl = t / CH, ck = t - rl * CH;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (rl < RPB) {
+        for (int64_t m = (int64_t)blockIdx.x * RPB + rl; m < S.M; m += (int64_t)gridDim.x * RPB) {
+            int b, tp, hp, wp;
+            tok_coords(S, m, b, tp, hp, wp);
+            const bool masked = dmasked && vmask[((int64_t)b * S.mh + hp / S.ch) * S.mw + wp / S.cw] != 0;
+            Frag8 c, d, o;
+            c.u4 = dclean ? *reinterpret_cast<const uint4*>(dclean + m * CV + ck * 8) : make_uint4(0, 0, 0, 0);
+            d.u4 = dmasked ? *reinterpret_cast<const uint4*>(dmasked + m * CV + ck * 8) : make_uint4(0, 0, 0, 0);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dm = bf2f(d.h[e]);
+                v[e] = bf2f(c.h[e]) + (masked ? 0.f : dm);
+                if (masked) acc[e] += dm;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.u[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<uint4*>(dy + m * CV + ck * 8) = o.u4;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl][ck * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (dmt && t < CV) {
+        float sum = 0.f;
+        for (int r = 0; r < RPB; ++r) sum += red[r][t];
+        if (sum != 0.f) atomicAdd(dmt + t, sum);
+    }
+}
+
 }  // namespace
 
 extern "C" int clv_patch_embed_fwd(const float* x, const void* w, const float* bias, const float* gamma,
@@ -224,5 +270,30 @@ extern "C" int clv_im2col_patches(const float* x, void* patches, int32_t B, int3
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)patches, S);
+    return clv_check_launch();
+}
+
+extern "C" int clv_patch_embed_blend_bwd(const void* dclean, const void* dmasked, const int64_t* vmask, void* dy,
+                                         float* dmask_token, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C,
+                                         int32_t mh, int32_t mw, void* stream) {
+    PEShape S;
+    if (!dy || (!dclean && !dmasked) || (dmasked && (!vmask || !dmask_token))) return CLV_ERR_ARG;
+    if (!make_shape(S, B, T, H, W, dmasked ? mh : 1, dmasked ? mw : 1)) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define BB_LAUNCH(CV)                                                                                             \
+    {                                                                                                             \
+        const int rpb = 256 / (CV / 8);                                                                           \
+        int64_t g = (S.M + rpb - 1) / rpb;                                                                        \
+        if (g > 2048) g = 2048;                                                                                   \
+        hipLaunchKernelGGL((blend_bwd_kernel<CV>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dclean,    \
+                           (const bf16_t*)dmasked, vmask, (bf16_t*)dy, dmask_token, S);                           \
+    }
+    switch (C) {
+        case 48: BB_LAUNCH(48) break;
+        case 96: BB_LAUNCH(96) break;
+        case 128: BB_LAUNCH(128) break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef BB_LAUNCH
     return clv_check_launch();
 }

@@ -958,20 +958,25 @@ class _PatchEmbed(torch.autograd.Function):
         B, T, H, W, Cout, want_clean, want_masked, wshape, mtshape = ctx.meta
         Tp, Hp, Wp = T // 2, H // 4, W // 4
         M = B * Tp * Hp * Wp
-        dy = None
-        dmt = None
-        if want_clean and dclean is not None:
-            dy = dclean.reshape(M, Cout).float()
-        if want_masked and dmasked is not None:
-            mh, mw = vm.shape[1], vm.shape[2]
-            wt = vm.to(torch.float32).repeat_interleave(Hp // mh, 1).repeat_interleave(Wp // mw, 2)   # [B,Hp,Wp]
-            wt = wt[:, None].expand(B, Tp, Hp, Wp).reshape(M, 1)
-            dm = dmasked.reshape(M, Cout).float()
-            dmt = (dm * wt).sum(0).reshape(mtshape)
-            dm = dm * (1.0 - wt)
-            dy = dm if dy is None else dy + dm
         L = _lib.lib()
-        dyb = dy.to(BF16).contiguous()
+
+        def bf(t):
+            if t is None:
+                return None
+            t = _c(t.reshape(M, Cout))
+            return t if t.dtype == BF16 else t.to(BF16)
+        dc = bf(dclean) if want_clean else None
+        dm = bf(dmasked) if want_masked else None
+        dmt = None
+        if dm is None:
+            dyb = dc
+        else:
+            # dy = d_clean + d_masked (1 - w), d mask_token = sum d_masked w — one kernel (clv_patch_embed_blend_bwd)
+            dyb = torch.empty(M, Cout, device=xc.device, dtype=BF16)
+            dmt = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
+            check(L.clv_patch_embed_blend_bwd(_ptr(dc), _ptr(dm), _ptr(vm), _ptr(dyb), _ptr(dmt), B, T, H, W, Cout,
+                                              vm.shape[1], vm.shape[2], _stream()), 'clv_patch_embed_blend_bwd')
+            dmt = dmt.reshape(mtshape)
         if gf is not None:
             nblk = L.clv_layernorm_bwd_blocks(M, Cout)
             partial = torch.empty(2 * nblk * Cout, device=xc.device, dtype=torch.float32)

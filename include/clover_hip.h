@@ -167,6 +167,11 @@ int clv_patch_embed_fwd(const float* x, const void* w, const float* bias, const 
                         void* out_clean, void* out_masked, void* z_out, float* mean, float* rstd,
                         int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t mh,
                         int32_t mw, float eps, void* stream);
+/* Backward of the mask-token blend (:222-230): dy = d_clean + d_masked (1 - w) (bf16 [M][C]; either input may be NULL)
+ * and dmask_token float [C] += sum over tokens of d_masked w (ACCUMULATED; caller zeroes), w from vmask as above. */
+int clv_patch_embed_blend_bwd(const void* dclean, const void* dmasked, const int64_t* vmask, void* dy,
+                              float* dmask_token, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C,
+                              int32_t mh, int32_t mw, void* stream);
 /* im2col of the clip into bf16 patches [M][96] (k = c*32 + dt*16 + dy*4 + dx): the operand
  * of the weight-gradient GEMM dW = dZ^T * patches (the conv3d weight grad of :681). */
 int clv_im2col_patches(const float* x, void* patches, int32_t B, int32_t T, int32_t H, int32_t W,
