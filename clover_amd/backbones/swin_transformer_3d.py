@@ -339,6 +339,13 @@ class PatchEmbed3D(nn.Module):
         eps = self.norm.eps if self.norm is not None else 1e-5
         return ops.patch_embed(x, self.proj.weight, self.proj.bias, g, b, mask_token, vmask, want_clean, eps)
 
+    def tokens_stacked(self, x, mask_token, vmask):
+        """fp32 clip [B,3,T,H,W] -> bf16 [2B,T',H',W',C]: clean tokens, then mask-token-blended tokens."""
+        x = self.pad(x)
+        g, b = (self.norm.weight, self.norm.bias) if self.norm is not None else (None, None)
+        eps = self.norm.eps if self.norm is not None else 1e-5
+        return ops.patch_embed_stacked(x, self.proj.weight, self.proj.bias, g, b, mask_token, vmask, eps)
+
     def forward(self, x):
         """Reference contract: [B,3,T,H,W] -> [B,C,T',H',W']."""
         clean, _ = self.tokens(x)
@@ -494,8 +501,7 @@ class SwinTransformer3D(nn.Module):
 
     def forward_both(self, x, mask):
         """As ``forward_pair`` but returns the one [2B,T',h,w,Cf] tensor (clean clips first, masked clips second)."""
-        clean, masked = self.patch_embed.tokens(x, self.mask_token, mask)
-        return self._stages(torch.cat([clean, masked], dim=0))
+        return self._stages(self.patch_embed.tokens_stacked(x, self.mask_token, mask))
 
     def forward(self, x, mask=None):
         """Reference contract: [B,3,T,H,W] -> [B,Cf,T',h,w]; with ``mask`` -> (x, w)."""

@@ -920,7 +920,7 @@ def seq_attention(qkv, kmask, num_heads, dropout_p=0.0):
 # --------------------------------------------------------------------------- patch embed
 class _PatchEmbed(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps):
+    def forward(ctx, x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps, stacked=False):
         _need_gpu(x, weight)
         B, Cin, T, H, W = x.shape
         Cout = weight.shape[0]
@@ -937,8 +937,14 @@ class _PatchEmbed(torch.autograd.Function):
         M = B * Tp * Hp * Wp
         dev = x.device
         need_grad = any(t is not None and t.requires_grad for t in (weight, bias, gamma, beta, mask_token))
-        clean = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_clean else None
-        masked = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_masked else None
+        both = None
+        if stacked:                      # clean and masked tokens as the two halves of ONE [2B, ...] tensor
+            assert want_clean and want_masked
+            both = torch.empty(2 * B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16)
+            clean, masked = both[:B], both[B:]
+        else:
+            clean = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_clean else None
+            masked = torch.empty(B, Tp, Hp, Wp, Cout, device=dev, dtype=BF16) if want_masked else None
         z = torch.empty(M, Cout, device=dev, dtype=BF16) if need_grad else None
         mean = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
         rstd = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
@@ -949,6 +955,9 @@ class _PatchEmbed(torch.autograd.Function):
         ctx.save_for_backward(xc, z, mean, rstd, gf, vm)
         ctx.meta = (B, T, H, W, Cout, want_clean, want_masked, weight.shape,
                     mask_token.shape if mask_token is not None else None)
+        ctx.stacked = bool(stacked)
+        if stacked:
+            return both, x.new_empty(0)
         outs = (clean if want_clean else x.new_empty(0), masked if want_masked else x.new_empty(0))
         return outs
 
@@ -965,6 +974,8 @@ class _PatchEmbed(torch.autograd.Function):
                 return None
             t = _c(t.reshape(M, Cout))
             return t if t.dtype == BF16 else t.to(BF16)
+        if ctx.stacked:                  # dclean holds the gradient of the stacked [2B, ...] output
+            dclean, dmasked = (dclean[:B], dclean[B:]) if dclean is not None else (None, None)
         dc = bf(dclean) if want_clean else None
         dm = bf(dmasked) if want_masked else None
         dmt = None
@@ -992,7 +1003,7 @@ class _PatchEmbed(torch.autograd.Function):
         check(L.clv_im2col_patches(_ptr(xc), _ptr(patches), B, T, H, W, _stream()), 'clv_im2col_patches')
         dw, dbias = linear_wgrad(dz, patches, True)
         dw = dw.reshape(wshape)
-        return None, dw, dbias, dg, db, dmt, None, None, None
+        return None, dw, dbias, dg, db, dmt, None, None, None, None
 
 
 def patch_embed(x, weight, bias, gamma, beta, mask_token=None, vmask=None, want_clean=True, eps=1e-5):
@@ -1000,6 +1011,12 @@ def patch_embed(x, weight, bias, gamma, beta, mask_token=None, vmask=None, want_
     Returns (clean, masked) bf16 [B,T/2,H/4,W/4,C] channels-last (masked None without vmask)."""
     clean, masked = _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps)
     return (clean if want_clean else None), (masked if vmask is not None else None)
+
+
+def patch_embed_stacked(x, weight, bias, gamma, beta, mask_token, vmask, eps=1e-5):
+    """As patch_embed, but the clean and the masked tokens are written as the two halves of one bf16
+    [2B,T/2,H/4,W/4,C] tensor (clean first) — the layout the doubled Swin pass consumes, without a cat."""
+    return _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, True, eps, True)[0]
 
 
 # --------------------------------------------------------------------------- focal MLM loss

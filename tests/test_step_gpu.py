@@ -64,12 +64,14 @@ def test_swin_backbone(model):
         y = model.backbone(x)
         ym, w = model.backbone(x.clone(), vm)
         yc2, ym2 = model.backbone.forward_pair(x, vm)
+        yb = model.backbone.forward_both(x, vm)
     assert y.shape == g['clean.out'].shape
     assert rel(y, g['clean.out']) < 3e-2, rel(y, g['clean.out'])
     assert rel(ym, g['masked.out']) < 3e-2
     assert np.array_equal(w.float().cpu().numpy().astype(np.int8), g["masked.w"])          # bit-exact blend map
     # the batched 2B pass equals the two separate passes
     assert torch.equal(yc2.permute(0, 4, 1, 2, 3), y) and torch.equal(ym2.permute(0, 4, 1, 2, 3), ym)
+    assert torch.equal(yb, torch.cat([yc2, ym2], 0))           # stacked patch-embed output, no cat
 
 
 def test_text_and_fusion(model):
