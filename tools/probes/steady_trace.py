@@ -53,7 +53,10 @@ for s, e, n in win:
     short = n.replace('(anonymous namespace)::', '').replace('void ', '')
     short = short.split('(')[0] if not short.startswith(('Cijk', 'Custom')) else 'hipBLASLt GEMM'
     if 'at::native' in short:
-        short = 'aten ' + short.split('at::native::')[1][:60]
+        import re
+        body = short.split('at::native::', 1)[1]
+        fn = re.findall(r'at::native::(?:\(anonymous namespace\)::)?([A-Za-z_0-9]+(?:<[a-zA-Z0-9_:]+>)?)', short)
+        short = 'aten ' + body.split('<')[0][:28] + ' ' + ' '.join(fn[1:3])[:60]
     agg[short][0] += 1
     agg[short][1] += e - s
 print(f'{"kernel":70s} {"n/step":>7s} {"us/step":>9s} {"share":>6s}')
