@@ -134,18 +134,21 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
     def _parse_losses(self, losses):
         """loss = sum of every entry whose key contains 'loss'; log_vars = all entries (+ 'loss'),
         averaged over ranks (reference :254-288)."""
-        log_vars = OrderedDict()
+        vals = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                vals[name] = value if value.dim() == 0 else value.mean()       # mean of a scalar is the scalar
             elif isinstance(value, list):
-                log_vars[name] = sum(_l.mean() for _l in value)
+                vals[name] = sum(_l.mean() for _l in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
-        names = list(log_vars.keys())
-        packed = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        # one stack + one sum instead of a chain of scalar kernels (and of their backward nodes)
+        names = list(vals.keys())
+        stacked = torch.stack([v.float().reshape(()) for v in vals.values()])
+        pick = [i for i, k in enumerate(names) if 'loss' in k]
+        loss = stacked.sum() if len(pick) == len(names) else stacked[pick].sum()
+        names.append('loss')
+        packed = torch.cat([stacked.detach(), loss.detach().reshape(1)])
         if collectives_active():
             packed = packed / dist.get_world_size()
             dist.all_reduce(packed)
