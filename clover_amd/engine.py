@@ -18,6 +18,8 @@ DefaultOptimizerConstructor + AdamW (pretrain_webvid_cc3m.py:129-137), Fp16Optim
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -119,6 +121,7 @@ class CloverEngine:
         self.step_count = 0
         self.graph = None
         self.graph_bwd_video = None
+        self.graph_bwd_text = None
         self._captures = {}                    # batch-shape signature -> the captured graphs + their static tensors
         self._active_sig = None
         device = next(model.parameters()).device
@@ -198,8 +201,8 @@ class CloverEngine:
         return out
 
     # ------------------------------------------------------------------ hipGraph mode
-    _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', '_static_batch', '_static_emb', '_static_mlm',
-                       '_static_demb', '_static_dmlm', '_static_cuts')
+    _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
+                       '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts')
 
     @staticmethod
     def _signature(batch):
@@ -225,13 +228,30 @@ class CloverEngine:
         self._static_demb.copy_(emb.grad)
         if mlm is not None:
             self._static_dmlm.copy_(mlm.grad)
+        self._replay_backward()
+        return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
+
+    def _replay_backward(self):
         self.graph_bwd.replay()
         if self.graph_bwd_video is not None:
-            # heads / fusion / text-encoder gradients are complete: put their buckets on the wire, then run the
-            # video encoder's backward underneath that traffic (step() -> reducer.finish() sends the rest)
-            self.reducer.launch_where(self._is_non_video)
-            self.graph_bwd_video.replay()
-        return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
+            # Data-parallel mode: the backward is cut at the encoders' outputs.  The heads / fusion gradients are
+            # complete now: put their buckets on the wire.  Then the text encoder's backward (its own graph, on its
+            # own stream) and the video encoder's backward run CONCURRENTLY — as they do inside the single backward
+            # graph of a 1-GPU job — and the text encoder's buckets leave as soon as its graph is through, under the
+            # rest of the video backward; step() -> reducer.finish() sends what is left (the video encoder's).
+            if self.graph_bwd_text is not None:
+                self.reducer.launch_where(self._is_head)
+                main = torch.cuda.current_stream()
+                ts = self._bwd_text_stream
+                ts.wait_stream(main)
+                with torch.cuda.stream(ts):
+                    self.graph_bwd_text.replay()
+                    self.reducer.launch_where(self._is_non_video)
+                self.graph_bwd_video.replay()
+                main.wait_stream(ts)
+            else:
+                self.reducer.launch_where(self._is_non_video)
+                self.graph_bwd_video.replay()
 
     def capture(self, batch, warmup=2):
         """Capture the rank-local part of the step — CloverPretrain.encode and its backward, ~2300 of
@@ -247,55 +267,77 @@ class CloverEngine:
         self._static_batch = {k: v.clone() for k, v in batch.items()}
         sb = self._static_batch
 
+        import inspect
         cut_ok = self.reducer.active and hasattr(model, 'backbone')
+        text_ok = (cut_ok and hasattr(model, 'text_backbone')
+                   and 'text_cut' in inspect.signature(model.encode).parameters
+                   and os.environ.get('CLOVER_TEXT_CUT', '1') == '1')
         video_ids = {id(q) for q in model.backbone.parameters()} if cut_ok else set()
+        text_ids = {id(q) for q in model.text_backbone.parameters()} if text_ok else set()
         self._is_non_video = lambda q: id(q) not in video_ids
+        self._is_head = lambda q: id(q) not in video_ids and id(q) not in text_ids
+        if text_ok and getattr(self, '_bwd_text_stream', None) is None:
+            self._bwd_text_stream = torch.cuda.Stream()
 
-        def encode(cuts=None):
-            return model.encode(sb['imgs'], video_cut=cuts, **{k: sb[k] for k in aux})
+        def encode(vcuts=None, tcuts=None):
+            kw = {k: sb[k] for k in aux}
+            if text_ok:
+                kw['text_cut'] = tcuts
+            return model.encode(sb['imgs'], video_cut=vcuts, **kw)
 
-        def backward(emb, mlm, demb, dmlm, cuts):
-            """Backward in two pieces when the video encoder is cut off: everything else first (its gradient
-            buckets can then travel while the video encoder's backward runs), the video encoder second."""
-            torch.autograd.backward([emb] + ([mlm] if mlm is not None else []),
-                                    [demb] + ([dmlm] if mlm is not None else []))
-            if cuts:
-                torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
+        def roots(emb, mlm, demb, dmlm):
+            return [emb] + ([mlm] if mlm is not None else []), [demb] + ([dmlm] if mlm is not None else [])
+
+        def bwd_cut(cuts):
+            torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
         self.reducer.enabled = False           # no collective may be issued from inside a capture; in graph
         self.reducer.reset()                   # mode the engine launches the buckets between / after the replays
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                cuts = [] if cut_ok else None
-                emb, mlm = encode(cuts)
-                backward(emb, mlm, torch.zeros_like(emb), torch.zeros_like(mlm) if mlm is not None else None, cuts)
+                vcuts = [] if cut_ok else None
+                tcuts = [] if text_ok else None
+                emb, mlm = encode(vcuts, tcuts)
+                torch.autograd.backward(*roots(emb, mlm, torch.zeros_like(emb),
+                                               torch.zeros_like(mlm) if mlm is not None else None))
+                if vcuts:
+                    bwd_cut(vcuts)
+                if tcuts:
+                    bwd_cut(tcuts)
         torch.cuda.current_stream().wait_stream(side)
         # no autograd graph may survive into the capture: a live one pins the parameters'
         # AccumulateGrad nodes to the warm-up stream and their accumulation escapes the hipGraph
-        del emb, mlm, cuts
+        del emb, mlm, vcuts, tcuts
         for seg in self.segments:
             seg.flat_g.zero_()
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gb2 = torch.cuda.CUDAGraph() if cut_ok else None
+        gb3 = torch.cuda.CUDAGraph() if text_ok else None
         # thread_local: RCCL's watchdog thread (W > 1) keeps polling events while we capture
-        cuts = [] if cut_ok else None
+        vcuts = [] if cut_ok else None
+        tcuts = [] if text_ok else None
         with torch.cuda.graph(gf, capture_error_mode='thread_local'):
-            emb, mlm = encode(cuts)
+            emb, mlm = encode(vcuts, tcuts)
         self._static_demb = torch.zeros_like(emb)
         self._static_dmlm = torch.zeros_like(mlm) if mlm is not None else None
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
-            backward_outs = [emb] + ([mlm] if mlm is not None else [])
-            torch.autograd.backward(backward_outs, [self._static_demb, self._static_dmlm][:len(backward_outs)])
+            torch.autograd.backward(*roots(emb, mlm, self._static_demb, self._static_dmlm))
         if cut_ok:
             with torch.cuda.graph(gb2, pool=gf.pool(), capture_error_mode='thread_local'):
-                torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
+                bwd_cut(vcuts)
+        if text_ok:
+            # captured LAST and into a pool of its own: it replays concurrently with the video graph, so neither
+            # may recycle memory the other still reads (blocks this capture frees return to gf's pool after the
+            # video graph has been laid out; its own temporaries never alias the video graph's)
+            with torch.cuda.graph(gb3, capture_error_mode='thread_local'):
+                bwd_cut(tcuts)
         for seg in self.segments:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit
-        self.graph, self.graph_bwd, self.graph_bwd_video = gf, gb, gb2
+        self.graph, self.graph_bwd, self.graph_bwd_video, self.graph_bwd_text = gf, gb, gb2, gb3
         self._static_emb, self._static_mlm = emb, mlm
-        self._static_cuts = cuts
+        self._static_cuts = (vcuts, tcuts)
         self._active_sig = self._signature(batch)
         self._captures[self._active_sig] = tuple(getattr(self, f) for f in self._CAPTURE_FIELDS)
         return True

@@ -44,7 +44,7 @@ class CloverFinetune(BaseRecognizer):
     CLV_ENCODE_KEYS = ('token_ids', 'input_mask')
     EMB_NAMES = ('visual_emb', 'text_emb')
 
-    def _embeddings(self, imgs, token_ids, input_mask, video_cut=None):
+    def _embeddings(self, imgs, token_ids, input_mask, video_cut=None, text_cut=None):
         """Shared by train and test (:61-81 / :128-147): video tokens (mean over the clips of a sample when
         there are several), caption hidden states, then the two projections."""
         if self.training and imgs.is_cuda:
@@ -58,6 +58,10 @@ class CloverFinetune(BaseRecognizer):
 
         def text_side():
             text = self.text_backbone(token_ids, input_mask)['last_hidden_state']     # :78-79
+            if text_cut is not None:
+                leaf = text.detach().requires_grad_()
+                text_cut.append((text, leaf))
+                text = leaf
             return self.ssl_head.forward_text(text, input_mask, token_ids)
         # the caption encoder's kernels are tiny (B x L tokens) and independent of the video encoder: run them on
         # a side stream underneath the Swin kernels, as in the pre-training step
@@ -88,9 +92,9 @@ class CloverFinetune(BaseRecognizer):
             object.__setattr__(self, '_txt_stream', st)
         return st
 
-    def encode(self, imgs, token_ids=None, input_mask=None, video_cut=None, **kwargs):
+    def encode(self, imgs, token_ids=None, input_mask=None, video_cut=None, text_cut=None, **kwargs):
         """-> (emb fp32 [B, 2, D] in EMB_NAMES order, None): the retrieval step has no rank-local loss."""
-        v, t = self._embeddings(imgs, token_ids, input_mask, video_cut)
+        v, t = self._embeddings(imgs, token_ids, input_mask, video_cut, text_cut)
         return torch.stack([v, t], dim=1).float(), None
 
     def contrastive_losses(self, emb, _local_loss=None):

@@ -58,7 +58,7 @@ class CloverPretrain(BaseRecognizer):
                  'mask_word_recon_emb')
 
     def encode(self, imgs, token_ids=None, input_mask=None, mlm_label=None, v_token_mask=None, video_cut=None,
-               **kwargs):
+               text_cut=None, **kwargs):
         """Everything of the step that touches only THIS rank's samples: the three encoders, the heads
         and the MLM loss.  Returns (emb fp32 [B, 6, D] in EMB_NAMES order, mlm_loss).  No collective
         and no data-dependent shape inside — the engine captures it (and its backward) as hipGraphs."""
@@ -96,18 +96,16 @@ class CloverPretrain(BaseRecognizer):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                text_out = self.text_backbone(text_ids2, text_mask2)['last_hidden_state']
+                text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
                 txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
 
         # ---- video encoder: clean (:91) + masked (:114) pass as one 2B-clip pass, channels-last [2B,T',h,w,Cf]
         vis_both = self.backbone.forward_both(imgs, v_token_mask)
         if video_cut is not None:
-            # engine graph mode: cut the autograd graph at the video encoder's output, so that its backward can run
-            # as a separate graph AFTER the gradient all-reduce of everything else has been put in flight.
-            # video_cut receives [(output, detached leaf standing in for it downstream), ...]
-            cut = (vis_both, vis_both.detach().requires_grad_())
-            video_cut.append(cut)
-            vis_both = cut[1]
+            # engine graph mode (data parallel): the autograd graph is cut at the encoders' outputs, so that each
+            # encoder's backward is a graph of its own and gradient buckets can leave between them.
+            # A cut list receives [(output, detached leaf standing in for it downstream), ...]
+            vis_both = self._cut(vis_both, video_cut)
         _, T, h, w, D = vis_both.shape
 
         # ---- text encoder: masked caption (:110-111) + un-masked caption (:97-101)
@@ -116,7 +114,7 @@ class CloverPretrain(BaseRecognizer):
             text_out.record_stream(main)
             txt_emb_both.record_stream(main)
         else:
-            text_out = self.text_backbone(text_ids2, text_mask2)['last_hidden_state']
+            text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
             txt_emb_both = self.ssl_head.forward_text(text_out)
 
         # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack
@@ -141,6 +139,14 @@ class CloverPretrain(BaseRecognizer):
         emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
                            mask_word_recon_emb], dim=1).float()
         return emb, mlm_loss
+
+    @staticmethod
+    def _cut(t, cuts):
+        if cuts is None:
+            return t
+        leaf = t.detach().requires_grad_()
+        cuts.append((t, leaf))
+        return leaf
 
     def _text_stream(self, device):
         st = getattr(self, '_txt_stream', None)

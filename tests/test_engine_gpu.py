@@ -182,7 +182,7 @@ def test_finetune_engine_graph_equals_eager_and_trains(monkeypatch):
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         rccl, eng = run('rccl')
-        assert eng.reducer.active and eng.graph_bwd_video is not None
+        assert eng.reducer.active and eng.graph_bwd_video is not None and eng.graph_bwd_text is not None
     finally:
         dist.destroy_process_group()
     print(eager, graph, rccl)
@@ -207,6 +207,22 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
         eng.capture(b)
         return [eng.step(b)['log_vars']['loss'] for _ in range(3)], eng
 
+    def grads(eng, graph=True):
+        """every parameter's gradient of one more forward/backward (+ collectives), by name"""
+        for seg in eng.segments:
+            seg.flat_g.zero_()
+        if graph:
+            eng._graphed_forward_backward(b)
+        else:
+            eng.model.train_step(b, None)['loss'].backward()
+        eng.reducer.finish()
+        torch.cuda.synchronize()
+        out = {}
+        for seg in eng.segments:
+            for name, p_, off in zip(seg.names, seg.params, seg.offsets):
+                out[name] = seg.flat_g[off:off + p_.numel()].clone()
+        return out
+
     ref, _ = run()
     monkeypatch.setenv('CLOVER_FORCE_COLLECTIVES', '1')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -215,10 +231,18 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
     try:
         got, eng = run()
         assert eng.reducer.active and len(eng.reducer.buckets) > 1
+        assert eng.graph_bwd_video is not None and eng.graph_bwd_text is not None      # three backward graphs
+        g_got, g_ref = grads(eng), grads(eng, graph=False)
     finally:
         dist.destroy_process_group()
     for a, g in zip(ref, got):
         assert abs(a - g) < 0.02 * max(1.0, abs(a)), (ref, got)
+    # the cut backward (heads | text encoder || video encoder, buckets leaving in between) delivers every
+    # parameter's gradient, equal to the plain eager backward's on the same weights
+    assert set(g_got) == set(g_ref)
+    for name, r in g_ref.items():
+        scale = r.abs().max().item()
+        assert (g_got[name] - r).abs().max().item() <= 3e-2 * scale + 1e-6, name
 
 
 def test_checkpoint_roundtrip_through_engine(tmp_path):

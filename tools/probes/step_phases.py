@@ -34,10 +34,7 @@ for _ in range(N):
     loss.backward()
     eng._static_demb.copy_(emb.grad); eng._static_dmlm.copy_(mlm.grad)
     e[2].record()
-    eng.graph_bwd.replay()
-    if eng.graph_bwd_video is not None:
-        eng.reducer.launch_where(eng._is_non_video)
-        eng.graph_bwd_video.replay()
+    eng._replay_backward()
     e[3].record()
     eng.reducer.finish()
     e5 = ev(); e5.record()
