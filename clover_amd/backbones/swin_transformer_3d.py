@@ -475,21 +475,37 @@ class SwinTransformer3D(nn.Module):
         for i, m in enumerate(self._dp_mods):
             m.preset(scales[i])
 
-    def _stages(self, x):
+    # Data-parallel graph mode cuts the backward inside the encoder as well: the stages from CUT_STAGE on hold
+    # ~90 % of the encoder's parameters (Swin-T: 25 M of 28 M) but run on 1/16 of the tokens, so their backward is
+    # through early and their gradient buckets can travel under the token-heavy backward of stages 0-1.
+    CUT_STAGE = 2
+
+    def late_parameters(self):
+        """Parameters whose gradients are complete once the backward has come down to the CUT_STAGE input."""
+        if self.CUT_STAGE >= self.num_layers - 1:      # no such cut point in _stages (the last stage is not cut)
+            return []
+        mods = list(self.layers[self.CUT_STAGE:]) + [self.norm]
+        return [q for m in mods for q in m.parameters()]
+
+    def _stages(self, x, mid_cut=None):
         self._draw_drop_paths(x.shape[0], x.device)
         x = self.pos_drop(x)
-        for layer in self.layers[:-1]:
+        for i, layer in enumerate(self.layers[:-1]):
+            if mid_cut is not None and i == self.CUT_STAGE:
+                leaf = x.detach().requires_grad_()
+                mid_cut.append((x, leaf))
+                x = leaf
             x = layer(x)
         s, m, sc = self.layers[-1].forward_pending(x)    # last stage has no downsample:
         return self.norm(m, residual=s, x_scale=sc)      # its final residual add rides in the norm
 
-    def forward_tokens(self, x, mask=None):
+    def forward_tokens(self, x, mask=None, mid_cut=None):
         """[B,3,T,H,W] -> channels-last features [B,T',h,w,Cf] (masked pass if `mask` given)."""
         if mask is None:
             t, _ = self.patch_embed.tokens(x)
         else:
             _, t = self.patch_embed.tokens(x, self.mask_token, mask, want_clean=False)
-        return self._stages(t)
+        return self._stages(t, mid_cut)
 
     def forward_pair(self, x, mask):
         """Clean + masked pass of the pre-training step as ONE 2B-clip pass.
@@ -499,9 +515,10 @@ class SwinTransformer3D(nn.Module):
         y = self._stages(torch.cat([clean, masked], dim=0))
         return y[:B], y[B:]
 
-    def forward_both(self, x, mask):
-        """As ``forward_pair`` but returns the one [2B,T',h,w,Cf] tensor (clean clips first, masked clips second)."""
-        return self._stages(self.patch_embed.tokens_stacked(x, self.mask_token, mask))
+    def forward_both(self, x, mask, mid_cut=None):
+        """As ``forward_pair`` but returns the one [2B,T',h,w,Cf] tensor (clean clips first, masked clips second).
+        mid_cut: optional list that receives the (tensor, detached leaf) pair of the in-encoder backward cut."""
+        return self._stages(self.patch_embed.tokens_stacked(x, self.mask_token, mask), mid_cut)
 
     def forward(self, x, mask=None):
         """Reference contract: [B,3,T,H,W] -> [B,Cf,T',h,w]; with ``mask`` -> (x, w)."""

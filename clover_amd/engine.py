@@ -167,8 +167,21 @@ class CloverEngine:
         self.num_params = sum(p.numel() for _, p in used)
 
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
+        # gradient classes in the order their backward completes: 'h' heads + fusion encoder, 't' text encoder,
+        # 'v1' late video stages, 'v0' early video stages + patch embedding (graph mode sends buckets per class)
+        self._pclass = {}
+        if hasattr(model, 'backbone'):
+            for q in model.backbone.parameters():
+                self._pclass[id(q)] = 'v0'
+            if hasattr(model.backbone, 'late_parameters'):
+                for q in model.backbone.late_parameters():
+                    self._pclass[id(q)] = 'v1'
+        if hasattr(model, 'text_backbone'):
+            for q in model.text_backbone.parameters():
+                self._pclass[id(q)] = 't'
         self.reducer = BucketedGradReducer([(seg.flat_g, seg.params, seg.offsets) for seg in self.segments],
-                                           bucket_bytes=bucket_mb << 20)
+                                           bucket_bytes=bucket_mb << 20,
+                                           split_key=lambda q: self._pclass.get(id(q), 'h'))
         per_mod = {}
         for mod, grp in groups:
             seg = next(sg for sg in self.segments if any(q is grp[0] for q in sg.params))
@@ -231,27 +244,35 @@ class CloverEngine:
         self._replay_backward()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
 
+    def _ready(self, *classes):
+        cl = self._pclass
+        return lambda q: cl.get(id(q), 'h') in classes
+
     def _replay_backward(self):
         self.graph_bwd.replay()
-        if self.graph_bwd_video is not None:
-            # Data-parallel mode: the backward is cut at the encoders' outputs.  The heads / fusion gradients are
-            # complete now: put their buckets on the wire.  Then the text encoder's backward (its own graph, on its
-            # own stream) and the video encoder's backward run CONCURRENTLY — as they do inside the single backward
-            # graph of a 1-GPU job — and the text encoder's buckets leave as soon as its graph is through, under the
-            # rest of the video backward; step() -> reducer.finish() sends what is left (the video encoder's).
-            if self.graph_bwd_text is not None:
-                self.reducer.launch_where(self._is_head)
-                main = torch.cuda.current_stream()
-                ts = self._bwd_text_stream
-                ts.wait_stream(main)
-                with torch.cuda.stream(ts):
-                    self.graph_bwd_text.replay()
-                    self.reducer.launch_where(self._is_non_video)
-                self.graph_bwd_video.replay()
-                main.wait_stream(ts)
-            else:
-                self.reducer.launch_where(self._is_non_video)
-                self.graph_bwd_video.replay()
+        if self.graph_bwd_video is None:
+            return
+        # Data-parallel mode: the backward is cut at the encoders' outputs (and once inside the video encoder).  The
+        # heads / fusion gradients are complete now: put their buckets on the wire.  Then the text encoder's
+        # backward (its own graph, on its own stream) and the video encoder's backward run CONCURRENTLY — as they do
+        # inside the single backward graph of a 1-GPU job — and each gradient class's buckets leave as soon as its
+        # graph is through: the text encoder's under the rest of the video backward, the late video stages'
+        # (most of the encoder's parameters, little of its time) under the token-heavy early stages;
+        # step() -> reducer.finish() sends what is left (early stages + patch embedding: a few MB).
+        main = torch.cuda.current_stream()
+        ts = self._bwd_text_stream if self.graph_bwd_text is not None else None
+        self.reducer.launch_where(self._ready('h'))
+        if ts is not None:
+            ts.wait_stream(main)
+            with torch.cuda.stream(ts):
+                self.graph_bwd_text.replay()
+                self.reducer.launch_where(self._ready('h', 't'))
+        for i, g in enumerate(self.graph_bwd_video):
+            g.replay()
+            if i + 1 < len(self.graph_bwd_video):          # came down to the in-encoder cut
+                self.reducer.launch_where(self._ready('h', 'v1') if ts is not None else self._ready('h', 't', 'v1'))
+        if ts is not None:
+            main.wait_stream(ts)
 
     def capture(self, batch, warmup=2):
         """Capture the rank-local part of the step — CloverPretrain.encode and its backward, ~2300 of
@@ -272,10 +293,6 @@ class CloverEngine:
         text_ok = (cut_ok and hasattr(model, 'text_backbone')
                    and 'text_cut' in inspect.signature(model.encode).parameters
                    and os.environ.get('CLOVER_TEXT_CUT', '1') == '1')
-        video_ids = {id(q) for q in model.backbone.parameters()} if cut_ok else set()
-        text_ids = {id(q) for q in model.text_backbone.parameters()} if text_ok else set()
-        self._is_non_video = lambda q: id(q) not in video_ids
-        self._is_head = lambda q: id(q) not in video_ids and id(q) not in text_ids
         if text_ok and getattr(self, '_bwd_text_stream', None) is None:
             self._bwd_text_stream = torch.cuda.Stream()
 
@@ -290,6 +307,10 @@ class CloverEngine:
 
         def bwd_cut(cuts):
             torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
+
+        def bwd_video(cuts):                   # output cut first, then the in-encoder cut (backward order)
+            for c in reversed(cuts):
+                bwd_cut([c])
         self.reducer.enabled = False           # no collective may be issued from inside a capture; in graph
         self.reducer.reset()                   # mode the engine launches the buckets between / after the replays
         side = torch.cuda.Stream()
@@ -302,7 +323,7 @@ class CloverEngine:
                 torch.autograd.backward(*roots(emb, mlm, torch.zeros_like(emb),
                                                torch.zeros_like(mlm) if mlm is not None else None))
                 if vcuts:
-                    bwd_cut(vcuts)
+                    bwd_video(vcuts)
                 if tcuts:
                     bwd_cut(tcuts)
         torch.cuda.current_stream().wait_stream(side)
@@ -313,7 +334,7 @@ class CloverEngine:
             seg.flat_g.zero_()
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        gb2 = torch.cuda.CUDAGraph() if cut_ok else None
+        gb2 = None
         gb3 = torch.cuda.CUDAGraph() if text_ok else None
         # thread_local: RCCL's watchdog thread (W > 1) keeps polling events while we capture
         vcuts = [] if cut_ok else None
@@ -325,8 +346,12 @@ class CloverEngine:
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
             torch.autograd.backward(*roots(emb, mlm, self._static_demb, self._static_dmlm))
         if cut_ok:
-            with torch.cuda.graph(gb2, pool=gf.pool(), capture_error_mode='thread_local'):
-                bwd_cut(vcuts)
+            gb2 = []
+            for c in reversed(vcuts):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=gf.pool(), capture_error_mode='thread_local'):
+                    bwd_cut([c])
+                gb2.append(g)
         if text_ok:
             # captured LAST and into a pool of its own: it replays concurrently with the video graph, so neither
             # may recycle memory the other still reads (blocks this capture frees return to gf's pool after the

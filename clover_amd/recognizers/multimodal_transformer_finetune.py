@@ -71,7 +71,7 @@ class CloverFinetune(BaseRecognizer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 text_emb = text_side()
-        vis = self.backbone.forward_tokens(imgs)                                      # channels-last [B,T',h,w,D]
+        vis = self.backbone.forward_tokens(imgs, mid_cut=video_cut)                   # channels-last [B,T',h,w,D]
         if video_cut is not None:            # engine graph mode: see CloverPretrain.encode
             cut = (vis, vis.detach().requires_grad_())
             video_cut.append(cut)

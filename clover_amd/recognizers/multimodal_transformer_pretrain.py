@@ -100,7 +100,7 @@ class CloverPretrain(BaseRecognizer):
                 txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
 
         # ---- video encoder: clean (:91) + masked (:114) pass as one 2B-clip pass, channels-last [2B,T',h,w,Cf]
-        vis_both = self.backbone.forward_both(imgs, v_token_mask)
+        vis_both = self.backbone.forward_both(imgs, v_token_mask, mid_cut=video_cut)
         if video_cut is not None:
             # engine graph mode (data parallel): the autograd graph is cut at the encoders' outputs, so that each
             # encoder's backward is a graph of its own and gradient buckets can leave between them.

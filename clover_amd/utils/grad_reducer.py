@@ -12,9 +12,11 @@ from .dist import collectives_active
 
 
 class BucketedGradReducer:
-    def __init__(self, slabs, bucket_bytes=64 << 20):
+    def __init__(self, slabs, bucket_bytes=64 << 20, split_key=None):
         """slabs: list of (flat_grad, params, offsets) with params[i].grad a view of
-        flat_grad[offsets[i]:offsets[i+1]] (in the order backward is expected to fill them)."""
+        flat_grad[offsets[i]:offsets[i+1]] (in the order backward is expected to fill them).
+        split_key(param): buckets never span a change of key (the engine's graph mode launches buckets per
+        gradient class — heads / text encoder / late / early video stages — as each class completes)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.enabled = True         # False: hooks are inert (hipGraph capture) and finish() sends everything
         self.buckets = []           # [flat_grad, start, end, n_params]
@@ -41,7 +43,8 @@ class BucketedGradReducer:
             for i, p in enumerate(params):
                 count += 1
                 end = offsets[i + 1]
-                if end - start >= cap or i == len(params) - 1:
+                boundary = split_key is not None and i + 1 < len(params) and split_key(params[i + 1]) != split_key(p)
+                if end - start >= cap or i == len(params) - 1 or boundary:
                     self.buckets.append([flat, start, end, count])
                     self._bucket_params.append(list(params[i + 1 - count:i + 1]))
                     b = len(self.buckets) - 1

@@ -202,6 +202,7 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
 
     def run():
         m = make_model()
+        m.backbone.CUT_STAGE = 0          # the tiny 2-stage encoder has no stage 2: put the in-encoder cut at stage 0
         eng = CloverEngine(m, b, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, bucket_mb=1)
         eng.step(b)
         eng.capture(b)
@@ -231,7 +232,10 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
     try:
         got, eng = run()
         assert eng.reducer.active and len(eng.reducer.buckets) > 1
-        assert eng.graph_bwd_video is not None and eng.graph_bwd_text is not None      # three backward graphs
+        assert len(eng.graph_bwd_video) == 2 and eng.graph_bwd_text is not None        # four backward graphs
+        classes = {eng._pclass.get(id(q), 'h') for ps in eng.reducer._bucket_params for q in ps}
+        assert classes == {'h', 't', 'v1', 'v0'}
+        assert all(len({eng._pclass.get(id(q), 'h') for q in ps}) == 1 for ps in eng.reducer._bucket_params)
         g_got, g_ref = grads(eng), grads(eng, graph=False)
     finally:
         dist.destroy_process_group()
