@@ -224,3 +224,44 @@ def test_finetune_other_tasks_refuse():
         cfg['task'] = task
         with pytest.raises(NotImplementedError):
             clover_amd.build_model(cfg)
+
+
+# ----------------------------------------------------------------------------- BASELINE config 2 at full size
+def test_full_size_step_matches_oracle():
+    """VideoSwin-T + BERT-base + 3-layer fusion at the benchmark's shapes (8 frames x 224^2, 32 tokens, B = 2,
+    seeded random init, eval mode so no dropout / DropPath): the five losses of the HIP step against the fp32 oracle
+    on the host cores, and a few gradients that cross every encoder.  Same tolerances as the config-1 goldens."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    from oracle import model as om
+    torch.manual_seed(4321)
+    cfg = bench.model_cfg('T', 8)
+    m = clover_amd.build_model(cfg).eval()
+    P = {k: v.detach().float().clone().requires_grad_(v.is_floating_point())
+         for k, v in m.state_dict().items() if 'relative_position_index' not in k}
+    batch = bench.synthetic_batch(2, 8, 32, seed=77)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    losses = om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False)
+    loss_ref, lv_ref = om.parse_losses(losses)
+    loss_ref.backward()
+
+    m = m.to(DEV)
+    out = m.train_step({k: v.to(DEV) for k, v in batch.items()}, None)
+    lv = out['log_vars']
+    errs = {k: abs(lv[k] - lv_ref[k]) for k in LOSS_KEYS}
+    print('full-size loss errors', errs, {k: lv_ref[k] for k in LOSS_KEYS})
+    for k in LOSS_KEYS:
+        assert errs[k] <= LOSS_TOL[k], (k, lv[k], lv_ref[k])
+    out['loss'].backward()
+    named = dict(m.named_parameters())
+    keys = ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.3.attn.relative_position_bias_table',
+            'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
+            'text_backbone.bert.encoder.layer.6.attention.self.query.weight',
+            'multimodal_backbone.bert_encoder.layer.2.output.dense.weight', 'mlm_head.predictions.decoder.weight']
+    worst = {k: rel(named[k].grad, P[k].grad.numpy()) for k in keys}
+    print('full-size grad rel errors', worst)
+    for k, e in worst.items():
+        assert e < 6e-2, (k, e)
