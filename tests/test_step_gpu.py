@@ -265,3 +265,31 @@ def test_full_size_step_matches_oracle():
     print('full-size grad rel errors', worst)
     for k, e in worst.items():
         assert e < 6e-2, (k, e)
+
+
+@pytest.mark.parametrize('frames', [16, 32])
+def test_long_clip_losses_match_oracle(frames):
+    """16- and 32-frame clips (BASELINE configs 4 / 5 clip lengths; windows of 392 tokens; fusion sequences of 424 tokens
+    on the fused kernels and of 816 tokens on the unfused GEMM + row-softmax path): the five losses of the HIP step
+    against the fp32 oracle, Swin-T + BERT-base, B = 2, eval mode."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    from oracle import model as om
+    torch.manual_seed(97 + frames)
+    cfg = bench.model_cfg('T', frames)
+    m = clover_amd.build_model(cfg).eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items() if 'relative_position_index' not in k}
+    batch = bench.synthetic_batch(2, frames, 32, seed=78)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        _, lv_ref = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
+    m = m.to(DEV)
+    with torch.no_grad():
+        lv = m.train_step({k: v.to(DEV) for k, v in batch.items()}, None)['log_vars']
+    errs = {k: abs(lv[k] - lv_ref[k]) for k in LOSS_KEYS}
+    print(f'{frames}-frame loss errors', errs)
+    for k in LOSS_KEYS:
+        assert errs[k] <= LOSS_TOL[k], (k, lv[k], lv_ref[k])
