@@ -296,6 +296,12 @@ def main():
             if os.path.exists(pmc):
                 rec = json.load(open(pmc)).get(res['roofline']['kernel'])
                 res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
+            # fraction of the dense bf16 MFMA peak the same kernel sustains, from the SQ / GRBM counter pass
+            # (tools/pmc_mfma.sh -> profiles/r01_pmc_mfma.json); null when not measured
+            mf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_mfma.json')
+            if os.path.exists(mf):
+                rec = json.load(open(mf)).get(res['roofline']['kernel'])
+                res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
         print(json.dumps(res))
