@@ -3,6 +3,7 @@ index/geometry helpers against the reference goldens (bit-exact), the C ABI surf
 no-CPU-fallback rule."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -297,3 +298,35 @@ def test_finetune_registered_and_refuses_without_gpu():
     assert not any(k.startswith(('mlm_head', 'mlm_ssl')) for k in m.state_dict())
     with pytest.raises(RuntimeError):
         m.loss_func(torch.randn(4, 8), torch.randn(4, 8))
+
+
+def test_tools_cli_host_side():
+    """tools/train.py and tools/test.py: the reference's argument names parse, and the synthetic test loader shards the
+    test set rank-major without losing or duplicating a pair (no GPU involved)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mods = {}
+    for name in ('train', 'test'):
+        spec = importlib.util.spec_from_file_location(f'clv_tools_{name}', os.path.join(root, 'tools', f'{name}.py'))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    argv = sys.argv
+    try:
+        sys.argv = ['train.py', 'cfg.py', '--work_dir', 'w', '--resume-from', 'a.pth', '--seed', '3', '--launcher', 'none',
+                    '--cfg-options', 'total_epochs=1', 'optimizer.base_lr=0.1']
+        a = mods['train'].parse_args()
+        assert (a.config, a.work_dir, a.resume_from, a.seed, a.launcher) == ('cfg.py', 'w', 'a.pth', 3, 'none')
+        assert a.cfg_options == ['total_epochs=1', 'optimizer.base_lr=0.1']
+        sys.argv = ['test.py', 'cfg.py', 'ckpt.pth', '--eval', 'recall_for_video_text_retrieval', '--gpu-collect',
+                    '--out', 'o.json']
+        t = mods['test'].parse_args()
+        assert (t.config, t.checkpoint, t.eval, t.out) == ('cfg.py', 'ckpt.pth', ['recall_for_video_text_retrieval'], 'o.json')
+    finally:
+        sys.argv = argv
+    seen = []
+    for rank in range(3):
+        ld = mods['test'].SyntheticTestLoader(pairs=10, batch=2, frames=2, tokens=8, rank=rank, world=3, device='cpu')
+        for b in ld:
+            assert b['imgs'].shape[0] == b['index'].numel() == b['token_ids'].shape[0]
+            seen += b['index'].tolist()
+    assert sorted(seen) == list(range(10))
