@@ -293,3 +293,28 @@ def test_long_clip_losses_match_oracle(frames):
     print(f'{frames}-frame loss errors', errs)
     for k in LOSS_KEYS:
         assert errs[k] <= LOSS_TOL[k], (k, lv[k], lv_ref[k])
+
+
+@pytest.mark.parametrize('size', [96, 80, 104])
+def test_swin_padded_sizes(model, size):
+    """Inputs whose token grids are not multiples of the window (24, 20, 26 tokens a side: window padding,
+    swin_transformer_3d.py:452-457,478-479) and, for 104, odd at the merge (13 tokens: PatchMerging's zero pad
+    :531-533): forward and two gradients against the oracle."""
+    from oracle import model as om
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in cf.cf_state(gutil.manifest()).items()}
+    ocfg = cf.oracle_cfg_from(cf.tiny_model_cfg())
+    x = cf.cf_float(f'pad.{size}', (2, 3, 4, size, size), 1.7)
+    ref = om.swin_forward(P, 'backbone.', x, ocfg['backbone'])
+    w = cf.cf_float(f'pad.w.{size}', tuple(ref.shape), 1.0)
+    (ref * w).sum().backward()
+    model.zero_grad(set_to_none=True)
+    y = model.backbone(x.to(DEV))
+    assert y.shape == ref.shape
+    assert rel(y, ref.detach().numpy()) < 3e-2, rel(y, ref.detach().numpy())
+    (y.float() * w.to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    for k in ['backbone.layers.0.blocks.1.attn.relative_position_bias_table', 'backbone.layers.0.downsample.reduction.weight',
+              'backbone.patch_embed.proj.weight']:
+        e = rel(named[k].grad, P[k].grad.numpy())
+        assert e < 4e-2, (k, e)
+    model.zero_grad(set_to_none=True)
