@@ -145,7 +145,7 @@ __device__ __forceinline__ float exp_sub(float x, float negL2) { return __builti
 
 // ------------------------------------------------------------------------- forward
 template <int HD, int NKT, bool DROP, int MODE>
-__global__ void __launch_bounds__(THREADS, 3) attn_fwd_kernel(
+__global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const float* __restrict__ bias,
     const int* __restrict__ rid, const float* __restrict__ kmask, const unsigned long long* __restrict__ seedp,

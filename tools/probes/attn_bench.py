@@ -9,6 +9,8 @@ from clover_amd.backbones.swin_transformer_3d import window_geometry
 B, D, H, W, C, nH = 16, 4, 56, 56, 96, 3
 if len(sys.argv) > 1 and sys.argv[1] == 's2':
     B, D, H, W, C, nH = 16, 4, 14, 14, 384, 12
+if len(sys.argv) > 1 and sys.argv[1] == 'd8':            # 16-frame clips: windows of 8 x 7 x 7 = 392 tokens (Swin-B stage 0)
+    B, D, H, W, C, nH = 16, 8, 56, 56, 128, 4
 torch.manual_seed(0)
 qkv = torch.randn(B, D, H, W, 3 * C, device='cuda').to(torch.bfloat16).requires_grad_()
 table = (torch.randn(15 * 13 * 13, nH, device='cuda') * 0.5).requires_grad_()
