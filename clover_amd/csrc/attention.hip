@@ -20,6 +20,9 @@ namespace {
 
 constexpr int WAVES = 4;
 constexpr int THREADS = WAVES * 64;
+// long windows (NKT > 16: 72 KB of K / V per workgroup, two workgroups per CU): 8 waves share the staged operands,
+// so that a CU still holds 16 waves for the per-tile latency chains
+constexpr int DKV_THREADS(int nkt) { return nkt > 16 ? 512 : THREADS; }
 
 struct Geom {
     ClvAttnGeom g;
@@ -106,9 +109,10 @@ __device__ __forceinline__ void lds_frags(Frag8 (&f)[(HD + 31) / 32], const bf16
 // LDS rm[NK][HD+8]; pad rows are zeroed.  Transposed operands are NOT materialised: they are read
 // with the gfx950 LDS transpose read (tr4 below).
 template <int HD, int NK>
-__device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int ld, int h, int N, bf16_t* rm, int tid) {
+__device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int ld, int h, int N, bf16_t* rm, int tid,
+                                      int nthr = THREADS) {
     constexpr int CH = HD / 8, LDR = HD + 8;
-    for (int idx = tid; idx < NK * CH; idx += THREADS) {
+    for (int idx = tid; idx < NK * CH; idx += nthr) {
         const int n = idx / CH, c = idx - n * CH;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (n < N) val = *reinterpret_cast<const uint4*>(base + (int64_t)row_s[n] * ld + h * HD + c * 8);
@@ -119,8 +123,8 @@ __device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int 
 // The token -> tensor-row map of this window (roll / partition folded in, ~60 integer VALU ops with five
 // divisions) is evaluated ONCE per workgroup into LDS; staging and the per-tile operand loads index it.
 template <int NK>
-__device__ __forceinline__ void token_rows(const Geom& G, int grp, int* row_s, int tid) {
-    for (int n = tid; n < NK; n += THREADS) row_s[n] = (n < G.g.N) ? (int)tok_row(G, grp, n) : 0;
+__device__ __forceinline__ void token_rows(const Geom& G, int grp, int* row_s, int tid, int nthr = THREADS) {
+    for (int n = tid; n < NK; n += nthr) row_s[n] = (n < G.g.N) ? (int)tok_row(G, grp, n) : 0;
     __syncthreads();
 }
 
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
 
 // ------------------------------------------------------------------------- backward B: dK, dV
 template <int HD, int NKT, bool DROP, int MODE>
-__global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
+__global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum,
     const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     float* D_s = L_s + NK;
     float* aux = D_s + NK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
@@ -437,13 +441,13 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     int* linb_s = row_s + NK;
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);
     const bool tb = MODE == 1 && bias != nullptr;
-    token_rows<NK>(G, grp, row_s, tid);
-    stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid);
-    stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid);
-    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
+    token_rows<NK>(G, grp, row_s, tid, nthr);
+    stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid, nthr);
+    stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid, nthr);
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
-    for (int n = tid; n < NK; n += THREADS) {
+    for (int n = tid; n < NK; n += nthr) {
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
         L_s[n] = (n < N) ? -lse[li] * LOG2E : -INFINITY;    // -L * log2e (exp_sub's form); pad queries: P = exp2(-inf) = 0
         D_s[n] = (n < N) ? dsum[li] : 0.f;
@@ -455,7 +459,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dkv_kernel(
     const int nkt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int kt = wave + WAVES * part; kt < nkt; kt += WAVES * G.tsplit) {
+    for (int kt = wave + nwaves * part; kt < nkt; kt += nwaves * G.tsplit) {
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
         const int64_t krow = row_s[kv ? nk : 0];
@@ -756,7 +760,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         if (rc) return rc;
     }
     if (stages & 4) {
-        CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(THREADS), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
+        CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(DKV_THREADS(NKT)), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
                  (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
         rc = clv_check_launch();
     }
