@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
 // Window mode also writes dS (bf16) of every (window, head) to a scratch; dbias_table_kernel sums it over the
 // windows and scatters the sums into the table gradient.
 template <int HD, int NKT, bool DROP, int MODE>
-__global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
+__global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
@@ -304,19 +304,19 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     int* linb_s = row_s + NK;
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
     const bool tb = MODE == 1 && bias != nullptr;
 
-    token_rows<NK>(G, grp, row_s, tid);
-    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
-    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
-    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
+    token_rows<NK>(G, grp, row_s, tid, nthr);
+    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid, nthr);
+    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid, nthr);
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
-    for (int n = tid; n < NK; n += THREADS) {
+    for (int n = tid; n < NK; n += nthr) {
         if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
         kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
     }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(THREADS) attn_bwd_dq_kernel(
     const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int qt = wave + WAVES * part; qt < nqt; qt += WAVES * G.tsplit) {
+    for (int qt = wave + nwaves * part; qt < nqt; qt += nwaves * G.tsplit) {
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
         const int64_t qrow = row_s[qv ? nq : 0];
@@ -737,7 +737,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const int nblk = G.g.groups * G.g.nH * G.tsplit;
     int rc = CLV_OK;
     if (stages & 1) {
-        CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(THREADS), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
+        CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(DKV_THREADS(NKT)), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
                  (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq,
                  (bf16_t*)(bias ? work : nullptr), dsum, seed, G));
         rc = clv_check_launch();
