@@ -20,9 +20,10 @@ namespace {
 
 constexpr int WAVES = 4;
 constexpr int THREADS = WAVES * 64;
-// long windows (NKT > 16: 72 KB of K / V per workgroup, two workgroups per CU): 8 waves share the staged operands,
-// so that a CU still holds 16 waves for the per-tile latency chains
-constexpr int DKV_THREADS(int nkt) { return nkt > 16 ? 512 : THREADS; }
+// The backward kernels run 8 waves per workgroup from 14 key tiles up: twice as many waves share the staged K / V
+// (Q / dO), which is what limits the workgroups per CU (392-token windows: 72 KB -> two workgroups, -40 % per
+// kernel; 196-token windows: 50 KB -> three, -7 % / -13 %)
+constexpr int DKV_THREADS(int nkt) { return nkt >= 14 ? 512 : THREADS; }
 
 struct Geom {
     ClvAttnGeom g;
