@@ -169,8 +169,8 @@ def cpu_baseline_subprocess(variant, frames, L, timeout_s=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=8, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--tokens', type=int, default=32)
