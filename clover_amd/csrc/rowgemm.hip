@@ -25,7 +25,10 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_BWD = 2 };
 template <int KS>
 struct RGCfg {
     static constexpr int K = KS * 32;
-    static constexpr int TN = (KS <= 12) ? 128 : 64;       // columns per workgroup
+    // columns per workgroup.  K <= 128 (stage-0 widths: LN + QKV, fc1 + GELU, fc2-dgrad + GELU'): 64, so that weight
+    // tile + per-wave staging stay near 30 KB and 4-5 workgroups share a CU (+1.0 % on the step against 128, where
+    // 61 KB allowed two); K = 192..384: 128 (64 measured equal); wider K: 64 (LDS)
+    static constexpr int TN = (KS <= 12 && KS > 4) ? 128 : 64;
     static constexpr int LDW = K + 8;                       // padded LDS row of the weight tile
     static constexpr int LDO = TN + 8;
 };
