@@ -15,7 +15,8 @@ class BertFromPretrained(nn.Module):
                                   num_hidden_layers=num_hidden_layers)
         self.bert = BertModel(cfg)
         init_bert_weights(self.bert)
-        load_pretrained_dir(self.bert, pretrained_model, prefix='bert.')
+        load_pretrained_dir(self.bert, pretrained_model, prefix='bert.', allow_missing=('pooler.',),   # unused here
+                            allow_unexpected=tuple(f'layer.{i}.' for i in range(cfg['num_hidden_layers'], 64)))
 
     def forward(self, token_ids=None, input_mask=None, **kwargs):
         """-> mapping with 'last_hidden_state' [B,L,H] (reference :26-32)."""

@@ -46,8 +46,25 @@ def resolve_bert_config(pretrained_model='bert-base-uncased', bert_config=None, 
     return cfg
 
 
-def load_pretrained_dir(module, pretrained_model, prefix=''):
-    """Load ``<dir>/model.safetensors`` / ``pytorch_model.bin`` if present (non-strict)."""
+def hf_legacy_key(k):
+    """Key renames ``from_pretrained`` applies while loading (transformers 4.6.1 ``modeling_utils.py``
+    ``_load_state_dict_into_model``): the stock bert-base-uncased weights still carry the TF names
+    ``LayerNorm.gamma`` / ``LayerNorm.beta``."""
+    if 'gamma' in k:
+        k = k.replace('gamma', 'weight')
+    if 'beta' in k:
+        k = k.replace('beta', 'bias')
+    return k
+
+
+def load_pretrained_dir(module, pretrained_model, prefix='', allow_unexpected=(), allow_missing=()):
+    """Load ``<dir>/model.safetensors`` / ``pytorch_model.bin`` into ``module`` the way the reference's
+    ``from_pretrained`` calls do (bert_from_hugface.py:13-15, cross_transformer.py:24-29, mlm_itm_head.py:33-35):
+    legacy ``gamma`` / ``beta`` names are mapped to ``weight`` / ``bias``, the MLM head's output bias is stored as
+    ``cls.predictions.bias`` (HF ties ``decoder.bias`` to it) and its ``decoder.weight`` is tied to the word
+    embeddings when the file does not carry it.  Returns False when the directory holds no weight file.
+    Raises if a parameter of ``module`` is left un-initialised (except names matching ``allow_missing``) — a silent
+    partial load would start pre-training from a half-random text encoder."""
     d = str(pretrained_model)
     sd = None
     if os.path.isfile(os.path.join(d, 'model.safetensors')):
@@ -57,9 +74,33 @@ def load_pretrained_dir(module, pretrained_model, prefix=''):
         sd = torch.load(os.path.join(d, 'pytorch_model.bin'), map_location='cpu')
     if sd is None:
         return False
-    if prefix:
-        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-    module.load_state_dict(sd, strict=False)
+    full = {hf_legacy_key(k): v for k, v in sd.items()}
+    if prefix.startswith('bert.') and not any(k.startswith('bert.') for k in full):
+        prefix = prefix[len('bert.'):]               # a bare BertModel checkpoint (HF strips / adds base_model_prefix)
+    sd = {k[len(prefix):]: v for k, v in full.items() if k.startswith(prefix)} if prefix else dict(full)
+    if not sd:
+        import warnings
+        warnings.warn(f'{d}: no weights under {prefix!r}; {type(module).__name__} keeps its fresh initialisation '
+                      '(what from_pretrained does, with the same warning)')
+        return False
+    if prefix == 'cls.predictions.':
+        if 'bias' in sd:
+            sd.setdefault('decoder.bias', sd['bias'])
+            del sd['bias']
+        for tied in ('bert.embeddings.word_embeddings.weight', 'embeddings.word_embeddings.weight'):
+            if 'decoder.weight' not in sd and tied in full:
+                sd['decoder.weight'] = full[tied]
+    res = module.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if not any(a in k for a in allow_missing)]
+    unexpected = [k for k in res.unexpected_keys
+                  if not any(a in k for a in tuple(allow_unexpected) + ('position_ids',))]
+    if missing:
+        raise RuntimeError(f'{d}: {len(missing)} parameter(s) of {type(module).__name__} not found in the '
+                           f'checkpoint (prefix {prefix!r}): {missing[:8]}')
+    if unexpected:
+        import warnings
+        warnings.warn(f'{d}: {len(unexpected)} checkpoint key(s) under {prefix!r} have no counterpart in '
+                      f'{type(module).__name__}: {unexpected[:8]}')
     return True
 
 

@@ -25,7 +25,9 @@ class CrossModalTransformerFromPretrained(nn.Module):
         init_bert_weights(self.bert_embedding)
         init_bert_weights(self.bert_encoder)
         load_pretrained_dir(self.bert_embedding, pretrained_model, prefix='bert.embeddings.')
-        load_pretrained_dir(self.bert_encoder, pretrained_model, prefix='bert.encoder.')
+        # the fusion encoder takes the first num_hidden_layers layers of the checkpoint (cross_transformer.py:24-29)
+        load_pretrained_dir(self.bert_encoder, pretrained_model, prefix='bert.encoder.',
+                            allow_unexpected=tuple(f'layer.{i}.' for i in range(cfg['num_hidden_layers'], 64)))
         self.use_prompt = use_prompt
         if not use_text_cls:
             self.all_cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))

@@ -82,6 +82,82 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// Device-resident optimizer state (clv_optim_prep writes it, clv_adamw_step_dev reads it): the clip coefficient, Adam's
+// bias corrections and Adam's OWN step count t, which advances only on steps that are taken — the reference skips
+// optimizer.step() on a non-finite gradient (mmcv_Fp16OptimizerHook.py:123-141), so its Adam state['step'] does not
+// move there either — all without a host round trip.
+struct OptimState {
+    float coef;        // grad_scale * min(1, max_norm / (norm + 1e-6))
+    float bc1;         // 1 - beta1^t
+    float bc2_sqrt;    // sqrt(1 - beta2^t)
+    float norm;        // global gradient norm of this step (after grad_scale), for logging
+    int skip;          // 1: non-finite norm, leave parameters and moments alone
+    int t;             // Adam steps taken so far
+    int skipped;       // steps skipped so far
+    int pad;
+};
+
+__global__ void optim_prep_kernel(float* __restrict__ acc, OptimState* __restrict__ st, float beta1, float beta2,
+                                  float max_norm, float grad_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float ss = acc[0] * grad_scale * grad_scale;
+    acc[0] = 0.f;                                              // ready for the next step's clv_sumsq calls
+    OptimState o = *st;
+    if (!(ss == ss) || ss > 3.0e38f) {
+        o.skip = 1;
+        o.skipped += 1;
+        o.norm = ss;
+    } else {
+        o.skip = 0;
+        o.t += 1;
+        o.norm = sqrtf(ss);
+        float c = grad_scale;
+        if (max_norm > 0.f) c *= fminf(max_norm / (o.norm + 1e-6f), 1.0f);      // clip_grad_norm_
+        o.coef = c;
+        o.bc1 = (float)(1.0 - pow((double)beta1, (double)o.t));
+        o.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)o.t));
+    }
+    *st = o;
+}
+
+__global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        bf16_t* __restrict__ shadow, const OptimState* __restrict__ st,
+                                                        int64_t n, AdamArgs a) {
+    if (st->skip) return;
+    const float coef = st->coef;
+    a.bc1 = st->bc1;
+    a.bc2_sqrt = st->bc2_sqrt;
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pv.x, gv.x, mv.x, vv.x, a, coef);
+        adam_one(pv.y, gv.y, mv.y, vv.y, a, coef);
+        adam_one(pv.z, gv.z, mv.z, vv.z, a, coef);
+        adam_one(pv.w, gv.w, mv.w, vv.w, a, coef);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (shadow) {
+            uint2 o;
+            o.x = pack2bf(pv.x, pv.y);
+            o.y = pack2bf(pv.z, pv.w);
+            reinterpret_cast<uint2*>(shadow)[i] = o;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float pv = p[i], mv = m[i], vv = v[i];
+        adam_one(pv, g[i], mv, vv, a, coef);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+        if (shadow) shadow[i] = f2bf(pv);
+    }
+}
+
 int grid_for(int64_t n4) {
     int64_t b = (n4 + 255) / 256;
     if (b > 2048) b = 2048;
@@ -111,5 +187,27 @@ extern "C" int clv_adamw_step(float* p, const float* g, float* m, float* v, void
     AdamArgs a{lr, beta1, beta2, eps, weight_decay, bias_c1, sqrtf(bias_c2), max_norm, grad_scale};
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (bf16_t*)shadow, sumsq, n, a);
+    return clv_check_launch();
+}
+
+extern "C" int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float max_norm, float grad_scale,
+                              void* stream) {
+    if (!sumsq || !state || (((uintptr_t)state) & 3)) return CLV_ERR_ARG;
+    static_assert(sizeof(OptimState) == CLV_OPTIM_STATE_BYTES, "OptimState layout is part of the ABI");
+    hipLaunchKernelGGL(optim_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, (OptimState*)state, beta1,
+                       beta2, max_norm, grad_scale);
+    return clv_check_launch();
+}
+
+extern "C" int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow, const void* state,
+                                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  void* stream) {
+    if (!p || !g || !m || !v || !state || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CLV_ERR_ARG;
+    if (shadow && (((uintptr_t)shadow) & 7)) return CLV_ERR_ARG;
+    AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, 0.f, 1.f};
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (bf16_t*)shadow, (const OptimState*)state, n, a);
     return clv_check_launch();
 }

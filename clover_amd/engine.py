@@ -54,6 +54,38 @@ def paramwise_weight_decay(model, base_wd, norm_decay_mult=0.0, bias_decay_mult=
     return out
 
 
+def paramwise_options(model, base_wd, paramwise_cfg=None):
+    """mmcv 1.3.x DefaultOptimizerConstructor.add_params, per parameter:
+    {name: (weight_decay, lr_mult)}.  A ``custom_keys`` hit (substring, longest key first) decides both
+    ``lr_mult`` and ``decay_mult`` and switches the other rules off; otherwise ``bias_lr_mult`` applies to every
+    ``bias`` outside norm layers, and the decay is ``norm_decay_mult`` for norm layers, else ``bias_decay_mult`` for
+    a ``bias``, else 1."""
+    cfg = paramwise_cfg or {}
+    custom_keys = cfg.get('custom_keys') or {}
+    sorted_keys = sorted(sorted(custom_keys.keys()), key=len, reverse=True)
+    norm_types = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.GroupNorm, nn.LayerNorm)
+    out = {}
+    for mod_name, mod in model.named_modules():
+        is_norm = isinstance(mod, norm_types)
+        for pname, p in mod.named_parameters(recurse=False):
+            full = f'{mod_name}.{pname}' if mod_name else pname
+            wd, lr_mult = base_wd, 1.0
+            for key in sorted_keys:
+                if key in full:
+                    lr_mult = custom_keys[key].get('lr_mult', 1.0)
+                    wd = base_wd * custom_keys[key].get('decay_mult', 1.0)
+                    break
+            else:
+                if pname == 'bias' and not is_norm:
+                    lr_mult = cfg.get('bias_lr_mult', 1.0)
+                if is_norm:
+                    wd = base_wd * cfg.get('norm_decay_mult', 1.0)
+                elif pname == 'bias':
+                    wd = base_wd * cfg.get('bias_decay_mult', 1.0)
+            out[full] = (float(wd), float(lr_mult))
+    return out
+
+
 def cosine_lr(base_lr, it, max_iters, min_lr_ratio=1e-3, warmup_iters=0, warmup_ratio=1e-3):
     """mmcv CosineAnnealing (by_epoch=False) with linear warm-up."""
     end = base_lr * min_lr_ratio
@@ -65,10 +97,12 @@ def cosine_lr(base_lr, it, max_iters, min_lr_ratio=1e-3, warmup_iters=0, warmup_
 
 
 class _Segment:
-    """A flat fp32 slab: params / grads / exp_avg / exp_avg_sq of one weight-decay class."""
+    """A flat fp32 slab: params / grads / exp_avg / exp_avg_sq of one (weight_decay, lr_mult) class — what mmcv
+    expresses as one param group per parameter collapses to one slab per DISTINCT option pair."""
 
-    def __init__(self, named_params, weight_decay, device):
+    def __init__(self, named_params, weight_decay, device, lr_mult=1.0):
         self.weight_decay = weight_decay
+        self.lr_mult = lr_mult
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]          # 16-byte aligned slots
@@ -118,7 +152,9 @@ class CloverEngine:
         self.grad_clip = grad_clip
         self.max_iters, self.warmup_iters = max_iters, warmup_iters
         self.min_lr_ratio, self.warmup_ratio = min_lr_ratio, warmup_ratio
-        self.step_count = 0
+        self.step_count = 0                    # optimizer_step() calls (taken or skipped)
+        self.lr_iter = 0                       # index into the LR schedule when no runner drives it (set_lr)
+        self._lr_external = None
         self.graph = None
         self.graph_bwd_video = None
         self.graph_bwd_text = None
@@ -128,8 +164,7 @@ class CloverEngine:
         pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                    custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
                                                 'relative_position_bias_table': dict(decay_mult=0.)})
-        wd_map = paramwise_weight_decay(model, weight_decay, pw.get('norm_decay_mult', 1.0),
-                                        pw.get('bias_decay_mult', 1.0), pw.get('custom_keys'))
+        opt_map = paramwise_options(model, weight_decay, pw)       # name -> (weight_decay, lr_mult)
 
         # ---- dry run: which parameters does the step graph actually reach?
         model.zero_grad(set_to_none=True)
@@ -147,7 +182,7 @@ class CloverEngine:
         used_ids = {id(p) for _, p in used}
         for mod in model.modules():
             for grp in (mod.clv_fuse_groups() if hasattr(mod, 'clv_fuse_groups') else []):
-                if all(id(q) in used_ids for q in grp) and len({wd_map[name_of[id(q)]] > 0 for q in grp}) == 1:
+                if all(id(q) in used_ids for q in grp) and len({opt_map[name_of[id(q)]] for q in grp}) == 1:
                     groups.append((mod, grp))
         member = {id(q): gi for gi, (_, grp) in enumerate(groups) for q in grp}
         ordered, placed = [], set()
@@ -159,11 +194,15 @@ class CloverEngine:
                 placed.add(gi)
                 ordered.extend((name_of[id(q)], q) for q in groups[gi][1])
         used = ordered
-        decay = [(n, p) for n, p in used if wd_map[n] > 0]
-        no_decay = [(n, p) for n, p in used if wd_map[n] == 0]
-        self.segments = [s for s in (_Segment(decay, weight_decay, device) if decay else None,
-                                     _Segment(no_decay, 0.0, device) if no_decay else None) if s is not None]
+        # one slab per distinct (weight_decay, lr_mult): the reference config has two (decayed weights; norm / bias /
+        # position-table parameters without decay), any other decay_mult / lr_mult of a paramwise_cfg adds its own
+        classes = {}
+        for n, p_ in used:
+            classes.setdefault(opt_map[n], []).append((n, p_))
+        self.segments = [_Segment(members, wd, device, lr_mult=lm)
+                         for (wd, lm), members in sorted(classes.items(), key=lambda kv: (-kv[0][0], kv[0][1]))]
         self.sumsq = torch.zeros(1, device=device, dtype=torch.float32)
+        self.optim_state = ops.optim_state_new(device) if device.type == 'cuda' else None
         self.num_params = sum(p.numel() for _, p in used)
 
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
@@ -191,8 +230,29 @@ class CloverEngine:
 
     # ------------------------------------------------------------------ one step
     def current_lr(self):
-        return cosine_lr(self.base_lr, self.step_count, self.max_iters, self.min_lr_ratio, self.warmup_iters,
+        """LR of the NEXT optimizer step.  Under a runner the schedule is indexed by the runner's ``iter`` — batch
+        indices, which the two-loader mode advances once per TWO optimizer steps (clover_runner.py:76-91) — and set
+        through ``set_lr`` by ``runner.LrUpdaterHook`` as mmcv's LR hook does in ``before_train_iter``.  Stand-alone
+        (bench.py) the engine indexes the same schedule by its own count of steps, starting at 0 like mmcv's iter."""
+        if self._lr_external is not None:
+            return self._lr_external
+        return cosine_lr(self.base_lr, self.lr_iter, self.max_iters, self.min_lr_ratio, self.warmup_iters,
                          self.warmup_ratio)
+
+    def set_lr(self, lr):
+        """Externally scheduled learning rate, used by every following step until changed (None: own schedule)."""
+        self._lr_external = None if lr is None else float(lr)
+
+    def dry_step(self, batch):
+        """forward + backward + gradient exchange WITHOUT the optimizer: warms the kernels, the GEMM tuner and the
+        gradient reducer's hook calibration and leaves weights, Adam moments, step counts and the LR index untouched
+        (gradients are zeroed again)."""
+        out = self.model.train_step(batch, None)
+        out['loss'].backward()
+        self.reducer.finish()
+        for seg in self.segments:
+            seg.flat_g.zero_()
+        return out
 
     def step(self, batch):
         """forward + backward + gradient all-reduce + clip + AdamW.  Returns train_step's dict."""
@@ -368,28 +428,41 @@ class CloverEngine:
         return True
 
     def optimizer_step(self):
-        self.step_count += 1
+        """Global-norm clip + AdamW on the slabs; no host synchronisation.  The clip coefficient, Adam's bias
+        corrections and Adam's own step count live on the device (``clv_optim_prep``): a step with a non-finite
+        gradient norm is skipped there and does not advance Adam's count (mmcv_Fp16OptimizerHook.py:123-141), while
+        the LR index moves on like the reference's ``runner.iter``."""
         lr = self.current_lr()
+        self.lr_iter += 1
+        self.step_count += 1
         gscale = 1.0 / self.world                       # DDP averages the summed gradients
-        self.sumsq.zero_()
         for seg in self.segments:
             ops.sumsq_accumulate(seg.flat_g, self.sumsq)
+        ops.optim_prep(self.sumsq, self.optim_state, self.betas[0], self.betas[1],
+                       self.grad_clip if self.grad_clip else 0.0, gscale)
         for seg in self.segments:
-            ops.adamw_step(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, seg.shadow, self.sumsq, lr,
-                           self.betas[0], self.betas[1], self.eps, seg.weight_decay, self.step_count,
-                           self.grad_clip if self.grad_clip else 0.0, gscale)
+            ops.adamw_step_dev(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, seg.shadow, self.optim_state,
+                               lr * seg.lr_mult, self.betas[0], self.betas[1], self.eps, seg.weight_decay)
         for seg in self.segments:
             seg.flat_g.zero_()
+        self.last_lr = lr
 
     def optimizer_state(self):
         """AdamW state for checkpoints: per segment the flat moments + names/offsets, and the step count."""
-        return dict(step=self.step_count,
+        st = ops.optim_state_read(self.optim_state)
+        return dict(step=st['t'], skipped=st['skipped'], calls=self.step_count, lr_iter=self.lr_iter,
                     segments=[dict(names=list(sg.names), offsets=list(sg.offsets), weight_decay=sg.weight_decay,
+                                   lr_mult=sg.lr_mult,
                                    exp_avg=sg.exp_avg.detach().cpu(), exp_avg_sq=sg.exp_avg_sq.detach().cpu())
                               for sg in self.segments])
 
     def load_optimizer_state(self, state):
-        self.step_count = int(state['step'])
+        self.step_count = int(state.get('calls', state['step']))
+        self.lr_iter = int(state.get('lr_iter', state['step']))
+        self.optim_state.zero_()
+        self.optim_state[5] = int(state['step'])                 # Adam's t (ops.optim_state_read layout)
+        self.optim_state[6] = int(state.get('skipped', 0))
+        assert len(self.segments) == len(state['segments']), 'optimizer state belongs to a different parameter layout'
         for sg, st in zip(self.segments, state['segments']):
             assert list(sg.names) == list(st['names']), 'optimizer state belongs to a different parameter layout'
             sg.exp_avg.copy_(st['exp_avg'])
@@ -404,4 +477,8 @@ class CloverEngine:
 
     def grad_norm(self):
         """Global gradient norm of the last step's (averaged) gradients — host sync, logging only."""
-        return float(self.sumsq.sqrt().item()) / self.world
+        return ops.optim_state_read(self.optim_state)['norm']
+
+    def adam_steps(self):
+        """Adam's own step count = optimizer steps actually taken (host sync)."""
+        return ops.optim_state_read(self.optim_state)['t']

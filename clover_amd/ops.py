@@ -1196,3 +1196,32 @@ def adamw_step(p, g, m, v, shadow, sumsq, lr, beta1, beta2, eps, weight_decay, s
                                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                     float(bc1), float(bc2), float(max_norm), float(grad_scale), _stream()),
           'clv_adamw_step')
+
+
+OPTIM_STATE_BYTES = 32
+
+
+def optim_state_new(device):
+    """Device-resident optimizer scalars (include/clover_hip.h: CLV_OPTIM_STATE_BYTES), zero-initialised."""
+    return torch.zeros(OPTIM_STATE_BYTES // 4, device=device, dtype=torch.int32)
+
+
+def optim_state_read(state):
+    """Host copy (syncs): dict(coef, bc1, bc2_sqrt, norm, skip, t, skipped)."""
+    raw = state.detach().cpu()
+    f = raw.view(torch.float32)
+    return dict(coef=float(f[0]), bc1=float(f[1]), bc2_sqrt=float(f[2]), norm=float(f[3]), skip=int(raw[4]),
+                t=int(raw[5]), skipped=int(raw[6]))
+
+
+def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0):
+    _need_gpu(sumsq, state)
+    check(_lib.lib().clv_optim_prep(_ptr(sumsq), _ptr(state), float(beta1), float(beta2), float(max_norm),
+                                    float(grad_scale), _stream()), 'clv_optim_prep')
+
+
+def adamw_step_dev(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay):
+    _need_gpu(p, g, m, v, state)
+    check(_lib.lib().clv_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(state), p.numel(),
+                                        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                        _stream()), 'clv_adamw_step_dev')

@@ -132,6 +132,41 @@ class Hook:
     def after_train_iter(self, runner): pass
 
 
+class LrUpdaterHook(Hook):
+    """mmcv 1.3.x ``CosineAnnealingLrUpdaterHook`` with ``by_epoch=False`` and linear warm-up (the reference's
+    ``lr_config``, pretrain_webvid_cc3m.py:139-140).  The schedule is indexed by ``runner.iter`` —
+    which the multi-loader runner advances once per batch INDEX, so both loaders' steps of one index share one LR
+    (clover_runner.py:76-91) — against ``runner._max_iters`` (epochs x the LONGEST loader), and ``warmup_iters`` given
+    in epochs is multiplied by that loader's length in ``before_train_epoch`` as mmcv does.  ``before_train_iter``
+    hands the value to the stepper (``set_lr``), i.e. before the step that uses it, starting at iter 0."""
+
+    def __init__(self, base_lr, min_lr_ratio=None, min_lr=None, warmup=None, warmup_iters=0, warmup_ratio=0.1,
+                 warmup_by_epoch=False, **_ignored):
+        assert (min_lr is None) ^ (min_lr_ratio is None), 'exactly one of min_lr / min_lr_ratio'
+        assert warmup in (None, 'linear'), 'only linear warm-up is restated'
+        self.base_lr = base_lr
+        self.min_lr_ratio = min_lr_ratio if min_lr_ratio is not None else min_lr / base_lr
+        self.warmup, self.warmup_ratio = warmup, warmup_ratio
+        self.warmup_epochs = warmup_iters if warmup_by_epoch else None
+        self.warmup_iters = None if warmup_by_epoch else warmup_iters
+        self.history = []
+
+    def before_train_epoch(self, runner):
+        if self.warmup_iters is None:
+            self.warmup_iters = self.warmup_epochs * runner.epoch_len
+
+    def lr_at(self, it, max_iters):
+        from .engine import cosine_lr
+        return cosine_lr(self.base_lr, it, max_iters, self.min_lr_ratio,
+                         self.warmup_iters if self.warmup else 0, self.warmup_ratio)
+
+    def before_train_iter(self, runner):
+        lr = self.lr_at(runner.iter, runner._max_iters)
+        self.history.append(lr)
+        if hasattr(runner.stepper, 'set_lr'):
+            runner.stepper.set_lr(lr)
+
+
 class LogHook(Hook):
     """TextLoggerHook stand-in: keeps the last ``log_vars`` (same keys the reference logs) every `interval` iters."""
 
@@ -167,6 +202,7 @@ class CloverRunner:
         self._max_epochs, self._max_iters = max_epochs, None
         self.epoch, self.iter, self.inner_iter = 0, 0, 0
         self.hooks, self.outputs, self.mode = [], None, None
+        self.epoch_len = None                 # len(runner.data_loader): the longest loader in multi-loader mode
 
     def register_hook(self, hook):
         self.hooks.append(hook)
@@ -185,6 +221,7 @@ class CloverRunner:
 
     # ---- clover_runner.py:17-35 (single loader)
     def _train_single(self, loader):
+        self.epoch_len = len(loader)
         self._max_iters = self._max_epochs * len(loader)
         self.call_hook('before_train_epoch')
         for i, data_batch in enumerate(loader):
@@ -200,7 +237,8 @@ class CloverRunner:
 
     # ---- clover_runner.py:60-96 (several loaders; one optimizer step per loader per batch index)
     def _train_multi(self, loaders):
-        self._max_iters = self._max_epochs * max(len(ld) for ld in loaders)
+        self.epoch_len = max(len(ld) for ld in loaders)                # :62-69 — data_loader = the longest one
+        self._max_iters = self._max_epochs * self.epoch_len
         self.call_hook('before_train_epoch')
         short_loader = None
         for batch_idx, batches in enumerate(zip_longest(*loaders)):

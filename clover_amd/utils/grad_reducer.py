@@ -30,6 +30,7 @@ class BucketedGradReducer:
         self.seen = {}
         self.calibrated = False
         self.comm_stream = None
+        self._producers = []        # per bucket: the streams its gradients were produced on (eager mode)
         self.active = collectives_active()
         self._bucket_params = []
         if not self.active:
@@ -61,11 +62,16 @@ class BucketedGradReducer:
         self.pending = [b[3] for b in self.buckets]
         self.handles = []
         self.seen = {}
+        self._producers = [[] for _ in self.buckets]
 
     def _launch(self, b):
         flat, s, e, _ = self.buckets[b]
         if self.comm_stream is not None:
+            # The hook countdown is HOST-ordered: the bucket's other gradients may have been produced on another
+            # stream than the last hook's (the text tower runs on a side stream) — wait for every producer stream.
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in self._producers[b]:
+                self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(flat[s:e], async_op=True))
         else:
@@ -76,6 +82,10 @@ class BucketedGradReducer:
             if not self.enabled:
                 return
             k = id(param)
+            if self.comm_stream is not None:
+                cur = torch.cuda.current_stream()
+                if all(cur != st for st in self._producers[b]):
+                    self._producers[b].append(cur)
             self.seen[k] = self.seen.get(k, 0) + 1
             if not self.calibrated or self.seen[k] != self.expect.get(k, 1):
                 return

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 1
+#define CLV_ABI_VERSION 2
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -274,6 +274,19 @@ int clv_sumsq(const float* g, float* acc, int64_t n, void* stream);
 int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, const float* sumsq,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_c1, float bias_c2, float max_norm, float grad_scale, void* stream);
+
+/* The same step with the optimizer's scalars held on the DEVICE (no host sync, hipGraph-safe):
+ * state = CLV_OPTIM_STATE_BYTES bytes {float coef, bc1, bc2_sqrt, norm; int32 skip, t, skipped, pad}, zeroed once by
+ * the caller.  clv_optim_prep (one thread, after every segment's clv_sumsq): reads and re-zeroes sumsq, computes the
+ * clip coefficient (grad_scale * min(1, max_norm/(norm+1e-6)); max_norm <= 0: no clipping); a finite norm advances
+ * Adam's step count t and refreshes the bias corrections, a non-finite one sets skip — the reference skips
+ * optimizer.step() on overflow (mmcv_Fp16OptimizerHook.py:123-141), so Adam's step count does not advance either.
+ * clv_adamw_step_dev: clv_adamw_step with coefficient / bias corrections / skip read from state. */
+#define CLV_OPTIM_STATE_BYTES 32
+int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float max_norm, float grad_scale,
+                   void* stream);
+int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow, const void* state, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

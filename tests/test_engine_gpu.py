@@ -50,6 +50,71 @@ def test_engine_matches_torch_adamw_and_clip():
     assert worst < 0.1, worst
 
 
+def test_engine_lr_mult_and_fractional_decay_match_torch_param_groups():
+    """any decay_mult / lr_mult of a paramwise_cfg gets its own slab (mmcv makes one param group per
+    parameter); compared with torch.optim.AdamW over the same per-parameter options."""
+    from clover_amd.engine import CloverEngine, paramwise_options
+    b = batch(tag='pw')
+    pw = dict(norm_decay_mult=0.0, bias_decay_mult=0.0, bias_lr_mult=2.0,
+              custom_keys={'backbone.layers': dict(lr_mult=0.25, decay_mult=0.5),
+                           'relative_position_bias_table': dict(decay_mult=0.)})
+    m1, m2 = make_model(), make_model()
+    eng = CloverEngine(m1, b, lr=1e-3, weight_decay=0.01, paramwise_cfg=pw, grad_clip=15.0, max_iters=10 ** 9)
+    assert len(eng.segments) >= 4 and len({(sg.weight_decay, sg.lr_mult) for sg in eng.segments}) == len(eng.segments)
+    o = paramwise_options(m2, 0.01, pw)
+    named = [(n, p) for n, p in m2.named_parameters() if n not in eng.unused_names]
+    opt = torch.optim.AdamW([dict(params=[p], weight_decay=o[n][0], lr=1e-3 * o[n][1]) for n, p in named],
+                            lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    for it in range(3):
+        eng.step(b)
+        opt.zero_grad(set_to_none=True)
+        m2.train_step(b, None)['loss'].backward()
+        torch.nn.utils.clip_grad_norm_([p for _, p in named], 15.0)
+        opt.step()
+    p1 = dict(m1.named_parameters())
+    p0 = dict(make_model().named_parameters())
+    for n, p in named:
+        moved = (p.detach() - p0[n]).abs().max().item()
+        d = (p1[n].detach() - p.detach()).abs().max().item()
+        # Adam moves every weight by ~lr per step: a wrong lr_mult shows as a 2-8x different displacement
+        assert d <= 0.35 * moved + 1e-7, (n, d, moved, o[n])
+
+
+def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():
+    """A non-finite gradient norm skips the update on the device and does not advance Adam's step count (the
+    reference skips optimizer.step(), mmcv_Fp16OptimizerHook.py:123-141) while the LR index moves on; dry_step —
+    the warm-up tools/train.py runs before capturing graphs — changes nothing."""
+    from clover_amd.engine import CloverEngine
+    b = batch(tag='skip')
+    eng = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=100, warmup_iters=10)
+    snap = [(sg.flat_p.clone(), sg.exp_avg.clone(), sg.exp_avg_sq.clone(), sg.shadow.clone()) for sg in eng.segments]
+    eng.dry_step(b)
+    for sg, (p0, m0, v0, s0) in zip(eng.segments, snap):
+        assert torch.equal(sg.flat_p, p0) and torch.equal(sg.exp_avg, m0) and torch.equal(sg.exp_avg_sq, v0)
+        assert torch.equal(sg.shadow, s0) and float(sg.flat_g.abs().max()) == 0.0
+    assert eng.step_count == 0 and eng.lr_iter == 0 and eng.adam_steps() == 0
+    lr0 = eng.current_lr()
+    eng.step(b)
+    assert eng.last_lr == lr0 and eng.adam_steps() == 1                     # the first step uses schedule index 0
+    snap = [(sg.flat_p.clone(), sg.exp_avg.clone()) for sg in eng.segments]
+    eng.model.train_step(b, None)['loss'].backward()
+    eng.segments[0].flat_g[7] = float('nan')
+    eng.reducer.finish()
+    eng.optimizer_step()
+    for sg, (p0, m0) in zip(eng.segments, snap):
+        assert torch.equal(sg.flat_p, p0) and torch.equal(sg.exp_avg, m0)
+        assert float(sg.flat_g.abs().nan_to_num(0).max()) == 0.0            # gradients are cleared all the same
+    st = eng.optimizer_state()
+    assert st['step'] == 1 and st['skipped'] == 1 and st['calls'] == 2 and eng.lr_iter == 2
+    eng.step(b)
+    assert eng.adam_steps() == 2
+    # bias corrections after the skipped step are those of t = 2
+    from clover_amd import ops
+    s = ops.optim_state_read(eng.optim_state)
+    assert abs(s['bc1'] - (1 - 0.9 ** 2)) < 1e-6 and abs(s['bc2_sqrt'] - (1 - 0.98 ** 2) ** 0.5) < 1e-6
+    assert s['norm'] > 0 and s['coef'] <= 1.0
+
+
 def test_engine_gradient_slab_equals_plain_autograd():
     """The engine's plumbing — gradient sinks into the flat fp32 slab, bf16 shadow weights, fused Q|K|V slab
     views (clv_fuse_groups) — must leave exactly the gradients plain autograd computes on an identical model."""
@@ -279,7 +344,7 @@ def test_checkpoint_roundtrip_through_engine(tmp_path):
     e3 = CloverEngine(make_model(), b, **kw)
     r3 = CloverRunner(e3, work_dir=str(tmp_path))
     r3.resume(str(tmp_path / 'a.pth'))
-    assert e3.step_count == 3
+    assert e3.step_count == 3 and e3.adam_steps() == 3 and e3.lr_iter == 3
     got = [e3.step(b)['log_vars']['loss'] for _ in range(2)]
     for a, g in zip(nxt, got):
         assert abs(a - g) < 2e-2 * max(1.0, abs(a)), (nxt, got)

@@ -145,6 +145,109 @@ def test_optimizer_param_groups_and_lr_schedule():
     assert cosine_lr(base, 10, 1000, warmup_iters=10) == cosine_lr(base, 10, 1000)
 
 
+def test_paramwise_lr_mult_and_fractional_decay():
+    """mmcv DefaultOptimizerConstructor: custom_keys carry lr_mult AND decay_mult (any value), bias_lr_mult applies to
+    non-norm biases; a custom-key hit switches the norm / bias rules off."""
+    import clover_amd
+    from clover_amd.engine import paramwise_options
+    m = clover_amd.build_model(cf.tiny_model_cfg())
+    o = paramwise_options(m, 0.01, dict(norm_decay_mult=0.0, bias_decay_mult=0.0, bias_lr_mult=2.0, custom_keys={
+        'backbone.layers': dict(lr_mult=0.1, decay_mult=0.5), 'relative_position_bias_table': dict(decay_mult=0.)}))
+    assert o['backbone.layers.0.blocks.0.attn.relative_position_bias_table'] == (0.0, 1.0)   # longest key wins
+    assert o['backbone.layers.0.blocks.0.attn.qkv.weight'] == (0.005, 0.1)
+    assert o['backbone.layers.0.blocks.0.attn.qkv.bias'] == (0.005, 0.1)          # custom key: bias rule is off
+    assert o['backbone.layers.0.blocks.0.norm1.weight'] == (0.005, 0.1)           # ... and the norm rule
+    assert o['text_backbone.bert.encoder.layer.0.output.dense.bias'] == (0.0, 2.0)
+    assert o['text_backbone.bert.encoder.layer.0.output.LayerNorm.bias'] == (0.0, 1.0)
+    assert o['text_backbone.bert.encoder.layer.0.output.dense.weight'] == (0.01, 1.0)
+
+
+def test_lr_follows_runner_iter_in_two_loader_mode():
+    """the reference's LR hook reads runner.iter, which the two-loader runner advances once per batch
+    INDEX (clover_runner.py:76-91), so both loaders' steps of an index share one LR, the first step uses iter 0 and
+    warm-up lasts warmup_epochs x len(longest loader) indices.  Checked against mmcv's formula written out."""
+    import math
+    from clover_amd.runner import CloverRunner, LrUpdaterHook
+
+    class Stepper(_FakeStepper):
+        def __init__(self):
+            super().__init__()
+            self.lrs = []
+
+        def set_lr(self, lr):
+            self._lr = lr
+
+        def train_step(self, batch, opt):
+            self.lrs.append(self._lr)
+            return super().train_step(batch, opt)
+    A, B = [f'a{i}' for i in range(6)], [f'b{i}' for i in range(4)]
+    base, epochs, warm_epochs = 1e-3, 3, 1
+    st = Stepper()
+    r = CloverRunner(st, max_epochs=epochs)
+    r.register_hook(LrUpdaterHook(base, min_lr_ratio=1e-3, warmup='linear', warmup_iters=warm_epochs,
+                                  warmup_ratio=0.001, warmup_by_epoch=True))
+    r.run([A, B], [('train', 1)], epochs)
+    max_iters, warm = epochs * len(A), warm_epochs * len(A)
+
+    def mmcv_lr(it):
+        end = base * 1e-3
+        lr = end + 0.5 * (base - end) * (1 + math.cos(math.pi * it / max_iters))          # annealing_cos
+        if it < warm:
+            k = (1 - it / warm) * (1 - 0.001)                                                # get_warmup_lr 'linear'
+            lr = lr * (1 - k)
+        return lr
+    want = [mmcv_lr(i) for i in range(max_iters) for _ in range(2)]                         # two steps per index
+    assert len(st.lrs) == len(want) == 36
+    assert max(abs(a - b) for a, b in zip(st.lrs, want)) < 1e-15
+    assert st.lrs[0] == mmcv_lr(0) and st.lrs[0] < base * 2e-3                              # iter 0, not 1
+    assert st.lrs[2 * warm] == mmcv_lr(warm) and st.lrs[-1] > base * 1e-3                   # never clamped early
+
+
+def test_bert_loader_maps_legacy_checkpoint_names(tmp_path, monkeypatch):
+    """the stock bert-base-uncased file names LayerNorm params gamma / beta and the MLM output bias
+    ``cls.predictions.bias``; from_pretrained (bert_from_hugface.py:13-15, mlm_itm_head.py:33-35) renames / ties
+    them.  A fake checkpoint in the OLD naming must initialise every parameter; a partial one must raise."""
+    from clover_amd.backbones.bert_from_hugface import BertFromPretrained
+    from clover_amd.backbones.cross_transformer import CrossModalTransformerFromPretrained
+    from clover_amd.heads.mlm_itm_head import MLMHead
+    bc = dict(vocab_size=50, hidden_size=16, num_hidden_layers=2, num_attention_heads=2, intermediate_size=32,
+              max_position_embeddings=24)
+    src = BertFromPretrained(None, bert_config=bc, num_hidden_layers=2)
+    g = torch.Generator().manual_seed(3)
+    new = {'bert.' + k: torch.randn(v.shape, generator=g) for k, v in src.bert.state_dict().items()}
+    new.update({'cls.predictions.transform.dense.weight': torch.randn(16, 16, generator=g),
+                'cls.predictions.transform.dense.bias': torch.randn(16, generator=g),
+                'cls.predictions.transform.LayerNorm.weight': torch.randn(16, generator=g),
+                'cls.predictions.transform.LayerNorm.bias': torch.randn(16, generator=g),
+                'cls.predictions.bias': torch.randn(50, generator=g)})                     # no decoder.* keys at all
+    old = {k.replace('LayerNorm.weight', 'LayerNorm.gamma').replace('LayerNorm.bias', 'LayerNorm.beta'): v
+           for k, v in new.items()}
+    assert any('gamma' in k for k in old)
+    d = tmp_path / 'bert-base-uncased'
+    d.mkdir()
+    import json
+    (d / 'config.json').write_text(json.dumps(bc))
+    torch.save(old, str(d / 'pytorch_model.bin'))
+    monkeypatch.chdir(tmp_path)                             # the MLM head's hard-coded 'bert-base-uncased' (:33)
+    text = BertFromPretrained('bert-base-uncased', num_hidden_layers=2)
+    for k, v in text.bert.state_dict().items():
+        assert torch.equal(v, new['bert.' + k]), k
+    fuse = CrossModalTransformerFromPretrained('bert-base-uncased', hidden_size=16, img_in_size=16, num_frames=2,
+                                               spacial_tokens=4, num_hidden_layers=1, use_text_cls=True)
+    assert torch.equal(fuse.bert_encoder.layer[0].output.LayerNorm.weight,
+                       new['bert.encoder.layer.0.output.LayerNorm.weight'])
+    assert torch.equal(fuse.bert_embedding.LayerNorm.bias, new['bert.embeddings.LayerNorm.bias'])
+    head = MLMHead(16, 50)
+    assert torch.equal(head.predictions.decoder.bias, new['cls.predictions.bias'])          # tied bias
+    assert torch.equal(head.predictions.decoder.weight, new['bert.embeddings.word_embeddings.weight'])   # tied weight
+    assert torch.equal(head.predictions.transform.LayerNorm.weight, new['cls.predictions.transform.LayerNorm.weight'])
+    # a checkpoint that lacks a parameter must not load silently
+    broken = {k: v for k, v in old.items() if 'layer.1.output.LayerNorm.beta' not in k}
+    torch.save(broken, str(d / 'pytorch_model.bin'))
+    with pytest.raises(RuntimeError, match='not found in the checkpoint'):
+        BertFromPretrained('bert-base-uncased', num_hidden_layers=2)
+
+
 def test_lazy_log_vars_and_parse_losses():
     from clover_amd.recognizers.base import BaseRecognizer, LazyLogVars
     lv = LazyLogVars(['a_loss', 'b'], torch.tensor([1.5, 2.0]))

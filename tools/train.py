@@ -49,7 +49,8 @@ class SyntheticLoader:
 
 def main():
     args = parse_args()
-    from clover_amd.runner import (CheckpointHook, CloverRunner, Config, LogHook, parse_cfg_options, scaled_lr)
+    from clover_amd.runner import (CheckpointHook, CloverRunner, Config, LogHook, LrUpdaterHook, parse_cfg_options,
+                                   scaled_lr)
     import clover_amd
     from clover_amd.engine import CloverEngine
 
@@ -84,20 +85,20 @@ def main():
     loaders = [SyntheticLoader(s['length'], cfg.get('videos_per_gpu', 1), s.get('frames', 8), s.get('tokens', 32),
                                1000 * (i + 1) + rank, dev) for i, s in enumerate(syn)]
     opt, lrc = cfg.optimizer, cfg.lr_config
-    iters_per_epoch = max(len(ld) for ld in loaders)
     engine = CloverEngine(model, next(iter(loaders[0])), lr=lr, betas=tuple(opt.get('betas', (0.9, 0.999))),
                           eps=opt.get('eps', 1e-8), weight_decay=opt.get('weight_decay', 0.0),
                           paramwise_cfg=opt.get('paramwise_cfg'),
-                          grad_clip=(cfg.get('optimizer_config', {}).get('grad_clip') or {}).get('max_norm', 0.0),
-                          max_iters=cfg.total_epochs * iters_per_epoch,
-                          warmup_iters=lrc.get('warmup_iters', 0) * (iters_per_epoch if lrc.get('warmup_by_epoch') else 1),
-                          min_lr_ratio=lrc.get('min_lr_ratio', 1e-3), warmup_ratio=lrc.get('warmup_ratio', 1e-3))
+                          grad_clip=(cfg.get('optimizer_config', {}).get('grad_clip') or {}).get('max_norm', 0.0))
+    if lrc.get('policy', 'CosineAnnealing') != 'CosineAnnealing' or lrc.get('by_epoch', True):
+        raise NotImplementedError('lr_config: only CosineAnnealing with by_epoch=False (the reference recipe)')
     if cfg.get('hip_graph', True):                       # static shapes: replay the step as hipGraphs
         first = next(iter(loaders[0]))
-        engine.step(first)
+        engine.dry_step(first)                           # no optimizer step: training starts from the initial weights
         engine.capture(first)
     runner = CloverRunner(engine, model=model, work_dir=cfg.work_dir, max_epochs=cfg.total_epochs,
                           meta=dict(config_name=os.path.basename(args.config), seed=args.seed))
+    # the LR follows runner.iter (batch indices), not the count of optimizer steps (two per index with two loaders)
+    runner.register_hook(LrUpdaterHook(lr, **{k: v for k, v in dict(lrc).items() if k not in ('policy', 'by_epoch')}))
     if rank == 0:
         runner.register_hook(LogHook(cfg.get('log_config', {}).get('interval', 10), printer=print))
         if cfg.get('checkpoint_config'):
