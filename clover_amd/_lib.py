@@ -64,6 +64,9 @@ SIGNATURES = {
     'clv_normsoftmax_bwd': (C.c_int, [_p] * 6 + [_i32, _i32, _f, _p]),
     'clv_sumsq': (C.c_int, [_p, _p, _i64, _p]),
     'clv_adamw_step': (C.c_int, [_p] * 6 + [_i64] + [_f] * 9 + [_p]),
+    'clv_gemm_nt_supported': (C.c_int, [_i64, _i32, _i32]),
+    'clv_gemm_nt': (C.c_int, [_p] * 6 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p]),
+    'clv_transpose_batch': (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),
     'clv_adamw_step_dev': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
 }

@@ -1,0 +1,401 @@
+// LDS-tiled bf16 MFMA GEMM with fused epilogues for the mid-size Linear layers of the step (Swin stages 1-3, the
+// fusion encoder; M = 3 000 .. 50 000 rows, N and K = 192 .. 3072):
+//        C[M][N] = A[M][K] * B[N][K]^T  (+ bias)  (GELU | * GELU'(aux))
+// Both operands are K-contiguous ("NT"), which is what every GEMM of a Linear layer is once the weight is also kept
+// transposed:   forward  y  = x  W^T        A = x  [M][K],   B = W   [N][K]      (Mlp.fc1/fc2, qkv, proj:
+//               dgrad    dx = dy W          A = dy [M][N],   B = W^T [K][N]       swin_transformer_3d.py:262-268,376,398)
+// (the engine keeps a bf16 W^T next to the bf16 W shadow, refreshed once per step — clv_transpose_batch).
+// Epilogues: bias; bias + erf-GELU with the pre-activation kept (fc1 forward — replaces GEMM + GELU kernel);
+// multiply by GELU'(pre) (fc2 input gradient — replaces GEMM + GELU-backward kernel).
+//
+// Structure (gfx950): 256 x 128 (or 128 x 128) output tile per 512-thread workgroup (8 waves, 64 x 64 / 64 x 32 each,
+// 16x16x32 bf16 MFMA with swapped operands), 64-deep K stages brought global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring that fills the LDS, counted vmcnt waits
+// + one raw s_barrier per stage; ONE persistent workgroup per CU whose tiles form one flat pipeline (see the kernel).  LDS rows are 128 B
+// (64 bf16: full cache lines — 64-byte rows fetch at half the rate) with the 16-byte chunk index XORed with (row & 7)
+// on the SOURCE side (the DMA writes lane-linear), which makes every ds_read_b128 of an MFMA operand bank-conflict free.  The epilogue runs on the accumulators and stores 16 bytes per lane and instruction (no
+// LDS round trip); the bias row sits in LDS.  The tiles of one row block run on one XCD (blockIdx % 8), so A rows are
+// fetched from HBM once per XCD L2; B (the weight) is shared by all.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+constexpr int GN_BK = 64;                                      // bf16 elements per stage row = 128 B (a full L2 line:
+                                                               // 64-byte rows fetch at half the rate, tools/probes/dma_rate.cpp)
+constexpr int GN_MAX_BIAS = 3072;                              // bias row kept in LDS (as bf16)
+
+__device__ __forceinline__ void gn_dma16(const bf16_t* src, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_byte)
+                 : "memory");
+}
+template <int N_>
+__device__ __forceinline__ void gn_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// One operand stage: ROWS rows x 64 k.  A DMA piece is 1 KiB = 8 LDS rows x 128 B, written lane-linear: lane l lands at
+// LDS row l >> 3, chunk position l & 7, and fetches chunk (l & 7) ^ (row & 7) of the GLOBAL row that LDS row holds
+// (with this XOR the 16 rows x 16 B of an MFMA operand read cover the 16 slots of a 256-byte bank row once per
+// ds_read_b128 lane group).  ROWS / 64 pieces per wave.  Rows past the edge are CLAMPED to the last valid row: they feed
+// only accumulators that are never stored.  PERM_TN > 0 (the B operand): the LDS image is row-permuted so that the
+// swapped-operand MFMAs leave each lane with 8 CONSECUTIVE output columns per accumulator pair and the 4 lanes of a row
+// with 64 contiguous bytes per store instruction: LDS row j*16 + x of a wave's WN-row block holds global row
+// (j >> 1) * 32 + (x >> 2) * 8 + (j & 1) * 4 + (x & 3) — the per-lane source address makes any row permutation free.
+template <int ROWS, int WAVES>
+struct GnOper {
+    static constexpr int PIECES = ROWS / (8 * WAVES);
+    const bf16_t* src[PIECES];
+};
+
+template <int ROWS, int WAVES, int PERM_TN>
+__device__ __forceinline__ void gn_init(GnOper<ROWS, WAVES>& o, const bf16_t* base, int64_t row0, int64_t nrows, int64_t ld, int wave,
+                                        int lane) {
+#pragma unroll
+    for (int j = 0; j < GnOper<ROWS, WAVES>::PIECES; ++j) {
+        const int r = (wave * GnOper<ROWS, WAVES>::PIECES + j) * 8 + (lane >> 3);      // LDS row
+        const int c = (lane & 7) ^ (r & 7);
+        int g = r;                                                               // global row held by LDS row r
+        if (PERM_TN > 0) {
+            constexpr int WN = PERM_TN * 16;
+            const int h = r / WN, p = r % WN, jj = p >> 4, x = p & 15;
+            g = h * WN + (jj >> 1) * 32 + (x >> 2) * 8 + (jj & 1) * 4 + (x & 3);
+        }
+        int64_t gr = row0 + g;
+        gr = gr < nrows ? gr : nrows - 1;
+        o.src[j] = base + gr * ld + c * 8;
+    }
+}
+
+template <int ROWS, int WAVES>
+__device__ __forceinline__ void gn_issue(GnOper<ROWS, WAVES>& o, unsigned lds_oper_base, int wave) {
+#pragma unroll
+    for (int j = 0; j < GnOper<ROWS, WAVES>::PIECES; ++j) {
+#ifndef GN_ABL_NODMA
+        gn_dma16(o.src[j], __builtin_amdgcn_readfirstlane(lds_oper_base + (unsigned)((wave * GnOper<ROWS, WAVES>::PIECES + j) * 1024)));
+#endif
+        o.src[j] += GN_BK;
+    }
+}
+
+__device__ __forceinline__ Frag8 gn_frag(const unsigned char* oper, int r, int kc) {
+    Frag8 f;
+    f.u4 = *reinterpret_cast<const uint4*>(oper + r * 128 + ((kc ^ (r & 7)) << 4));
+    return f;
+}
+
+enum { GN_EPI_NONE = CLV_GEMM_EPI_NONE, GN_EPI_BIAS = CLV_GEMM_EPI_BIAS, GN_EPI_GELU = CLV_GEMM_EPI_BIAS_GELU,
+       GN_EPI_DGELU = CLV_GEMM_EPI_DGELU };
+
+__device__ __forceinline__ float gn_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float gn_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ONE persistent 8-wave workgroup per CU (waves as WAVES_M x WAVES_N, two per SIMD); workgroup w lives on XCD w & 7
+// (dispatch order) and walks the tiles of the row blocks mblk = xcd (mod 8) in (mblk, tn) order with stride gridDim / 8,
+// so the tiles that share A rows run on one XCD's L2.  The 64-deep stages of ALL its tiles form one flat software
+// pipeline through a ring of R slots that fills the LDS: while stage g is multiplied, stages g+1 .. g+R-1 — the next
+// tile's first stages included — are in flight (~100 KB per CU: LDS-DMA round trips measure 1 100 cycles from L2 and
+// 2 700 from the Infinity Cache), with counted vmcnt waits and one raw s_barrier per stage (LDS-DMA requests stay in
+// flight across it).  The epilogue runs straight on the accumulators; its stores are younger than the stages already in
+// flight, which the wait counts of the next R-1 stages account for (gfx9 returns loads and stores in issue order on
+// vmcnt), so the stores drain under the next tile's first stages instead of stalling the pipeline.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int R, int EPI>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                                const float* __restrict__ bias, const bf16_t* __restrict__ aux,
+                                                                bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N,
+                                                                int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN,
+                                                                int nmblk) {
+    constexpr int WAVES = WAVES_M * WAVES_N, GN_THREADS = 64 * WAVES;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int P = GnOper<BM, WAVES>::PIECES + GnOper<BN, WAVES>::PIECES;     // DMA pieces per wave and stage
+    constexpr int S = TM * (TN / 2) * (EPI == GN_EPI_GELU ? 2 : 1);      // store instructions per wave and epilogue
+    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU;
+    static_assert((R - 2) * P + S <= 63, "vmcnt immediate");
+    static_assert(TN % 2 == 0 && R >= 2, "tile shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[R * STAGE + (HAS_BIAS ? GN_MAX_BIAS * 2 : 0)];
+    bf16_t* bias_s = reinterpret_cast<bf16_t*>(ring + R * STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int my_mblks = (nmblk - xcd + 7) >> 3;
+    const int my_tiles = my_mblks * tilesN;
+    if (slot >= my_tiles) return;
+    if (HAS_BIAS) {                                           // whole bias row -> LDS (bf16, as the GEMM's bf16 bias operand
+        for (int i = tid * 4; i < N; i += GN_THREADS * 4) {   // was), before any DMA is in flight
+            const float4 bv = *reinterpret_cast<const float4*>(bias + i);
+            *reinterpret_cast<uint2*>(bias_s + i) = make_uint2(pack2bf(bv.x, bv.y), pack2bf(bv.z, bv.w));
+        }
+        __syncthreads();
+    }
+    const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0]);
+    const int nst = K / GN_BK;
+
+    GnOper<BM, WAVES> A;
+    GnOper<BN, WAVES> B;
+    int qn = slot;                                            // tile whose stages are being issued
+    int issued = 0;                                           // its stages issued so far
+    unsigned ibase = ring_base;                               // ring slot (LDS byte address) the next issue goes to
+    int inflight = 0;                                         // stages issued and not yet consumed
+    gn_init<BM, WAVES, 0>(A, a, (int64_t)(xcd + 8 * (qn / tilesN)) * BM, M, lda, wave, lane);
+    gn_init<BN, WAVES, TN>(B, b, (qn % tilesN) * BN, N, ldb, wave, lane);
+    auto issue_next = [&]() {                                 // one stage of the flat (tile, stage) sequence, if any is left
+        if (qn >= my_tiles) return;
+        gn_issue<BM, WAVES>(A, ibase, wave);
+        gn_issue<BN, WAVES>(B, ibase + A_BYTES, wave);
+        ibase = ibase == ring_base + (R - 1) * STAGE ? ring_base : ibase + STAGE;
+        ++inflight;
+        if (++issued == nst) {
+            issued = 0;
+            qn += nslot;
+            if (qn < my_tiles) {
+                gn_init<BM, WAVES, 0>(A, a, (int64_t)(xcd + 8 * (qn / tilesN)) * BM, M, lda, wave, lane);
+                gn_init<BN, WAVES, TN>(B, b, (qn % tilesN) * BN, N, ldb, wave, lane);
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d) issue_next();
+    int cslot = 0;                                            // ring slot of the stage being multiplied
+    int post_epi = 0;                                         // stage tops whose wait must also leave S stores in flight
+
+    for (int q = slot; q < my_tiles; q += nslot) {
+        f32x4_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int st = 0; st < nst; ++st) {
+            // the oldest stage in flight must have landed; a full pipeline leaves R-2 younger stages (and, right after an
+            // epilogue, its S stores) outstanding
+            if (inflight == R - 1) {
+                if (post_epi > 0) { gn_wait_vm<(R - 2) * P + S>(); --post_epi; }
+                else gn_wait_vm<(R - 2) * P>();
+            } else {
+                gn_wait_vm<0>();
+                post_epi = 0;
+            }
+            __builtin_amdgcn_s_barrier();                     // everyone's pieces landed; slot of stage g-1 is drained
+            --inflight;
+            issue_next();
+            const unsigned char* As = ring + cslot * STAGE;
+            const unsigned char* Bs = As + A_BYTES;
+            cslot = cslot == R - 1 ? 0 : cslot + 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag8 fa[TM], fb[TN];
+#ifdef GN_ABL_NOLDS
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i].u4 = make_uint4(0x3c003c00u + st, 0x3c003c00u, 0x3c003c00u + i, 0x3c003c00u);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j].u4 = make_uint4(0x3c003c00u + j, 0x3c003c00u, 0x3c003c00u + lane, 0x3c003c00u);
+#else
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = gn_frag(Bs, wn + j * 16 + lr, ks * 4 + lg);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = gn_frag(As, wm + i * 16 + lr, ks * 4 + lg);
+#endif
+#ifdef GN_ABL_NOMFMA
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i].u4.x), "v"(fa[i].u4.w));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j].u4.x), "v"(fb[j].u4.w));
+#else
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+#endif
+            }
+        }
+
+        // ---- epilogue of tile q, from registers.  Swapped MFMA + permuted B rows: acc[i][j][r] =
+        // C[m0 + wm + i*16 + lr][n0 + wn + (j>>1)*32 + lg*8 + (j&1)*4 + r]: the accumulator pair (2h, 2h+1) of a lane is
+        // 8 consecutive columns = one 16-byte store, and the 4 lanes of a row write 64 contiguous bytes per instruction
+        const int64_t m0 = (int64_t)(xcd + 8 * (q / tilesN)) * BM;
+        const int n0 = (q % tilesN) * BN;
+        const int nl = n0 + wn + lg * 8;                      // this lane's first column (of the pair h = 0)
+        const bool edge = m0 + BM > M || n0 + BN > N;         // wave-uniform
+#ifdef GN_ABL_NOSTORE
+        if (m0 < 0)
+#endif
+#pragma unroll
+        for (int h = 0; h < TN / 2; ++h) {
+            const int nh = nl + h * 32;
+            if (nh >= N) continue;                            // N % 8 == 0: groups of 8 columns are in or out together
+            float bn[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bn[e] = 0.f;
+            if (HAS_BIAS) {
+                const uint4 bv = *reinterpret_cast<const uint4*>(bias_s + nh);
+                const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bn[e] = (e & 1) ? gn_hi(bw[e >> 1]) : gn_lo(bw[e >> 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t m = m0 + wm + i * 16 + lr;
+                if (m >= M) continue;
+                const int64_t g = m * ldc + nh;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bn[e];
+                if (EPI == GN_EPI_GELU) {
+                    *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                                   pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (EPI == GN_EPI_DGELU) {
+                    const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
+                    const uint32_t pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] *= gelu_erf_grad((e & 1) ? gn_hi(pv[e >> 1]) : gn_lo(pv[e >> 1]));
+                }
+                *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                              pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+#ifdef GN_ABL_NOSTORE
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]));
+        gn_wait_vm<0>();
+#endif
+        if (edge || nst < R - 1) {                            // fewer than S stores were issued (edge), or a second epilogue
+            gn_wait_vm<0>();                                  // could fall into the window: drain, plain counts are valid again
+            post_epi = 0;
+        } else {
+            post_epi = R - 1;
+        }
+    }
+}
+
+// Batched 2-D transposes of bf16 matrices (the W^T shadows): one 64 x 64 tile per workgroup through LDS, 16-byte
+// accesses on both sides.  Entry e: src [rows][cols] -> dst [cols][rows]; tile_begin = prefix sum of tile counts.
+struct TrEntry {
+    int64_t src_off, dst_off;                                 // element offsets into src_base / dst_base
+    int32_t rows, cols, tile_begin, tiles_c;
+};
+
+__global__ void __launch_bounds__(256) transpose_batch_kernel(const bf16_t* __restrict__ src_base, bf16_t* __restrict__ dst_base,
+                                                              const TrEntry* __restrict__ table, int n_entries) {
+    __shared__ bf16_t tile[64][64 + 8];
+    const int t = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;                           // the entry whose tile range holds t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    const TrEntry e = table[lo];
+    const int lt = t - e.tile_begin, tr = lt / e.tiles_c, tc = lt % e.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const bf16_t* src = src_base + e.src_off;
+    bf16_t* dst = dst_base + e.dst_off;
+    const bool vec = (e.rows % 8 == 0) && (e.cols % 8 == 0);
+    for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
+        const int r = idx >> 3, c8 = (idx & 7) * 8;
+        if (vec) {
+            if (r0 + r < e.rows && c0 + c8 < e.cols)
+                *reinterpret_cast<uint4*>(&tile[r][c8]) =
+                    *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * e.cols + c0 + c8);
+        } else {
+            for (int q = 0; q < 8; ++q)
+                if (r0 + r < e.rows && c0 + c8 + q < e.cols) tile[r][c8 + q] = src[(int64_t)(r0 + r) * e.cols + c0 + c8 + q];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
+        const int cc = idx >> 3, r8 = (idx & 7) * 8;          // output row = source column
+        if (c0 + cc >= e.cols) continue;
+        if (vec) {
+            if (r0 + r8 < e.rows) {
+                u16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.v[q] = tile[r8 + q][cc];
+                *reinterpret_cast<u16x8*>(dst + (int64_t)(c0 + cc) * e.rows + r0 + r8) = o;
+            }
+        } else {
+            for (int q = 0; q < 8; ++q)
+                if (r0 + r8 + q < e.rows) dst[(int64_t)(c0 + cc) * e.rows + r0 + r8 + q] = tile[r8 + q][cc];
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int R>
+int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, const bf16_t* aux,
+              bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk) {
+#define GN_GO(E)                                                                                                         \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, R, E>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, st, \
+                       a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, tilesN, nmblk)
+    switch (epi) {
+        case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
+        case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
+        case GN_EPI_GELU: GN_GO(GN_EPI_GELU); break;
+        case GN_EPI_DGELU: GN_GO(GN_EPI_DGELU); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef GN_GO
+    return clv_check_launch();
+}
+
+}  // namespace
+
+extern "C" int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K) {
+    return M >= 1 && N >= 64 && N % 8 == 0 && N <= GN_MAX_BIAS && K >= 64 && K % GN_BK == 0;
+}
+
+extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
+                           int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream) {
+    if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return CLV_ERR_ARG;
+    if (!clv_gemm_nt_supported(M, N, K)) return CLV_ERR_UNSUPPORTED;
+    if ((lda & 7) || (ldb & 7) || (ldc & 7) || lda < K || ldb < K || ldc < N) return CLV_ERR_ARG;
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)c2) | ((uintptr_t)aux) | ((uintptr_t)bias)) & 15)
+        return CLV_ERR_ARG;
+    if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELU) && !bias) return CLV_ERR_ARG;
+    if (epilogue == GN_EPI_GELU && !c2) return CLV_ERR_ARG;
+    if (epilogue == GN_EPI_DGELU && !aux) return CLV_ERR_ARG;
+    const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8", "256x128w4"
+    int BM = 128, BN = 128, W = 4;
+    if (force) {
+        BM = atoi(force);
+        const char* x = strchr(force, 'x');
+        if (x) BN = atoi(x + 1);
+        const char* w = strchr(force, 'w');
+        W = w ? atoi(w + 1) : (BM == 256 ? 8 : 4);
+    }
+    const int tilesN = (N + BN - 1) / BN;
+    const int nmblk = (int)((M + BM - 1) / BM);
+    // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's tiles
+    const int per_cu = (BM == 128 && W == 4) ? 2 : 1;
+    const int max_tiles_xcd = ((nmblk + 7) / 8) * tilesN;
+    const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 32 * per_cu ? max_tiles_xcd : 32 * per_cu));
+    hipStream_t st = (hipStream_t)stream;
+#define GN_ARGS epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux, (bf16_t*)c, (bf16_t*)c2, M, N, K, \
+                lda, ldb, ldc, tilesN, nmblk
+    if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
+    if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
+    if (BM == 256 && BN == 128 && W == 4) return gn_launch<256, 128, 2, 2, 3>(GN_ARGS);   // wave tile 128 x 64
+    if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4
+#undef GN_ARGS
+    return CLV_ERR_UNSUPPORTED;
+}
+
+extern "C" int clv_transpose_batch(const void* src_base, void* dst_base, const void* table, int32_t n_entries,
+                                   int32_t total_tiles, void* stream) {
+    if (!src_base || !dst_base || !table || n_entries <= 0 || total_tiles <= 0) return CLV_ERR_ARG;
+    static_assert(sizeof(TrEntry) == CLV_TRANSPOSE_ENTRY_BYTES, "TrEntry layout is part of the ABI");
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src_base, (bf16_t*)dst_base, (const TrEntry*)table, (int)n_entries);
+    return clv_check_launch();
+}

@@ -430,6 +430,60 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+# --------------------------------------------------------------------------- LDS-tiled GEMM with fused epilogues
+GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU = 0, 1, 2, 3
+
+
+def gemm_nt_supported(M, N, K):
+    return bool(_lib.lib().clv_gemm_nt_supported(int(M), int(N), int(K)))
+
+
+def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
+    """Raw launcher of clv_gemm_nt (no autograd): c [M,N] = a [M,K] . b [N,K]^T with the epilogue fused.
+    a, b bf16 with unit inner stride; bias fp32 [N]; aux bf16 [M,N] contiguous (DGELU: the pre-activation).
+    Returns c, or (c, pre) for GEMM_EPI_BIAS_GELU."""
+    _need_gpu(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
+    c = out if out is not None else torch.empty(M, N, device=a.device, dtype=BF16)
+    c2 = torch.empty_like(c) if epilogue == GEMM_EPI_BIAS_GELU else None
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    if aux is not None:
+        assert aux.dtype == BF16 and aux.shape == (M, N) and aux.stride(1) == 1 and aux.stride(0) == c.stride(0)
+    args = (_ptr(a), _ptr(b), _ptr(bias), _ptr(aux), _ptr(c), _ptr(c2), M, N, K, a.stride(0), b.stride(0), c.stride(0),
+            int(epilogue), _stream())
+    if PROF is None:
+        check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
+    else:
+        nout = 2 if epilogue == GEMM_EPI_BIAS_GELU else 1
+        nin = 1 if epilogue == GEMM_EPI_DGELU else 0
+        with _Timed(f'gemm_nt_kernel<{128 if (N % 128 == 0 or N > 640) else 64}, {int(epilogue)}>', 2 * M * N * K,
+                    (M * K + N * K + (nout + nin) * M * N) * 2):
+            check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
+    return (c, c2) if epilogue == GEMM_EPI_BIAS_GELU else c
+
+
+def transpose_batch(src_base, dst_base, table, n_entries, total_tiles):
+    _need_gpu(src_base, dst_base, table)
+    check(_lib.lib().clv_transpose_batch(_ptr(src_base), _ptr(dst_base), _ptr(table), int(n_entries), int(total_tiles),
+                                         _stream()), 'clv_transpose_batch')
+
+
+def transpose_table(entries, device):
+    """entries: [(src_off, dst_off, rows, cols)] in elements -> (device table, n_entries, total_tiles) for
+    transpose_batch (include/clover_hip.h: CLV_TRANSPOSE_ENTRY_BYTES layout)."""
+    import struct
+    raw, tile = b'', 0
+    for src_off, dst_off, rows, cols in entries:
+        tr, tc = (rows + 63) // 64, (cols + 63) // 64
+        raw += struct.pack('<qqiiii', src_off, dst_off, rows, cols, tile, tc)
+        tile += tr * tc
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return t, len(entries), tile
+
+
 # --------------------------------------------------------------------------- row-streaming GEMM
 def rowgemm_supported(N, K, standardise=False):
     return bool(_lib.lib().clv_rowgemm_supported(int(N), int(K), int(bool(standardise))))

@@ -275,6 +275,34 @@ int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, c
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_c1, float bias_c2, float max_norm, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------ Linear layers: LDS-tiled MFMA GEMM (gemm_nt.hip)
+ * C[M][N] = A[M][K] . B[N][K]^T with fused epilogues — the forward and input-gradient GEMMs of nn.Linear as the
+ * reference's Mlp / qkv / proj / PatchMerging.reduction and the HF BERT layers run them
+ * (mmaction/models/backbones/swin_transformer_3d.py:262-268, 376, 398, 543; transformers 4.6.1 BertIntermediate /
+ * BertOutput), replacing torch's addmm + separate GELU kernels:
+ *   forward   y  = x W^T + b        A = x  [M][K], B = W   [N][K]          epilogue BIAS | BIAS_GELU | NONE
+ *   dgrad     dx = dy W             A = dy [M][N], B = W^T [K][N]          epilogue NONE | DGELU
+ * a, b, c, c2, aux: bf16, row strides lda / ldb / ldc elements (multiples of 8; c2 and aux share ldc); bias fp32 [N].
+ *   CLV_GEMM_EPI_NONE       c = acc
+ *   CLV_GEMM_EPI_BIAS       c = acc + bias
+ *   CLV_GEMM_EPI_BIAS_GELU  c2 = acc + bias (the pre-activation, kept for backward), c = GELU_erf(acc + bias)
+ *   CLV_GEMM_EPI_DGELU      c = acc * GELU_erf'(aux)      (aux = the forward's pre-activation)
+ * Needs N % 8 == 0, K % 64 == 0, 16-byte aligned pointers (clv_gemm_nt_supported); fp32 accumulation. */
+#define CLV_GEMM_EPI_NONE 0
+#define CLV_GEMM_EPI_BIAS 1
+#define CLV_GEMM_EPI_BIAS_GELU 2
+#define CLV_GEMM_EPI_DGELU 3
+int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
+int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
+                int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream);
+/* Batched transposes of bf16 matrices in one launch (the engine's W^T shadows, refreshed after every optimizer step).
+ * table: n_entries x {int64 src_off, dst_off (elements from src_base / dst_base); int32 rows, cols, tile_begin,
+ * tiles_c} on the device; entry e covers ceil(rows/64) * tiles_c tiles starting at tile_begin (tiles_c =
+ * ceil(cols/64)); total_tiles = the grid.  dst[c][r] = src[r][c]. */
+#define CLV_TRANSPOSE_ENTRY_BYTES 32
+int clv_transpose_batch(const void* src_base, void* dst_base, const void* table, int32_t n_entries,
+                        int32_t total_tiles, void* stream);
+
 /* The same step with the optimizer's scalars held on the DEVICE (no host sync, hipGraph-safe):
  * state = CLV_OPTIM_STATE_BYTES bytes {float coef, bc1, bc2_sqrt, norm; int32 skip, t, skipped, pad}, zeroed once by
  * the caller.  clv_optim_prep (one thread, after every segment's clv_sumsq): reads and re-zeroes sumsq, computes the

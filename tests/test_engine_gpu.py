@@ -73,11 +73,16 @@ def test_engine_lr_mult_and_fractional_decay_match_torch_param_groups():
         opt.step()
     p1 = dict(m1.named_parameters())
     p0 = dict(make_model().named_parameters())
+    for sg in eng.segments:                              # every parameter sits in the slab of ITS options
+        for n in sg.names:
+            assert o[n] == (sg.weight_decay, sg.lr_mult), (n, o[n], sg.weight_decay, sg.lr_mult)
     for n, p in named:
-        moved = (p.detach() - p0[n]).abs().max().item()
-        d = (p1[n].detach() - p.detach()).abs().max().item()
-        # Adam moves every weight by ~lr per step: a wrong lr_mult shows as a 2-8x different displacement
-        assert d <= 0.35 * moved + 1e-7, (n, d, moved, o[n])
+        # Adam moves each element by ~lr * lr_mult per step whatever the gradient's size (its sign may be noise):
+        # compare the mean displacement — a wrong lr_mult shows as a 2-8x ratio
+        mine = (p1[n].detach() - p0[n]).abs().mean().item()
+        ref = (p.detach() - p0[n]).abs().mean().item()
+        assert 0.6 * ref - 1e-9 <= mine <= 1.6 * ref + 1e-9, (n, mine, ref, o[n])
+        assert ref <= 3.3 * 1e-3 * o[n][1] + 1e-7, (n, ref, o[n])
 
 
 def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():

@@ -372,6 +372,103 @@ def test_adamw_and_clip():
     assert torch.equal(before, pg)
 
 
+def test_adamw_device_state_two_option_groups_and_skip():
+    """clv_optim_prep + clv_adamw_step_dev (the engine's path): two slabs with different (weight_decay, lr) — the
+    per-parameter options of a paramwise_cfg — against torch.optim.AdamW param groups with a global-norm clip; a
+    non-finite step is skipped on the device and leaves Adam's count (bias corrections) where it was."""
+    na, nb = 50001, 30002
+    pa0, pb0 = rnd(na, seed=161), rnd(nb, seed=162)
+    pra, prb = torch.nn.Parameter(pa0.clone()), torch.nn.Parameter(pb0.clone())
+    opt = torch.optim.AdamW([dict(params=[pra], weight_decay=0.5, lr=1e-2), dict(params=[prb], weight_decay=0.25, lr=2.5e-3)],
+                            betas=(0.9, 0.98), eps=1e-8)
+    pga, pgb = pa0.clone().to(DEV), pb0.clone().to(DEV)
+    ma, va, mb, vb = (torch.zeros(n, device=DEV) for n in (na, na, nb, nb))
+    sha = torch.zeros(na + (-na) % 4, device=DEV, dtype=BF)
+    state = ops().optim_state_new(DEV)
+    acc = torch.zeros(1, device=DEV)
+
+    def dev_step(ga, gb, world=1):
+        ops().sumsq_accumulate(ga, acc)
+        ops().sumsq_accumulate(gb, acc)
+        ops().optim_prep(acc, state, 0.9, 0.98, 15.0, 1.0 / world)
+        ops().adamw_step_dev(pga, ga, ma, va, sha, state, 1e-2, 0.9, 0.98, 1e-8, 0.5)
+        ops().adamw_step_dev(pgb, gb, mb, vb, None, state, 2.5e-3, 0.9, 0.98, 1e-8, 0.25)
+    for i, sc in enumerate([1.0, 30.0, 0.1]):
+        ga, gb = rnd(na, scale=sc, seed=170 + i), rnd(nb, scale=sc, seed=180 + i)
+        pra.grad, prb.grad = ga.clone(), gb.clone()
+        torch.nn.utils.clip_grad_norm_([pra, prb], 15.0)
+        opt.step()
+        if i == 1:                                          # a non-finite step in between changes nothing
+            bad = ga.clone()
+            bad[3] = float('inf')
+            before = (pga.clone(), ma.clone(), pgb.clone())
+            dev_step(bad.to(DEV), gb.to(DEV))
+            assert torch.equal(before[0], pga) and torch.equal(before[1], ma) and torch.equal(before[2], pgb)
+            assert ops().optim_state_read(state)['skip'] == 1
+        dev_step(2.0 * ga.to(DEV), 2.0 * gb.to(DEV), world=2)       # grad_scale = 1/W undoes the summed gradients
+        assert float(acc.item()) == 0.0                     # prep re-zeroes the accumulator
+    st = ops().optim_state_read(state)
+    assert st['t'] == 3 and st['skipped'] == 1 and st['skip'] == 0
+    assert rel(pga, pra.data) < 1e-5 and rel(pgb, prb.data) < 1e-5
+    assert rel(sha[:na].float(), pra.data) < 1e-2
+    gn = (rnd(na, scale=0.1, seed=172).double().pow(2).sum() + rnd(nb, scale=0.1, seed=182).double().pow(2).sum()).sqrt()
+    assert abs(st['norm'] - gn.item()) < 1e-3 * gn.item()
+
+
+# ----------------------------------------------------------------------------- LDS-tiled GEMM + epilogues
+@pytest.mark.parametrize('M,N,K', [(12544, 1536, 384), (3136, 768, 3072), (3648, 2304, 768), (50176, 192, 192),
+                                   (1000, 576, 192), (130, 64, 64), (257, 200, 128), (4096, 1152, 384)])
+def test_gemm_nt_epilogues(M, N, K):
+    """clv_gemm_nt against fp32 torch on the same bf16 operands: plain, bias, bias + GELU (pre-activation kept) and
+    the GELU-backward epilogue; ragged M / N edges, both tile widths."""
+    F_ = torch.nn.functional
+    a = rnd(M, K, seed=301).to(BF)
+    w = rnd(N, K, scale=0.05, seed=302).to(BF)
+    bias = rnd(N, scale=0.2, seed=303)
+    ref = a.float() @ w.float().t()
+    ag, wg, bg = a.to(DEV), w.to(DEV), bias.to(DEV)
+    scale = ref.abs().max().item()
+    c0 = ops().gemm_nt(ag, wg, epilogue=ops().GEMM_EPI_NONE)
+    assert (c0.float().cpu() - ref).abs().max().item() < 6e-3 * scale
+    c1 = ops().gemm_nt(ag, wg, bg, epilogue=ops().GEMM_EPI_BIAS)
+    assert (c1.float().cpu() - (ref + bias)).abs().max().item() < 6e-3 * scale
+    act, pre = ops().gemm_nt(ag, wg, bg, epilogue=ops().GEMM_EPI_BIAS_GELU)
+    assert (pre.float().cpu() - (ref + bias)).abs().max().item() < 6e-3 * scale
+    assert (act.float().cpu() - F_.gelu(ref + bias)).abs().max().item() < 6e-3 * scale
+    prein = rnd(M, N, seed=304).to(BF)
+    x = prein.float().requires_grad_()
+    F_.gelu(x).backward(torch.ones_like(x))
+    c3 = ops().gemm_nt(ag, wg, aux=prein.to(DEV), epilogue=ops().GEMM_EPI_DGELU)
+    want = ref.to(BF).float() * x.grad                    # the unfused path rounds d act to bf16 first
+    assert (c3.float().cpu() - want).abs().max().item() < 8e-3 * scale
+    # strided A (a column slice of a wider tensor, as the q|k|v views are); 32 elements keep 16-byte alignment
+    wide = torch.zeros(M, K + 64, dtype=BF)
+    wide[:, 32:32 + K] = a
+    c4 = ops().gemm_nt(wide.to(DEV)[:, 32:32 + K], wg, epilogue=ops().GEMM_EPI_NONE)
+    assert torch.equal(c4, c0)
+
+
+def test_transpose_batch():
+    shapes = [(384, 1536), (96, 288), (100, 72), (64, 64), (30522 // 6, 768), (7, 5)]
+    src = torch.zeros(sum(r * c for r, c in shapes) + 64, dtype=BF)
+    entries, off = [], 8
+    mats = []
+    for i, (r, c) in enumerate(shapes):
+        m = rnd(r, c, seed=310 + i).to(BF)
+        src[off:off + r * c] = m.flatten()
+        entries.append((off, off, r, c))
+        mats.append((off, m))
+        off += r * c
+    sg = src.to(DEV)
+    dg = torch.zeros_like(sg)
+    tab, n, tiles = ops().transpose_table(entries, DEV)
+    ops().transpose_batch(sg, dg, tab, n, tiles)
+    out = dg.cpu()
+    for (o, m) in mats:
+        r, c = m.shape
+        assert torch.equal(out[o:o + r * c].view(c, r), m.t().contiguous())
+
+
 # ----------------------------------------------------------------------------- linear weight grad
 @pytest.mark.parametrize('M,N,K', [(50176, 288, 96), (12544, 96, 384), (4096, 1152, 384), (3000, 96, 96), (777, 3072, 768),
                                    (256, 768, 3072), (1000, 200, 104), (33, 8, 8), (1500, 768, 768)])
