@@ -804,39 +804,36 @@ __global__ void __launch_bounds__(128) ln_fold_fwd_kernel(const float* __restric
     if (threadIdx.x == 0) bf[n] = (b ? b[n] : 0.f) + red[0] + red[1];
 }
 
-// dW[n][k] += dwf[n][k] gamma[k] + dbf[n] beta[k];  db[n] += dbf[n]   (grid over N*K)
-__global__ void __launch_bounds__(256) ln_fold_bwd_w_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ dw,
-                                                            float* __restrict__ db, int N, int K) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * K) return;
-    const int n = e / K, k = e - n * K;
-    dw[e] += dwf[e] * gamma[k] + dbf[n] * beta[k];
-    if (db && k == 0) db[n] += dbf[n];
-}
-
-// dgamma[k] += sum_n dwf[n][k] w[n][k];  dbeta[k] += sum_n dbf[n] w[n][k]   (block = 64 columns x 4 row lanes)
-__global__ void __launch_bounds__(256) ln_fold_bwd_g_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf,
-                                                            const float* __restrict__ w, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int N, int K) {
-    __shared__ float sg[4][64], sb[4][64];
-    const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + kl;
-    float g = 0.f, bb = 0.f;
-    if (k < K)
-        for (int n = rl; n < N; n += 4) {
-            const float wv = w[(int64_t)n * K + k];
-            g += dwf[(int64_t)n * K + k] * wv;
-            bb += dbf[n] * wv;
+// One pass over (dwf, w), ROWS rows per block, a thread per column:
+//   dW[n][k] += dwf[n][k] gamma[k] + dbf[n] beta[k];  db[n] += dbf[n];
+//   dgamma[k] += sum_n dwf[n][k] w[n][k];  dbeta[k] += sum_n dbf[n] w[n][k]   (block partials -> one atomic per column)
+// (was two kernels, the column sums a 2-block launch that walked all N rows serially: 30-40 us at N = 384.)
+constexpr int LNF_ROWS = 4;
+__global__ void __launch_bounds__(128) ln_fold_bwd_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf,
+                                                          const float* __restrict__ w, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ dw,
+                                                          float* __restrict__ db, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int N, int K) {
+    const int n0 = blockIdx.x * LNF_ROWS;
+    float dbn[LNF_ROWS];
+#pragma unroll
+    for (int r = 0; r < LNF_ROWS; ++r) dbn[r] = n0 + r < N ? dbf[n0 + r] : 0.f;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float gk = gamma[k], bk = beta[k];
+        float g = 0.f, bb = 0.f;
+#pragma unroll
+        for (int r = 0; r < LNF_ROWS; ++r) {
+            if (n0 + r >= N) break;
+            const int64_t e = (int64_t)(n0 + r) * K + k;
+            const float wv = w[e], dv = dwf[e];
+            dw[e] += dv * gk + dbn[r] * bk;
+            g += dv * wv;
+            bb += dbn[r] * wv;
         }
-    sg[rl][kl] = g;
-    sb[rl][kl] = bb;
-    __syncthreads();
-    if (rl == 0 && k < K) {
-        dgamma[k] += sg[0][kl] + sg[1][kl] + sg[2][kl] + sg[3][kl];
-        dbeta[k] += sb[0][kl] + sb[1][kl] + sb[2][kl] + sb[3][kl];
+        atomicAdd(dgamma + k, g);
+        atomicAdd(dbeta + k, bb);
     }
+    if (db && threadIdx.x < LNF_ROWS && n0 + threadIdx.x < N) db[n0 + threadIdx.x] += dbf[n0 + threadIdx.x];
 }
 
 }  // namespace
@@ -854,9 +851,7 @@ extern "C" int clv_ln_fold_bwd(const float* dwf, const float* dbf, const float* 
                                int32_t K, void* stream) {
     if (!dwf || !dbf || !w || !gamma || !beta || !dw || !dgamma || !dbeta || N <= 0 || K <= 0) return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ln_fold_bwd_w_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, dwf, dbf, gamma, beta, dw, db,
-                       (int)N, (int)K);
-    hipLaunchKernelGGL(ln_fold_bwd_g_kernel, dim3((K + 63) / 64), dim3(256), 0, st, dwf, dbf, w, dgamma, dbeta, (int)N,
-                       (int)K);
+    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3((N + LNF_ROWS - 1) / LNF_ROWS), dim3(128), 0, st, dwf, dbf, w, gamma, beta, dw,
+                       db, dgamma, dbeta, (int)N, (int)K);
     return clv_check_launch();
 }
