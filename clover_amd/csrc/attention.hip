@@ -171,6 +171,21 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     int* linb_s = row_s + NK;                                // mode 1 + bias: 4 * lin(n)
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);    //                the head's bias table
     token_rows<NK>(G, grp, row_s, tid);
+    // Q fragments of ALL this wave's query tiles go out before the K / V staging loads: their round trip (~2 us under
+    // load) then overlaps the staging instead of stalling every tile of the loop below.  (Long windows keep the
+    // per-tile load: their score registers leave no room.)
+    constexpr int PRE = NKT <= 16 ? (NKT + WAVES - 1) / WAVES : 1;
+    const int nqt = (N + 15) >> 4;
+    Frag8 qpre[PRE][KS];
+    if (PRE > 1) {
+#pragma unroll
+        for (int ti = 0; ti < PRE; ++ti) {
+            const int qt = wave + WAVES * part + ti * WAVES * G.tsplit;
+            const int nq = qt * 16 + (lane & 15);
+            const bool qv = qt < nqt && nq < N;
+            load_frags<HD>(qpre[ti], q + (int64_t)row_s[qv ? nq : 0] * G.g.ldq + h * HD, qv, lane);
+        }
+    }
     stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
     if (MODE == 1 && bias) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
@@ -185,14 +200,22 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     }
     __syncthreads();
 
-    const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
-    for (int qt = wave + WAVES * part; qt < nqt; qt += WAVES * G.tsplit) {
+    constexpr int UNR = PRE > 1 ? PRE : 1;
+#pragma unroll UNR
+    for (int ti = 0; ti < (NKT + WAVES - 1) / WAVES; ++ti) {
+        const int qt = wave + WAVES * part + ti * WAVES * G.tsplit;
+        if (qt >= nqt) break;
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
         const int64_t qrow = row_s[qv ? nq : 0];
         Frag8 qf[KS];
-        load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
+        if (PRE > 1) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) qf[s] = qpre[PRE > 1 ? ti : 0][s];
+        } else {
+            load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
+        }
 
         float p[NKT][4];
         // relative-position bias from the LDS table: byte offset = 4 * (lin(q) + tcst) - 4 * lin(key)
@@ -313,6 +336,21 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
     const bool tb = MODE == 1 && bias != nullptr;
 
     token_rows<NK>(G, grp, row_s, tid, nthr);
+    // q / dO / o fragments of all this wave's query tiles go out before the K / V staging loads (see attn_fwd_kernel)
+    constexpr int NWAVES = DKV_THREADS(NKT) / 64;
+    constexpr int PRE = (NKT + NWAVES - 1) / NWAVES;
+    const int nqt = (N + 15) >> 4;
+    Frag8 qpre[PRE][KS], dopre[PRE][KS], opre[PRE][KS];
+#pragma unroll
+    for (int ti = 0; ti < PRE; ++ti) {
+        const int qt = wave + nwaves * part + ti * nwaves * G.tsplit;
+        const int nq = qt * 16 + (lane & 15);
+        const bool qv = qt < nqt && nq < N;
+        const int64_t qrow = row_s[qv ? nq : 0];
+        load_frags<HD>(qpre[ti], q + qrow * G.g.ldq + h * HD, qv, lane);
+        load_frags<HD>(dopre[ti], dout + qrow * G.g.ldo + h * HD, qv, lane);
+        load_frags<HD>(opre[ti], o + qrow * G.g.ldo + h * HD, qv, lane);
+    }
     stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid, nthr);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid, nthr);
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
@@ -323,17 +361,18 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
     }
     __syncthreads();
 
-    const int nqt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int qt = wave + nwaves * part; qt < nqt; qt += nwaves * G.tsplit) {
+#pragma unroll
+    for (int ti = 0; ti < PRE; ++ti) {
+        const int qt = wave + nwaves * part + ti * nwaves * G.tsplit;
+        if (qt >= nqt) break;
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
         const int64_t qrow = row_s[qv ? nq : 0];
         Frag8 qf[KS], dof[KS], of[KS];
-        load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
-        load_frags<HD>(dof, dout + qrow * G.g.ldo + h * HD, qv, lane);
-        load_frags<HD>(of, o + qrow * G.g.ldo + h * HD, qv, lane);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { qf[s] = qpre[ti][s]; dof[s] = dopre[ti][s]; of[s] = opre[ti][s]; }
         float dsm = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -443,6 +482,20 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);
     const bool tb = MODE == 1 && bias != nullptr;
     token_rows<NK>(G, grp, row_s, tid, nthr);
+    // k / v fragments of all this wave's key tiles go out before the Q / dO staging loads (see attn_fwd_kernel)
+    constexpr int NWAVES = DKV_THREADS(NKT) / 64;
+    constexpr int PRE = (NKT + NWAVES - 1) / NWAVES;
+    const int nkt = (N + 15) >> 4;
+    Frag8 kpre[PRE][KS], vpre[PRE][KS];
+#pragma unroll
+    for (int ti = 0; ti < PRE; ++ti) {
+        const int kt = wave + nwaves * part + ti * nwaves * G.tsplit;
+        const int nk = kt * 16 + (lane & 15);
+        const bool kv = kt < nkt && nk < N;
+        const int64_t krow = row_s[kv ? nk : 0];
+        load_frags<HD>(kpre[ti], k + krow * G.g.ldk + h * HD, kv, lane);
+        load_frags<HD>(vpre[ti], v + krow * G.g.ldv + h * HD, kv, lane);
+    }
     stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid, nthr);
     stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid, nthr);
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
@@ -457,16 +510,18 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     }
     __syncthreads();
 
-    const int nkt = (N + 15) >> 4;
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
-    for (int kt = wave + nwaves * part; kt < nkt; kt += nwaves * G.tsplit) {
+#pragma unroll
+    for (int ti = 0; ti < PRE; ++ti) {
+        const int kt = wave + nwaves * part + ti * nwaves * G.tsplit;
+        if (kt >= nkt) break;
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
         const int64_t krow = row_s[kv ? nk : 0];
         Frag8 kf[KS], vf[KS];
-        load_frags<HD>(kf, k + krow * G.g.ldk + h * HD, kv, lane);
-        load_frags<HD>(vf, v + krow * G.g.ldv + h * HD, kv, lane);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { kf[s] = kpre[ti][s]; vf[s] = vpre[ti][s]; }
         const int rk = (MODE == 1 && rid && kv) ? rid_s[nk] : 0;
         const float kmv = (MODE == 0 && kmask && kv) ? aux[nk] : 0.f;
         const int ko = tb ? linb_s[kv ? nk : 0] - 4 * G.tcst : 0;     // slot(q, key) = lin(q) - (lin(key) - tcst)

@@ -9,6 +9,7 @@
 // accumulated straight into dW/db and there is no second kernel.  HBM-bound: algorithmic bytes = M (N + K) * 2.
 #include "common.hpp"
 #include "../../include/clover_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -306,26 +307,274 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma_kernel(const bf16_t* 
         }
 }
 
-// dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N).  Block = 64 consecutive e x
-// 16 split-lanes (1024 threads): coalesced 256-B reads, 16-way parallel splits loop, LDS tree at the end.
-__global__ void __launch_bounds__(1024) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                             float* __restrict__ db, int64_t NK, int64_t E2,
-                                                             int splits) {
-    __shared__ float sh[16][64];
-    const int el = threadIdx.x & 63, sp = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + el;
-    const int64_t Eeff = db ? E2 : NK;
-    float a = 0.f;
-    if (e < Eeff)
-        for (int s = sp; s < splits; s += 16) a += partial[(int64_t)s * E2 + e];
-    sh[sp][el] = a;
-    __syncthreads();
-    if (sp == 0 && e < Eeff) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) a += sh[k][el];
-        if (e < NK) dw[e] += a;
-        else db[e - NK] += a;
+// ---------------------------------------------------------------------------------------------------
+// Lean-loop version of wgrad_dma_kernel (same tiling, ring, swizzle and output).  The first version spent ~70 VALU and
+// ~50 SALU instructions per 32-row stage on per-piece pointer selects / 64-bit increments / bounds predicates / slot
+// arithmetic around its 16-20 MFMAs (rocprofv3 SQ counters: 3 445 VALU + 2 490 SALU per 49-stage wave) and, with one
+// wave per SIMD, ran at ~1 700 cycles per stage.  Here:
+//   * the loop is unrolled over the 4 ring slots, so every LDS address (DMA destination and transpose read) is a
+//     per-lane constant plus an IMMEDIATE;
+//   * the DMA uses the SGPR-base + 32-bit-VGPR-offset form: the per-lane offsets never change and a stage advance is
+//     two scalar adds per tensor; the four pieces of a stage are one asm block (M0 saved / restored once);
+//   * column overhang is handled by CLAMPING the source column (those products land in output rows / columns that are
+//     never stored); only the row tail needs zeros, and only the last stage of a slice can be ragged: it (and the
+//     drain of the pipeline) runs in a generic slow loop of at most 2 * RING stages.
+__device__ __forceinline__ void dma4(unsigned lds_wave_base, unsigned voff_y0, unsigned voff_y1, unsigned voff_x0,
+                                     unsigned voff_x1, const bf16_t* base_y, const bf16_t* base_x, int slot_const) {
+    unsigned keep;
+    // stage layout: [slot][dY | X][8 KiB], piece j at + j * 4096, this wave at + wave * 1024 (in lds_wave_base)
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_add_u32 m0, %[lds], %[o0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vy0], %[by]\n\t"
+        "s_add_u32 m0, %[lds], %[o1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vy1], %[by]\n\t"
+        "s_add_u32 m0, %[lds], %[o2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vx0], %[bx]\n\t"
+        "s_add_u32 m0, %[lds], %[o3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vx1], %[bx]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds_wave_base), [o0] "s"(slot_const), [o1] "s"(slot_const + 4096), [o2] "s"(slot_const + 8192),
+          [o3] "s"(slot_const + 8192 + 4096), [vy0] "v"(voff_y0), [vy1] "v"(voff_y1), [vx0] "v"(voff_x0),
+          [vx1] "v"(voff_x1), [by] "s"(base_y), [bx] "s"(base_x)
+        : "memory", "scc");
+}
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
+                                                                   const bf16_t* __restrict__ x,
+                                                                   float* __restrict__ out, float* __restrict__ out_b,
+                                                                   int64_t M, int N, int K, int ldy, int ldx, int tiles,
+                                                                   int tilesK, int nsplits, int64_t rows_per_split,
+                                                                   int want_bias) {
+    __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    int split, tile;
+    if (nsplits > 0) {                                                       // see wgrad_dma_kernel
+        const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+        split = xcd + 8 * (xslot / tiles);
+        tile = xslot % tiles;
+        if (split >= nsplits) return;
+    } else {
+        split = blockIdx.x / tiles;
+        tile = blockIdx.x - split * tiles;
     }
+    const int tn = tile / tilesK, tk = tile - tn * tilesK;
+    const int n0 = tn * TN, k0 = tk * TK;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int64_t m_begin = (int64_t)split * rows_per_split;
+    int64_t m_end = m_begin + rows_per_split;
+    if (m_end > M) m_end = M;
+    const bool do_bias = want_bias && tk == 0 && wk == 0;
+    const int rows = (int)(m_end - m_begin);
+    const int nst = (rows + SM - 1) / SM;                   // stages of this slice
+    const int nfull = rows / SM;                            // ... of which complete (all 32 rows inside)
+
+    // per-lane source offsets (bytes from the stage's first row), fixed for the whole slice: LDS position
+    // p = j*256 + tid -> row p>>4, physical chunk p&15 holds logical chunk (p&15) ^ ((row&7)<<1); columns clamped
+    unsigned vy[2], vx[2];
+    int rowj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 256 + tid;
+        const int r = p >> 4, c = ((p & 15) ^ ((r & 7) << 1)) * 8;
+        int cy = n0 + c, cx = k0 + c;
+        cy = cy < N ? cy : N - 8;
+        cx = cx < K ? cx : K - 8;
+        rowj[j] = r;
+        vy[j] = (unsigned)((r * ldy + cy) * 2);
+        vx[j] = (unsigned)((r * ldx + cx) * 2);
+    }
+    const bf16_t* by = dy + m_begin * ldy;                  // wave-uniform stage bases (SGPR pairs)
+    const bf16_t* bx = x + m_begin * ldx;
+    const int64_t step_y = (int64_t)SM * ldy, step_x = (int64_t)SM * ldx;
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)&ring[0][0][0] + (unsigned)wave * 1024u);
+    int issued = 0;                                         // stages issued so far
+    // generic issue (ragged last stage: rows past m_end read a zero chunk; past nst: nothing)
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+    auto issue_slow = [&](int slot) {
+        if (issued < nst) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool in = issued * SM + rowj[j] < rows;
+                dma16(in ? reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(by) + vy[j]) : zero,
+                      lds_wave + (unsigned)((slot * 2 + 0) * STAGE * 2 + j * 4096));
+                dma16(in ? reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(bx) + vx[j]) : zero,
+                      lds_wave + (unsigned)((slot * 2 + 1) * STAGE * 2 + j * 4096));
+            }
+            by += step_y;
+            bx += step_x;
+        }
+        ++issued;
+    };
+
+    f32x4_t acc[4][4];
+    f32x4_t bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    Frag8 ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+
+    // per-lane LDS read addresses inside a stage tensor (bf16 element offsets): transpose-read block of rows
+    // lg*4 + (lr>>2) .. , columns c0 + (lr&3)*4 .. with the pair swizzle; the second k-half is + 16 rows = + 2048 elements
+    int ry[4], rx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lg * 4 + (lr >> 2);
+        ry[i] = r * 128 + (((((wn + i * 16) >> 4) ^ (r & 7)) << 4) | ((lr & 3) << 2));
+        rx[i] = r * 128 + (((((wk + i * 16) >> 4) ^ (r & 7)) << 4) | ((lr & 3) << 2));
+    }
+    auto tr = [](const bf16_t* p) {
+        const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+        union { v4s_t v; uint2 u; } cv;
+        cv.v = v;
+        return cv.u;
+    };
+    auto compute = [&](const bf16_t* Ys, const bf16_t* Xs) {
+        Frag8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i].u2[0] = tr(Ys + ry[i]);
+            a[i].u2[1] = tr(Ys + ry[i] + 16 * 128);
+            b[i].u2[0] = tr(Xs + rx[i]);
+            b[i].u2[1] = tr(Xs + rx[i] + 16 * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = ACCUM ? mfma16(a[i], b[j], acc[i][j])      // D[n][k]: atomics coalesce along k across lanes
+                                  : mfma16(b[j], a[i], acc[i][j]);     // swapped, D[k][n]: 4 consecutive k per lane
+            if (do_bias) bacc[i] = ACCUM ? mfma16(a[i], ones, bacc[i]) : mfma16(ones, a[i], bacc[i]);
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d) issue_slow(d);       // prologue (also correct for slices shorter than the ring)
+    int st = 0;
+    // ---- lean main loop: 4 stages per trip, all issues complete stages (issued + 3 < nfull), slots are constants
+#define WG2_STAGE(SLOT)                                                                                     \
+    wait_vm<(RING - 2) * 4>();                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    WG2_DMA(lds_wave, vy[0], vy[1], vx[0], vx[1], by, bx, ((SLOT + RING - 1) % RING) * 2 * STAGE * 2);    \
+    by += step_y;                                                                                           \
+    bx += step_x;                                                                                           \
+    WG2_COMPUTE(ring[SLOT][0], ring[SLOT][1]);
+#ifdef WG_ABL_NODMA
+#define WG2_DMA(...)
+#else
+#define WG2_DMA dma4
+#endif
+#ifdef WG_ABL_NOCOMPUTE
+#define WG2_COMPUTE(a, b)
+#else
+#define WG2_COMPUTE compute
+#endif
+    for (; issued + RING <= nfull; st += RING, issued += RING) {
+        WG2_STAGE(0)
+        WG2_STAGE(1)
+        WG2_STAGE(2)
+        WG2_STAGE(3)
+    }
+#undef WG2_STAGE
+    // ---- generic tail: at most 2 * RING - 1 stages (the last complete ones, the ragged one, the drain)
+    int slot = 0;                                           // st is a multiple of RING here
+    for (; st < nst; ++st) {
+        if (issued - st == RING - 1 && issued <= nst) wait_vm<(RING - 2) * 4>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_slow(slot == 0 ? RING - 1 : slot - 1);
+        compute(ring[slot][0], ring[slot][1]);
+        slot = slot == RING - 1 ? 0 : slot + 1;
+    }
+    wait_vm<0>();
+    float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
+    float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
+    if (ACCUM) {
+        // acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]: this workgroup is the only writer of the
+        // element; the no-return L2 atomic is a fire-and-forget "+=", one instruction = 4 rows x 64 contiguous bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn + i * 16 + lg * 4 + r;
+                if (n >= N) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + wk + j * 16 + lr;
+                    if (k < K) atomicAdd(&pw[(int64_t)n * K + k], acc[i][j][r]);
+                }
+                if (do_bias && lr == 0) atomicAdd(&pb[n], bacc[i][r]);
+            }
+    } else {
+        // swapped MFMA: acc[i][j][r] = dW[n0 + wn + i*16 + lr][k0 + wk + j*16 + lg*4 + r] — a lane owns 4 consecutive k:
+        // one 16-byte store per (i, j), the 4 lanes of a row write 64 contiguous bytes (K % 8 == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn + i * 16 + lr;
+            if (n >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + j * 16 + lg * 4;
+                if (k < K)
+                    *reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            if (do_bias && lg == 0) pb[n] = bacc[i][0];       // all-ones operand: every r holds the column sum
+        }
+    }
+}
+
+// dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N): a thread owns 4 consecutive e (16-byte
+// loads, every wave load 1 KiB contiguous) for every SG-th slice, 4 loads in flight; the SG (1, 4 or 16) slice-lanes of
+// an element group are 64 threads apart and meet in LDS.  SG grows as the matrix shrinks, so that the launch has enough
+// threads (stage 0: 37 K elements x 86 slices).  (N*K and N are multiples of 8.)
+// The first version (scalar loads, 16 split-lanes per element) ran at ~1 TB/s: 78 us for 75 MB of partials.
+template <int SG>
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                            float* __restrict__ db, int64_t NK, int64_t E2,
+                                                            int splits) {
+    constexpr int EG = 256 / SG;                              // element groups (of 4) per block
+    __shared__ float4 sh[SG > 1 ? 256 : 1];
+    const int el = threadIdx.x % EG, sg = threadIdx.x / EG;
+    const int64_t e = ((int64_t)blockIdx.x * EG + el) * 4;
+    const int64_t Eeff = db ? E2 : NK;
+    const bool in = e < Eeff;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+        int sp = sg;
+        for (; sp + 3 * SG < splits; sp += 4 * SG) {
+            const float4 v0 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 0 * SG) * E2 + e);
+            const float4 v1 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 1 * SG) * E2 + e);
+            const float4 v2 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 2 * SG) * E2 + e);
+            const float4 v3 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 3 * SG) * E2 + e);
+            a.x += (v0.x + v1.x) + (v2.x + v3.x);
+            a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z);
+            a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < splits; sp += SG) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)sp * E2 + e);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    if (SG > 1) {
+        sh[threadIdx.x] = a;
+        __syncthreads();
+        if (sg != 0) return;
+#pragma unroll
+        for (int k = 1; k < SG; ++k) {
+            const float4 v = sh[k * EG + el];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    if (!in) return;
+    float* dst = e < NK ? dw + e : db + (e - NK);
+    float4 o = *reinterpret_cast<const float4*>(dst);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(dst) = o;
 }
 
 // db[n] += sum_m dy[m][n] for the library-GEMM layers (M of a few hundred..thousand rows): block = 64
@@ -360,8 +609,11 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 
 int pick_splits(int64_t M, int tiles) {
     if (M <= 1024) return 1;                            // few rows: one slice, accumulate directly (no partials)
-    int64_t s = (256 + tiles - 1) / tiles;              // ~1 workgroup per CU, 3 stages each in flight
-    if (tiles >= 4) s = (s + 7) / 8 * 8;                // whole M-slices per XCD (see wgrad_dma_kernel)
+    // ~1 workgroup per CU: every extra slice costs N*K*4 bytes of partial traffic (store + fold), which for the
+    // square-ish layers (stage 3, fusion: 144 tiles) is what the kernel's time consists of
+    if (const char* f = getenv("CLV_WGRAD_SPLITS")) return atoi(f) < (M + 255) / 256 ? atoi(f) : (int)((M + 255) / 256);
+    int64_t s = (256 + tiles - 1) / tiles;
+    if (tiles >= 4 && tiles <= 40) s = (s + 7) / 8 * 8; // whole M-slices per XCD (see wgrad_dma_kernel), while that rounding is cheap
     const int64_t max_by_rows = (M + 255) / 256;        // >= 256 rows per slice
     if (s > max_by_rows) s = max_by_rows;
     if (s < 1) s = 1;
@@ -391,7 +643,10 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     rows = (rows + TM - 1) / TM * TM;
     // up to 24 slices add their tiles into dW with no-return fp32 atomics (measured: cheaper than partials + fold;
     // with more slices the same-address contention at the memory-side atomic units costs more than the fold)
-    const bool atomic_acc = splits <= 24;
+    // one slice: its tiles are added straight into dW (no-return fp32 atomics as fire-and-forget read-modify-writes);
+    // several slices: fp32 partials + a streaming fold — atomics into dW from every slice measured 2x slower than the
+    // whole rest of the kernel (190 G atomics/s: 25 us for the 18.9 MB of a stage-2 fc1, 50 us for a stage-3 fc1)
+    const bool atomic_acc = getenv("CLV_WGRAD_ATOMIC") ? splits <= 24 : splits == 1;
     const bf16_t* dyp = (const bf16_t*)dy;
     const bf16_t* xp = (const bf16_t*)x;
     int rc = CLV_OK;
@@ -403,11 +658,18 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
         if (xmean) {                       // standardise-on-load needs the register-staged kernel
             hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(WG_THREADS), 0, st, dyp, xp, work, M, (int)N, (int)K,
                                (int)ldy, (int)ldx, tiles, tilesK, rows, db ? 1 : 0, xmean, xrstd);
+        } else if (getenv("CLV_WGRAD_OLD")) {                                       // A/B switch: the first version
+            if (atomic_acc)
+                hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+                                   (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
+            else
+                hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
+                                   M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else if (atomic_acc) {           // few M-slices: accumulate straight into dW / db, no partials, no fold
-            hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+            hipLaunchKernelGGL(wgrad_dma2_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
                                (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
+            hipLaunchKernelGGL(wgrad_dma2_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
                                M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         }
         rc = clv_check_launch();
@@ -416,8 +678,16 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
     if ((stages & 2) && !(atomic_acc && !xmean)) {
         const int64_t NK = (int64_t)N * K, E2 = NK + N;
         const int64_t Eeff = db ? E2 : NK;
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((Eeff + 63) / 64)), dim3(1024), 0, st, work, dw, db, NK,
-                           E2, splits);
+        const int64_t groups = (Eeff + 3) / 4;               // threads needed with one slice-lane
+        if (groups >= (1 << 17) || splits < 8)
+            hipLaunchKernelGGL(fold_partials_kernel<1>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, work, dw,
+                               db, NK, E2, splits);
+        else if (groups >= (1 << 15) || splits < 32)
+            hipLaunchKernelGGL(fold_partials_kernel<4>, dim3((unsigned)((groups + 63) / 64)), dim3(256), 0, st, work, dw,
+                               db, NK, E2, splits);
+        else
+            hipLaunchKernelGGL(fold_partials_kernel<16>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, work, dw,
+                               db, NK, E2, splits);
         rc = clv_check_launch();
     }
     return rc;
