@@ -292,13 +292,13 @@ def main():
             res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, prof_steps)
             # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes (tools/pmc_traffic.sh; counters
             # cannot be read from inside the process), null when no measurement of this kernel is committed
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
             if os.path.exists(pmc):
                 rec = json.load(open(pmc)).get(res['roofline']['kernel'])
                 res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
             # fraction of the dense bf16 MFMA peak the same kernel sustains, from the SQ / GRBM counter pass
-            # (tools/pmc_mfma.sh -> profiles/r01_pmc_mfma.json); null when not measured
-            mf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_mfma.json')
+            # (tools/pmc_mfma.sh -> profiles/r02_pmc_mfma.json); null when not measured
+            mf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_mfma.json')
             if os.path.exists(mf):
                 rec = json.load(open(mf)).get(res['roofline']['kernel'])
                 res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None

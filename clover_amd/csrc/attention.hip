@@ -170,6 +170,8 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
     int* linb_s = row_s + NK;                                // mode 1 + bias: 4 * lin(n)
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);    //                the head's bias table
+    int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);     // "window straddles shift regions"
+    if (tid == 0) *flag_s = 0;
     token_rows<NK>(G, grp, row_s, tid);
     // Q fragments of ALL this wave's query tiles go out before the K / V staging loads: their round trip (~2 us under
     // load) then overlaps the staging instead of stalling every tile of the loop below.  (Long windows keep the
@@ -194,11 +196,20 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
     float* kadd = aux + NK;
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    int differs = 0;
     for (int n = tid; n < NK; n += THREADS) {
-        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        if (MODE == 1 && rid) {
+            const int rv = (n < N) ? rid[wloc * N + n] : 0;
+            rid_s[n] = rv;
+            if (n < N) differs |= rv != rid[wloc * N];
+        }
         kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
     }
+    // a shifted block's windows that lie inside ONE region (all but the last row / column of windows: 49 of 64 at
+    // 56 x 56) need no mask: 12 VALU operations per key tile and query less
+    if (differs) *flag_s = 1;
     __syncthreads();
+    const bool masked = *flag_s != 0;
 
     const int lg = lane >> 4, lr = lane & 15;
     constexpr int UNR = PRE > 1 ? PRE : 1;
@@ -236,9 +247,12 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
             const float4 bv = bnext;
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
-            const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-            float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
-            if (MODE == 1 && rid) {                                   // wave-uniform: shifted block, region-id mask
+            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (MODE == 0 || (t + 1) * 16 > N) {                      // key mask (mode 0) / -inf on the pad keys of the last tiles
+                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+                bb[0] += ka.x; bb[1] += ka.y; bb[2] += ka.z; bb[3] += ka.w;
+            }
+            if (masked) {                                             // workgroup-uniform: window straddles shift regions
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
@@ -334,6 +348,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
     const bool tb = MODE == 1 && bias != nullptr;
+    int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);
+    if (tid == 0) *flag_s = 0;
 
     token_rows<NK>(G, grp, row_s, tid, nthr);
     // q / dO / o fragments of all this wave's query tiles go out before the K / V staging loads (see attn_fwd_kernel)
@@ -355,11 +371,18 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid, nthr);
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    int differs = 0;
     for (int n = tid; n < NK; n += nthr) {
-        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
+        if (MODE == 1 && rid) {
+            const int rv = (n < N) ? rid[wloc * N + n] : 0;
+            rid_s[n] = rv;
+            if (n < N) differs |= rv != rid[wloc * N];
+        }
         kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
     }
+    if (differs) *flag_s = 1;
     __syncthreads();
+    const bool masked = *flag_s != 0;                        // see attn_fwd_kernel
 
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
@@ -408,9 +431,12 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
                 pacc = mfma16(vf[s], dof[s], pacc);
             }
             const int key0 = t * 16 + lg * 4;
-            const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-            float bb[4] = {bv.x + ka.x, bv.y + ka.y, bv.z + ka.z, bv.w + ka.w};
-            if (MODE == 1 && rid) {
+            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            if (MODE == 0 || (t + 1) * 16 > N) {
+                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+                bb[0] += ka.x; bb[1] += ka.y; bb[2] += ka.z; bb[3] += ka.w;
+            }
+            if (masked) {
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
                 bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
                 bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
@@ -481,6 +507,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     int* linb_s = row_s + NK;
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);
     const bool tb = MODE == 1 && bias != nullptr;
+    int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);
+    if (tid == 0) *flag_s = 0;
     token_rows<NK>(G, grp, row_s, tid, nthr);
     // k / v fragments of all this wave's key tiles go out before the Q / dO staging loads (see attn_fwd_kernel)
     constexpr int NWAVES = DKV_THREADS(NKT) / 64;
@@ -501,14 +529,20 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    int differs = 0;
     for (int n = tid; n < NK; n += nthr) {
         const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
         L_s[n] = (n < N) ? -lse[li] * LOG2E : -INFINITY;    // -L * log2e (exp_sub's form); pad queries: P = exp2(-inf) = 0
         D_s[n] = (n < N) ? dsum[li] : 0.f;
-        if (MODE == 1 && rid) rid_s[n] = (n < N) ? rid[wloc * N + n] : 0;
-        else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        if (MODE == 1 && rid) {
+            const int rv = (n < N) ? rid[wloc * N + n] : 0;
+            rid_s[n] = rv;
+            if (n < N) differs |= rv != rid[wloc * N];
+        } else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
     }
+    if (differs) *flag_s = 1;
     __syncthreads();
+    const bool masked = *flag_s != 0;                        // see attn_fwd_kernel
 
     const int lg = lane >> 4, lr = lane & 15;
     const unsigned long long sd = DROP ? *seedp : 0ull;
@@ -559,7 +593,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
                     bv.w = *reinterpret_cast<const float*>(tp + qb.w);
                 }
                 float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-                if (MODE == 1 && rid) {
+                if (masked) {
                     const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
                     bb[0] += (rq4.x != rk) ? -100.0f : 0.0f;
                     bb[1] += (rq4.y != rk) ? -100.0f : 0.0f;
@@ -732,11 +766,11 @@ inline int64_t ds_scratch_bytes(const Geom& G, int nkt) {
 }
 
 template <int HD, int NKT>
-size_t fwd_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
+size_t fwd_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 template <int HD, int NKT>
-size_t dq_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
+size_t dq_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 template <int HD, int NKT>
-size_t dkv_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4; }
+size_t dkv_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 
 // Three compiled variants per (HD, NKT): window (bias/rid, no dropout), sequence, sequence + dropout.
 #define CLV_PICK(KERNEL, ...)                                                                          \

@@ -134,8 +134,8 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         if PROF is None:
             check(L.clv_linear_wgrad(*args, 0, _stream()), 'clv_linear_wgrad')
         else:                                  # one event pair per device kernel
-            slices = work.numel() // (N * K + N)             # <= 24 slices: atomics into dW (gemm_wgrad.hip)
-            kname = 'wgrad_kernel' if xstats else f"wgrad_dma_kernel<{'true' if slices <= 24 else 'false'}>"
+            slices = work.numel() // (N * K + N)             # one slice: atomics straight into dW (gemm_wgrad.hip)
+            kname = 'wgrad_kernel' if xstats else f"wgrad_dma2_kernel<{'true' if slices == 1 else 'false'}>"
             with _Timed(kname, 2 * M * N * K, M * (N + K) * 2):
                 check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
             check(L.clv_linear_wgrad(*args, 2, _stream()), 'clv_linear_wgrad')
