@@ -281,6 +281,201 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-tile-per-workgroup version (probe: CLV_GEMM_TILE=lean): ONE 128 x BN tile per 256-thread workgroup (2 x 2 waves), 64-deep stages in a double
+// buffer, two workgroups per CU.  What the SQ counters showed about the first loops applies here as it did to the
+// weight-gradient kernel: per-piece pointer bookkeeping cost several times the 32 MFMAs of a stage.  So: the loop is
+// unrolled over the two slots (every LDS address = per-lane constant + immediate), the 8 DMA pieces of a stage are one
+// asm block in the SGPR-base + 32-bit-VGPR-offset form (a stage advance = two scalar adds per operand), rows past the
+// edge are clamped.  Dispatch order keeps the N tiles of a row block on one XCD (as above).
+template <int NPIECE>
+__device__ __forceinline__ void gn_dma_block(unsigned lds, const unsigned (&v)[NPIECE], const bf16_t* base);
+template <>
+__device__ __forceinline__ void gn_dma_block<4>(unsigned lds, const unsigned (&v)[4], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [b] "s"(base)
+        : "memory", "scc");
+}
+template <>
+__device__ __forceinline__ void gn_dma_block<2>(unsigned lds, const unsigned (&v)[2], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [b] "s"(base)
+        : "memory", "scc");
+}
+
+template <int BN, int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_nt_lean_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                              const float* __restrict__ bias, const bf16_t* __restrict__ aux,
+                                                              bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N,
+                                                              int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN,
+                                                              int nmblk) {
+    constexpr int BM = 128, WAVES = 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int PA = BM / (8 * WAVES), PB = BN / (8 * WAVES);            // DMA pieces per wave: 4 and 4 (2)
+    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int mblk = xcd + 8 * (xslot / tilesN), tn = xslot % tilesN;
+    if (mblk >= nmblk) return;
+    const int64_t m0 = (int64_t)mblk * BM;
+    const int n0 = tn * BN;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+
+    // per-lane source offsets in bytes from the tile's first row (fixed for the whole K loop); the wave's pieces are
+    // consecutive 1-KiB blocks of the operand's LDS image
+    unsigned va[PA], vb[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int r = (wave * PA + j) * 8 + (lane >> 3);                   // LDS row = global row (A)
+        const int cch = (lane & 7) ^ (r & 7);
+        int64_t gr = m0 + r;
+        gr = gr < M ? gr : M - 1;
+        va[j] = (unsigned)(((gr - m0) * lda + cch * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int r = (wave * PB + j) * 8 + (lane >> 3);                   // LDS row; global row permuted (see gn_init)
+        const int cch = (lane & 7) ^ (r & 7);
+        const int hh = r / WN, p = r % WN, jj = p >> 4, x = p & 15;
+        int g = n0 + hh * WN + (jj >> 1) * 32 + (x >> 2) * 8 + (jj & 1) * 4 + (x & 3);
+        g = g < N ? g : N - 1;
+        vb[j] = (unsigned)(((int64_t)(g - n0) * ldb + cch * 8) * 2);
+    }
+    const bf16_t* abase = a + m0 * lda;                                    // wave-uniform (SGPR pairs), + 64 per stage
+    const bf16_t* bbase = b + (int64_t)n0 * ldb;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0];
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * PA * 1024));
+    const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds0 + A_BYTES + (unsigned)(wave * PB * 1024));
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment addresses inside an operand image: row (w? + t*16 + lr), k chunk ks*4 + lg, XOR (row & 7);
+    // (t*16 + lr) & 7 == lr & 7 and wm, wn are multiples of 8, so one base per k half + immediates t * 2048
+    int fa0[2], fb0[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        fa0[ks] = (wm + lr) * 128 + (((ks * 4 + lg) ^ (lr & 7)) << 4);
+        fb0[ks] = A_BYTES + (wn + lr) * 128 + (((ks * 4 + lg) ^ (lr & 7)) << 4);
+    }
+    auto compute = [&](const unsigned char* st) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag8 fa[TM], fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j].u4 = *reinterpret_cast<const uint4*>(st + fb0[ks] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i].u4 = *reinterpret_cast<const uint4*>(st + fa0[ks] + i * 2048);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+        }
+    };
+#define GNL_ISSUE(SLOT)                                  \
+    gn_dma_block<PA>(lds_a + (SLOT) * STAGE, va, abase); \
+    gn_dma_block<PB>(lds_b + (SLOT) * STAGE, vb, bbase); \
+    abase += GN_BK;                                      \
+    bbase += GN_BK;
+    const int nst = K / GN_BK;
+    GNL_ISSUE(0)
+    int st = 0;
+    for (; st + 2 <= nst; st += 2) {
+        gn_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                     // stage st landed everywhere; slot 1 is drained
+        GNL_ISSUE(1)
+        compute(ring);
+        gn_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nst) { GNL_ISSUE(0) }
+        compute(ring + STAGE);
+    }
+    if (st < nst) {                                       // odd stage count: the last one sits in slot 0
+        gn_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(ring);
+    }
+#undef GNL_ISSUE
+
+    // ---- epilogue from registers (see gemm_nt_kernel): accumulator pair (2h, 2h+1) = 8 consecutive columns
+    const int nl = n0 + wn + lg * 8;
+#pragma unroll
+    for (int h = 0; h < TN / 2; ++h) {
+        const int nh = nl + h * 32;
+        if (nh >= N) continue;
+        float bn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bn[e] = 0.f;
+        if (HAS_BIAS) {                                   // bias as the bf16 operand the library GEMM took
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + nh), b1 = *reinterpret_cast<const float4*>(bias + nh + 4);
+            const float bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bn[e] = bf2f(f2bf(bw[e]));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int64_t m = m0 + wm + i * 16 + lr;
+            if (m >= M) continue;
+            const int64_t g = m * ldc + nh;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bn[e];
+            if (EPI == GN_EPI_GELU) {
+                *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                               pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (EPI == GN_EPI_DGELU) {
+                const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
+                const uint32_t pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((e & 1) ? gn_hi(pv[e >> 1]) : gn_lo(pv[e >> 1]));
+            }
+            *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                          pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
+    }
+}
+
+template <int BN>
+int gn_launch_lean(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias,
+                   const bf16_t* aux, bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                   int tilesN, int nmblk) {
+#define GN_GO(E)                                                                                                       \
+    hipLaunchKernelGGL((gemm_nt_lean_kernel<BN, E>), dim3(grid), dim3(256), 0, st, a, b, bias, aux, c, c2, M, N, K, lda, \
+                       ldb, ldc, tilesN, nmblk)
+    switch (epi) {
+        case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
+        case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
+        case GN_EPI_GELU: GN_GO(GN_EPI_GELU); break;
+        case GN_EPI_DGELU: GN_GO(GN_EPI_DGELU); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef GN_GO
+    return clv_check_launch();
+}
+
 // Batched 2-D transposes of bf16 matrices (the W^T shadows): one 64 x 64 tile per workgroup through LDS, 16-byte
 // accesses on both sides.  Entry e: src [rows][cols] -> dst [cols][rows]; tile_begin = prefix sum of tile counts.
 struct TrEntry {
@@ -366,6 +561,20 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     if (epilogue == GN_EPI_GELU && !c2) return CLV_ERR_ARG;
     if (epilogue == GN_EPI_DGELU && !aux) return CLV_ERR_ARG;
     const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8", "256x128w4"
+    if (force && (!strcmp(force, "lean") || !strcmp(force, "lean64"))) {     // one tile per workgroup (measured 5-15 % behind)
+        // 4 GiB of addressable operand per tile row block (32-bit lane offsets)
+        if ((int64_t)128 * lda * 2 >= (1ll << 31) || (int64_t)128 * ldb * 2 >= (1ll << 31)) return CLV_ERR_UNSUPPORTED;
+        const int BNl = ((force && !strcmp(force, "lean64")) || (N % 128 != 0 && N <= 640)) ? 64 : 128;
+        const int tilesN = (N + BNl - 1) / BNl;
+        const int nmblk = (int)((M + 127) / 128);
+        const unsigned grid = (unsigned)(8 * tilesN * ((nmblk + 7) / 8));
+        hipStream_t st = (hipStream_t)stream;
+        if (BNl == 128)
+            return gn_launch_lean<128>(epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux,
+                                       (bf16_t*)c, (bf16_t*)c2, M, N, K, lda, ldb, ldc, tilesN, nmblk);
+        return gn_launch_lean<64>(epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux,
+                                  (bf16_t*)c, (bf16_t*)c2, M, N, K, lda, ldb, ldc, tilesN, nmblk);
+    }
     int BM = 128, BN = 128, W = 4;
     if (force) {
         BM = atoi(force);

@@ -8,8 +8,8 @@ names = ['qkv s1', 'proj s1', 'fc1 s1', 'fc2 s1', 'merge s1', 'qkv s2', 'proj s2
 out, cur = [], None
 for l in rows:
     med = float(re.search(r'median\s+([\d.]+)', l).group(1))
-    if 'gemm_nt_kernel' in l:
-        epi = int(re.search(r'gemm_nt_kernel<[\d, ]*?(\d)>', l).group(1))
+    if 'gemm_nt_' in l:
+        epi = int(re.search(r'gemm_nt_\w*kernel<[\d, ]*?(\d)>', l).group(1))
         if cur is not None:
             cur[epi] = med
             if epi == 3:
