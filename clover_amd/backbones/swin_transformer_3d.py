@@ -116,8 +116,12 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
+        self.fc1.weight._clv_want_t = self.fc2.weight._clv_want_t = True      # engine keeps W^T for the input gradients
 
     def forward(self, x):
+        if (type(self.act) is GELU and self.drop.p == 0.0 and self.fc1.bias is not None
+                and ops.mlp_gelu_ok(x, self.fc1.out_features)):
+            return ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -141,6 +145,7 @@ class WindowAttention3D(nn.Module):
         self.register_buffer('relative_position_index', build_relative_position_index(window_size))
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = Linear(dim, dim)
+        self.qkv.weight._clv_want_t = self.proj.weight._clv_want_t = True     # engine keeps W^T for the input gradients
         self.proj_drop = nn.Dropout(proj_drop)
         trunc_normal_(self.relative_position_bias_table, std=.02)
 
@@ -250,6 +255,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.dim = dim
         self.reduction = Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction.weight._clv_want_t = True
         self.norm = norm_layer(4 * dim)
 
     @staticmethod

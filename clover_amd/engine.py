@@ -123,6 +123,24 @@ class _Segment:
             p._clv_grad = p.grad                                                   # sink for ops.linear
             p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
         self.shadow.copy_(self.flat_p)
+        # bf16 W^T copies for the Linear weights whose input-gradient GEMM is the K-contiguous HIP kernel
+        # (ops.linear_dgrad): one batched transpose per optimizer step refreshes them all
+        want = [(p, off) for p, off in zip(self.params, self.offsets) if getattr(p, '_clv_want_t', False) and p.dim() == 2]
+        self.shadow_t, self._t_table = None, None
+        if want and self.flat_p.is_cuda:
+            self.shadow_t = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _ in want), device=device, dtype=torch.bfloat16)
+            entries, toff = [], 0
+            for p, off in want:
+                entries.append((off, toff, p.shape[0], p.shape[1]))
+                p._clv_shadow_t = self.shadow_t[toff:toff + p.numel()].view(p.shape[1], p.shape[0])
+                toff += (p.numel() + 7) // 8 * 8
+            self._t_table = ops.transpose_table(entries, device)
+            self.refresh_transposed()
+
+    def refresh_transposed(self):
+        if self._t_table is not None:
+            tab, n, tiles = self._t_table
+            ops.transpose_batch(self.shadow, self.shadow_t, tab, n, tiles)
 
     def fused_view(self, members):
         """One Parameter-like view over `members` (adjacent slots of this slab, equal trailing dims,
@@ -443,6 +461,7 @@ class CloverEngine:
         for seg in self.segments:
             ops.adamw_step_dev(seg.flat_p, seg.flat_g, seg.exp_avg, seg.exp_avg_sq, seg.shadow, self.optim_state,
                                lr * seg.lr_mult, self.betas[0], self.betas[1], self.eps, seg.weight_decay)
+            seg.refresh_transposed()
         for seg in self.segments:
             seg.flat_g.zero_()
         self.last_lr = lr
@@ -474,6 +493,7 @@ class CloverEngine:
         optimizer's back (``load_state_dict`` of a checkpoint: it copies into the slab views in place)."""
         for sg in self.segments:
             sg.shadow.copy_(sg.flat_p)
+            sg.refresh_transposed()
 
     def grad_norm(self):
         """Global gradient norm of the last step's (averaged) gradients — host sync, logging only."""

@@ -5,6 +5,8 @@ are what the registered nn.Modules call.  No CPU path exists: a non-HIP tensor r
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -160,13 +162,37 @@ def _rowgemm_fwd_ok(x, N, K):
     return x.is_cuda and K <= 128 and x.stride(-1) == 1 and rowgemm_supported(N, K)
 
 
-def linear_dgrad(dy2, wb):
-    """dx [M,K] = dy [M,N] . W [N,K]: as a row-streaming GEMM over the contraction N when that is
-    short (<= 288) or the output is narrow (K <= 128); the library GEMM otherwise."""
+def own_gemm_ok(a, N, K):
+    """Shapes on which clv_gemm_nt beats the tuned library GEMM (device-side durations, tools/probes/gemm_bench.py under
+    rocprofv3 --kernel-trace): token-parallel layers with a short contraction — Swin stages 1-2 (M = 12 544 .. 50 176,
+    K <= 576); long contractions with few tiles (stage 3, fusion, BERT) stay with the library."""
+    M = a.shape[0]
+    return (os.environ.get('CLOVER_OWN_GEMM', '1') == '1' and a.is_cuda and a.dtype == BF16 and M >= 8192
+            and 64 <= K <= 576 and K % 64 == 0 and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1
+            and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
+
+
+def _wt(weight, wb):
+    """bf16 W^T [K,N]: the engine's transposed shadow (refreshed once per step) or a transpose on the spot."""
+    wt = getattr(weight, '_clv_shadow_t', None) if weight is not None else None
+    return wt if wt is not None else wb.t().contiguous()
+
+
+def linear_dgrad(dy2, wb, weight=None, pre=None):
+    """dx [M,K] = dy [M,N] . W [N,K] (pre: times GELU'(pre), the fc2 input gradient of an MLP): as a row-streaming GEMM
+    over the contraction N when that is short (<= 288) or the output is narrow (K <= 128); the LDS-tiled HIP GEMM with
+    W^T as its K-contiguous B operand where that wins (own_gemm_ok); the library GEMM otherwise."""
     N, K = wb.shape
-    if dy2.is_cuda and (N <= 288 or K <= 128 and N <= 384) and rowgemm_supported(K, N) and dy2.stride(1) == 1:
-        return rowgemm(dy2, wb.t().contiguous(), None)['y']
-    return torch.mm(dy2, wb)
+    if pre is None and dy2.is_cuda and (N <= 288 or K <= 128 and N <= 384) and rowgemm_supported(K, N) and dy2.stride(1) == 1:
+        return rowgemm(dy2, _wt(weight, wb), None)['y']
+    if own_gemm_ok(dy2, K, N):
+        return gemm_nt(dy2, _wt(weight, wb), aux=pre, epilogue=GEMM_EPI_DGELU if pre is not None else GEMM_EPI_NONE)
+    dx = torch.mm(dy2, wb)
+    if pre is not None:
+        out = torch.empty_like(dx)
+        check(_lib.lib().clv_gelu_bwd(_ptr(dx), _ptr(pre), _ptr(out), dx.numel(), 0, _stream()), 'clv_gelu_bwd')
+        return out
+    return dx
 
 
 def _sink_or_return(param, grad):
@@ -203,9 +229,13 @@ class _Linear(torch.autograd.Function):
             if bb is None:
                 bb = bias.to(BF16)
         N, K = wb.shape
+        x2 = xb.reshape(-1, K)
         if _rowgemm_fwd_ok(xb, N, K):
             bf = bias if bias is not None and bias.dtype == torch.float32 else (bias.float() if bias is not None else None)
-            y = rowgemm(xb.reshape(-1, K), wb, bf)['y'].view(xb.shape[:-1] + (N,))
+            y = rowgemm(x2, wb, bf)['y'].view(xb.shape[:-1] + (N,))
+        elif own_gemm_ok(x2, N, K):
+            y = gemm_nt(x2, wb, bias.detach() if bias is not None else None,
+                        epilogue=GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE).view(xb.shape[:-1] + (N,))
         else:
             y = torch.nn.functional.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
@@ -223,7 +253,7 @@ class _Linear(torch.autograd.Function):
             dy2 = dy2.to(BF16)
         dy2 = _c(dy2)
         x2 = _c(xb.reshape(-1, K))
-        dx = linear_dgrad(dy2, wb).view(xb.shape) if ctx.needs_input_grad[0] else None
+        dx = linear_dgrad(dy2, wb, ctx.wref).view(xb.shape) if ctx.needs_input_grad[0] else None
         dw, db = (None, None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             wsink = getattr(ctx.wref, '_clv_grad', None)
@@ -428,6 +458,70 @@ def fused_block_supported(C_, hidden):
 
 def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
+
+
+def _param_grads(dy2, x2, weight, bias):
+    """dW / db of one Linear into the engine's slab views (-> None, None) or returned to autograd."""
+    wsink = getattr(weight, '_clv_grad', None)
+    bsink = getattr(bias, '_clv_grad', None) if bias is not None else None
+    if wsink is not None and (bsink is not None or bias is None):
+        linear_wgrad(dy2, x2, bias is not None, wsink, bsink)
+        weight._clv_ready()
+        if bias is not None:
+            bias._clv_ready()
+        return None, None
+    dw, db = linear_wgrad(dy2, x2, bias is not None)
+    return dw.to(weight.dtype), (db.to(bias.dtype) if db is not None else None)
+
+
+class _MlpGelu(torch.autograd.Function):
+    """out = fc2(GELU(fc1(x))) (Mlp.forward, swin_transformer_3d.py:262-268, no dropout) with the activation inside the
+    GEMMs: fc1 = clv_gemm_nt with the bias + GELU epilogue (pre-activation kept for backward), fc2's input gradient =
+    clv_gemm_nt with the GELU-backward epilogue — the two standalone GELU passes over the [M, 4C] tensor are gone."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        w1b = getattr(w1, '_clv_shadow', None)
+        w1b = w1b if w1b is not None else w1.to(BF16)
+        w2b = getattr(w2, '_clv_shadow', None)
+        w2b = w2b if w2b is not None else w2.to(BF16)
+        act, pre = gemm_nt(x2, w1b, b1.detach(), epilogue=GEMM_EPI_BIAS_GELU)
+        Hd, C_ = w1b.shape[0], w2b.shape[0]
+        if own_gemm_ok(act, C_, Hd):
+            out = gemm_nt(act, w2b, b2.detach() if b2 is not None else None,
+                          epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
+        else:
+            b2b = getattr(b2, '_clv_shadow', None) if b2 is not None else None
+            out = torch.nn.functional.linear(act, w2b, b2b if b2b is not None or b2 is None else b2.to(BF16))
+        ctx.save_for_backward(x2, pre, act, w1b, w2b)
+        ctx.refs = (w1, b1, w2, b2)
+        ctx.xshape = x.shape
+        return out.view(x.shape[:-1] + (C_,))
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, pre, act, w1b, w2b = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.refs
+        do2 = _c(dout.reshape(-1, w2b.shape[0]))
+        if do2.dtype != BF16:
+            do2 = do2.to(BF16)
+        dpre = linear_dgrad(do2, w2b, w2, pre=pre)           # (d out . W2) * GELU'(pre)
+        dw2, db2 = _param_grads(do2, act, w2, b2)
+        dx = linear_dgrad(dpre, w1b, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1, db1 = _param_grads(dpre, x2, w1, b1)
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp_gelu_ok(x, hidden):
+    """The fused-activation MLP is used where its fc1 GEMM (contraction C, 4C outputs) is one of clv_gemm_nt's shapes."""
+    x2 = x.reshape(-1, x.shape[-1])
+    return x.is_cuda and x.dtype == BF16 and own_gemm_ok(x2, hidden, x.shape[-1])
+
+
+def mlp_gelu(x, w1, b1, w2, b2):
+    return _MlpGelu.apply(x, w1, b1, w2, b2)
 
 
 # --------------------------------------------------------------------------- LDS-tiled GEMM with fused epilogues

@@ -85,6 +85,32 @@ def test_engine_lr_mult_and_fractional_decay_match_torch_param_groups():
         assert ref <= 3.3 * 1e-3 * o[n][1] + 1e-7, (n, ref, o[n])
 
 
+def test_transposed_weight_shadows_follow_the_optimizer():
+    """The engine keeps bf16 W^T copies of the Linear weights whose input gradient runs on clv_gemm_nt; they must equal
+    the transposed bf16 shadow after construction, after every optimizer step and after a checkpoint load."""
+    from clover_amd.engine import CloverEngine
+    b = batch(tag='wt')
+    eng = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=100)
+    flagged = [p for sg in eng.segments for p in sg.params if getattr(p, '_clv_want_t', False)]
+    assert flagged and all(hasattr(p, '_clv_shadow_t') for p in flagged)
+
+    def check():
+        for p in flagged:
+            assert p._clv_shadow_t.shape == (p.shape[1], p.shape[0])
+            assert torch.equal(p._clv_shadow_t, p._clv_shadow.t().contiguous())
+            assert torch.equal(p._clv_shadow, p.data.to(torch.bfloat16))
+    check()
+    w0 = flagged[0]._clv_shadow_t.clone()
+    eng.step(b)
+    check()
+    assert not torch.equal(w0, flagged[0]._clv_shadow_t)
+    with torch.no_grad():
+        for p in flagged:
+            p.mul_(0.5)
+    eng.refresh_shadow()
+    check()
+
+
 def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():
     """A non-finite gradient norm skips the update on the device and does not advance Adam's step count (the
     reference skips optimizer.step(), mmcv_Fp16OptimizerHook.py:123-141) while the LR index moves on; dry_step —

@@ -448,6 +448,43 @@ def test_gemm_nt_epilogues(M, N, K):
     assert torch.equal(c4, c0)
 
 
+@pytest.mark.parametrize('M,C,Hd', [(8192, 192, 768), (12544, 384, 1536), (9000, 128, 512)])
+def test_linear_and_mlp_on_the_hip_gemm(M, C, Hd):
+    """ops.linear / ops.mlp_gelu on shapes that take clv_gemm_nt (own_gemm_ok): forward, input gradient (through the
+    transposed-weight operand) and parameter gradients against fp32 torch on the same bf16 operands."""
+    F_ = torch.nn.functional
+    x = rnd(M, C, seed=321).to(BF)
+    w1, b1 = rnd(Hd, C, scale=0.05, seed=322), rnd(Hd, scale=0.1, seed=323)
+    w2, b2 = rnd(C, Hd, scale=0.05, seed=324), rnd(C, scale=0.1, seed=325)
+    dy = rnd(M, C, seed=326).to(BF)
+    xr = x.float().requires_grad_()
+    pr = [t.clone().requires_grad_() for t in (w1, b1, w2, b2)]
+    h = F_.linear(xr, pr[0].to(BF).float(), pr[1])
+    yr = F_.linear(F_.gelu(h).to(BF).float(), pr[2].to(BF).float(), pr[3])
+    yr.backward(dy.float())
+    xg = x.to(DEV).requires_grad_()
+    pg = [t.to(DEV).requires_grad_() for t in (w1, b1, w2, b2)]
+    assert ops().mlp_gelu_ok(xg, Hd)
+    yg = ops().mlp_gelu(xg, *pg)
+    yg.backward(dy.to(DEV))
+    assert rel(yg, yr) < 1.5e-2
+    assert rel(xg.grad, xr.grad) < 2e-2
+    for a, r in zip(pg, pr):
+        assert rel(a.grad, r.grad) < 2e-2
+    # a plain Linear on the same kernel (bias epilogue; dgrad with W^T)
+    xg2 = x.to(DEV).requires_grad_()
+    wg, bg = w1.to(DEV).requires_grad_(), b1.to(DEV).requires_grad_()
+    assert ops().own_gemm_ok(xg2, Hd, C)
+    y2 = ops().linear(xg2, wg, bg)
+    d2 = rnd(M, Hd, seed=327).to(BF)
+    y2.backward(d2.to(DEV))
+    xr2 = x.float().requires_grad_()
+    wr, br = w1.clone().requires_grad_(), b1.clone().requires_grad_()
+    F_.linear(xr2, wr.to(BF).float(), br).backward(d2.float())
+    assert rel(y2, F_.linear(x.float(), w1.to(BF).float(), b1)) < 1e-2
+    assert rel(xg2.grad, xr2.grad) < 2e-2 and rel(wg.grad, wr.grad) < 2e-2 and rel(bg.grad, br.grad) < 2e-2
+
+
 def test_transpose_batch():
     shapes = [(384, 1536), (96, 288), (100, 72), (64, 64), (30522 // 6, 768), (7, 5)]
     src = torch.zeros(sum(r * c for r, c in shapes) + 64, dtype=BF)
