@@ -49,8 +49,8 @@ __device__ __forceinline__ int win_lin(const Geom& G, int n) {
 // Per-workgroup bias state in LDS (mode 1): the head's table and 4 * lin(n) per window token (byte offsets).
 template <int NK>
 __device__ __forceinline__ void load_bias_table(const Geom& G, const float* table, int h, float* tab_s, int* linb_s,
-                                                int tid, int nthreads) {
-    for (int i = tid; i < G.tlen; i += nthreads) tab_s[i] = table[(int64_t)i * G.g.nH + h];   // [tlen][nH] parameter layout
+                                                int tid, int nthreads, float mul = 1.f) {
+    for (int i = tid; i < G.tlen; i += nthreads) tab_s[i] = table[(int64_t)i * G.g.nH + h] * mul;   // [tlen][nH] parameter layout
     for (int n = tid; n < NK; n += nthreads) linb_s[n] = (n < G.g.N) ? 4 * win_lin(G, n) : 0;
 }
 
@@ -109,14 +109,20 @@ __device__ __forceinline__ void lds_frags(Frag8 (&f)[(HD + 31) / 32], const bf16
 // Stage `N` rows (tensor rows row_s[n]) of a [tokens][ld] bf16 matrix (cols h*HD .. +HD) row-major into
 // LDS rm[NK][HD+8]; pad rows are zeroed.  Transposed operands are NOT materialised: they are read
 // with the gfx950 LDS transpose read (tr4 below).
-template <int HD, int NK>
+template <int HD, int NK, bool SCALE = false>
 __device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int ld, int h, int N, bf16_t* rm, int tid,
-                                      int nthr = THREADS) {
+                                      int nthr = THREADS, float mul = 1.f) {
     constexpr int CH = HD / 8, LDR = HD + 8;
     for (int idx = tid; idx < NK * CH; idx += nthr) {
         const int n = idx / CH, c = idx - n * CH;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (n < N) val = *reinterpret_cast<const uint4*>(base + (int64_t)row_s[n] * ld + h * HD + c * 8);
+        if (SCALE) {                 // fold softmax scale * log2(e) into the staged operand: the scores leave the MFMA ready for exp2
+            uint32_t* w = reinterpret_cast<uint32_t*>(&val);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = pack2bf(__uint_as_float(w[e] << 16) * mul, __uint_as_float(w[e] & 0xffff0000u) * mul);
+        }
         *reinterpret_cast<uint4*>(rm + n * LDR + c * 8) = val;
     }
 }
@@ -188,12 +194,14 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             load_frags<HD>(qpre[ti], q + (int64_t)row_s[qv ? nq : 0] * G.g.ldq + h * HD, qv, lane);
         }
     }
-    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid);
+    // K is staged as K * scale * log2(e) and every additive term (bias table, key mask, region mask) is kept in log2
+    // units: the MFMA, started from the additive terms as its accumulator, delivers the exp2-ready score — one VALU
+    // operation per score less than scale-and-add after the MFMA.
+    stage<HD, NK, true>(row_s, k, G.g.ldk, h, N, Ks, tid, THREADS, G.g.scale * LOG2E);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
-    if (MODE == 1 && bias) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS);
+    if (MODE == 1 && bias) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS, LOG2E);
     int* rid_s = reinterpret_cast<int*>(aux);
     // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
-    // Adding it costs one VALU op per score; testing `key < N` per element costs two v_cndmask plus mask traffic.
     float* kadd = aux + NK;
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     int differs = 0;
@@ -203,7 +211,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
         }
-        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
+        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f) : -INFINITY;
     }
     // a shifted block's windows that lie inside ONE region (all but the last row / column of windows: 49 of 64 at
     // 56 x 56) need no mask: 12 VALU operations per key tile and query less
@@ -212,6 +220,8 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     const bool masked = *flag_s != 0;
 
     const int lg = lane >> 4, lr = lane & 15;
+    Frag8 onesf;
+    onesf.u[0] = onesf.u[1] = onesf.u[2] = onesf.u[3] = 0x3f803f80u;      // bf16 1.0 pairs
     constexpr int UNR = PRE > 1 ? PRE : 1;
 #pragma unroll UNR
     for (int ti = 0; ti < (NKT + WAVES - 1) / WAVES; ++ti) {
@@ -238,49 +248,44 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
             Frag8 kf[KS];
             lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
             const int key0 = t * 16 + lg * 4;
             asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
             const float4 bv = bnext;
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
-            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            f32x4_t acc = {bv.x, bv.y, bv.z, bv.w};                   // additive terms first, the MFMA adds q.k on top
             if (MODE == 0 || (t + 1) * 16 > N) {                      // key mask (mode 0) / -inf on the pad keys of the last tiles
                 const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-                bb[0] += ka.x; bb[1] += ka.y; bb[2] += ka.z; bb[3] += ka.w;
+                acc[0] += ka.x; acc[1] += ka.y; acc[2] += ka.z; acc[3] += ka.w;
             }
             if (masked) {                                             // workgroup-uniform: window straddles shift regions
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
-                bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
-                bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
-                bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
-                bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
+                acc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
+                acc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
+                acc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
+                acc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
             }
 #pragma unroll
+            for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = fmaf(acc[r], G.g.scale, bb[r]);
-                p[t][r] = s;
-                m = fmaxf(m, s);
+                p[t][r] = acc[r];
+                m = fmaxf(m, acc[r]);
             }
         }
-        m = grp4_max(m);
-        const float nm2 = -m * LOG2E;
+        m = grp4_max(m);                                     // log2 units
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp_sub(p[t][r], nm2);
+                const float e = __builtin_amdgcn_exp2f(p[t][r] - m);
                 p[t][r] = e;
-                sum += e;
+                if (DROP) sum += e;
             }
-        sum = grp4_sum(sum);
-        if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = m + __logf(sum);
-        const float inv = 1.0f / sum;
         if (DROP) {                                        // dropout on the probabilities (after softmax)
+            sum = grp4_sum(sum);
             const unsigned long long sd = *seedp;
             const unsigned rowid = (unsigned)((grp * G.g.nH + h) * N + nq);
 #pragma unroll
@@ -291,6 +296,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
         }
 
         f32x4_t oacc[NC];
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};                 // row sums of P from the matrix pipe (all-ones "V" block)
 #pragma unroll
         for (int c = 0; c < NC; ++c) oacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -307,7 +313,13 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
                 vf.u2[1] = tr4(Vs, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
                 oacc[c] = mfma16(vf, pf, oacc[c]);
             }
+            // without dropout the softmax denominator is the sum of the SAME bf16 probabilities the P.V product uses:
+            // seven idle-pipe MFMAs instead of 56 adds and two shuffles per query tile
+            if (!DROP) sacc = mfma16(onesf, pf, sacc);
         }
+        if (!DROP) sum = sacc[0];
+        if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = (m + __log2f(sum)) * (1.0f / LOG2E);
+        const float inv = 1.0f / sum;
         if (qv) {
             bf16_t* orow = o + qrow * G.g.ldo + h * HD + lg * 4;
 #pragma unroll
@@ -367,9 +379,11 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
         load_frags<HD>(dopre[ti], dout + qrow * G.g.ldo + h * HD, qv, lane);
         load_frags<HD>(opre[ti], o + qrow * G.g.ldo + h * HD, qv, lane);
     }
-    stage<HD, NK>(row_s, k, G.g.ldk, h, N, Ks, tid, nthr);
+    // K staged as K * scale * log2(e), additive terms in log2 units, MFMA started from them (see attn_fwd_kernel);
+    // dQ = dS . K * scale then is (dS . K') / log2(e)
+    stage<HD, NK, true>(row_s, k, G.g.ldk, h, N, Ks, tid, nthr, G.g.scale * LOG2E);
     stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid, nthr);
-    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr, LOG2E);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     int differs = 0;
     for (int n = tid; n < NK; n += nthr) {
@@ -378,7 +392,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
         }
-        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f) : -INFINITY;
+        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f) : -INFINITY;
     }
     if (differs) *flag_s = 1;
     __syncthreads();
@@ -421,7 +435,19 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
             asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
             const float4 bv = bnext;
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
-            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
+            const int key0 = t * 16 + lg * 4;
+            if (MODE == 0 || (t + 1) * 16 > N) {
+                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+                sacc[0] += ka.x; sacc[1] += ka.y; sacc[2] += ka.z; sacc[3] += ka.w;
+            }
+            if (masked) {
+                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
+                sacc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
+                sacc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
+                sacc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
+                sacc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
+            }
             Frag8 kf[KS], vf[KS];
             lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
             lds_frags<HD>(vf, Vs + (t * 16 + lr) * LDR, lane);
@@ -430,23 +456,10 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
                 sacc = mfma16(kf[s], qf[s], sacc);
                 pacc = mfma16(vf[s], dof[s], pacc);
             }
-            const int key0 = t * 16 + lg * 4;
-            float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-            if (MODE == 0 || (t + 1) * 16 > N) {
-                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-                bb[0] += ka.x; bb[1] += ka.y; bb[2] += ka.z; bb[3] += ka.w;
-            }
-            if (masked) {
-                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
-                bb[0] += (rk.x != rq) ? -100.0f : 0.0f;
-                bb[1] += (rk.y != rq) ? -100.0f : 0.0f;
-                bb[2] += (rk.z != rq) ? -100.0f : 0.0f;
-                bb[3] += (rk.w != rq) ? -100.0f : 0.0f;
-            }
             float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = exp_sub(fmaf(sacc[r], G.g.scale, bb[r]), nL2);    // pad keys: exp2(-inf) = 0
+                const float pr = __builtin_amdgcn_exp2f(sacc[r] + nL2);           // pad keys: exp2(-inf) = 0
                 float dp = pacc[r];
                 if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
                 ds[r] = pr * (dp - dsm);
@@ -474,8 +487,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 uint2 w;
-                w.x = pack2bf(qacc[c][0] * G.g.scale, qacc[c][1] * G.g.scale);
-                w.y = pack2bf(qacc[c][2] * G.g.scale, qacc[c][3] * G.g.scale);
+                w.x = pack2bf(qacc[c][0] * (1.0f / LOG2E), qacc[c][1] * (1.0f / LOG2E));
+                w.y = pack2bf(qacc[c][2] * (1.0f / LOG2E), qacc[c][3] * (1.0f / LOG2E));
                 *reinterpret_cast<uint2*>(drow + c * 16) = w;
             }
         }
@@ -524,9 +537,11 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
         load_frags<HD>(kpre[ti], k + krow * G.g.ldk + h * HD, kv, lane);
         load_frags<HD>(vpre[ti], v + krow * G.g.ldv + h * HD, kv, lane);
     }
-    stage<HD, NK>(row_s, q, G.g.ldq, h, N, Qs, tid, nthr);
+    // Q staged as Q * scale * log2(e), additive terms in log2 units, MFMA started from them (see attn_fwd_kernel);
+    // dK = dS^T . Q * scale then is (dS^T . Q') / log2(e)
+    stage<HD, NK, true>(row_s, q, G.g.ldq, h, N, Qs, tid, nthr, G.g.scale * LOG2E);
     stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid, nthr);
-    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr);
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr, LOG2E);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     int differs = 0;
@@ -538,7 +553,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
             const int rv = (n < N) ? rid[wloc * N + n] : 0;
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
-        } else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] : 0.f;
+        } else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f;
     }
     if (differs) *flag_s = 1;
     __syncthreads();
@@ -572,15 +587,6 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = qp * 2 + half;
-                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
-                Frag8 qf[KS], dof[KS];
-                lds_frags<HD>(qf, Qs + (qt * 16 + lr) * LDR, lane);
-                lds_frags<HD>(dof, dOs + (qt * 16 + lr) * LDR, lane);
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    sacc = mfma16(qf[s], kf[s], sacc);     // S[query (lg*4+r)][key lr]
-                    pacc = mfma16(dof[s], vf[s], pacc);    // dP same layout
-                }
                 float pv[4], dsv[4];
                 const int qn0 = qt * 16 + lg * 4;
                 float4 bv = make_float4(kmv, kmv, kmv, kmv);
@@ -592,13 +598,21 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
                     bv.z = *reinterpret_cast<const float*>(tp + qb.z);
                     bv.w = *reinterpret_cast<const float*>(tp + qb.w);
                 }
-                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
                 if (masked) {
                     const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
-                    bb[0] += (rq4.x != rk) ? -100.0f : 0.0f;
-                    bb[1] += (rq4.y != rk) ? -100.0f : 0.0f;
-                    bb[2] += (rq4.z != rk) ? -100.0f : 0.0f;
-                    bb[3] += (rq4.w != rk) ? -100.0f : 0.0f;
+                    sacc[0] += (rq4.x != rk) ? -100.0f * LOG2E : 0.0f;
+                    sacc[1] += (rq4.y != rk) ? -100.0f * LOG2E : 0.0f;
+                    sacc[2] += (rq4.z != rk) ? -100.0f * LOG2E : 0.0f;
+                    sacc[3] += (rq4.w != rk) ? -100.0f * LOG2E : 0.0f;
+                }
+                Frag8 qf[KS], dof[KS];
+                lds_frags<HD>(qf, Qs + (qt * 16 + lr) * LDR, lane);
+                lds_frags<HD>(dof, dOs + (qt * 16 + lr) * LDR, lane);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    sacc = mfma16(qf[s], kf[s], sacc);     // S[query (lg*4+r)][key lr], log2 units
+                    pacc = mfma16(dof[s], vf[s], pacc);    // dP same layout
                 }
                 const float4 L4 = *reinterpret_cast<const float4*>(L_s + qn0);
                 const float4 D4 = *reinterpret_cast<const float4*>(D_s + qn0);
@@ -607,7 +621,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
                 for (int r = 0; r < 4; ++r) {
                     // pad queries carry L = -inf (P = 0); pad-key lanes compute finite garbage in output columns
                     // that are never stored, so neither needs a select here
-                    const float pr = exp_sub(fmaf(sacc[r], G.g.scale, bb[r]), Lr[r]);
+                    const float pr = __builtin_amdgcn_exp2f(sacc[r] + Lr[r]);
                     float ks = 1.f;
                     if (DROP)
                         ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + qn0 + r), (unsigned)nk, G.drop_thresh,
@@ -640,8 +654,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
                 w.x = pack2bf(dvacc[c][0], dvacc[c][1]);
                 w.y = pack2bf(dvacc[c][2], dvacc[c][3]);
                 *reinterpret_cast<uint2*>(dvrow + c * 16) = w;
-                w.x = pack2bf(dkacc[c][0] * G.g.scale, dkacc[c][1] * G.g.scale);
-                w.y = pack2bf(dkacc[c][2] * G.g.scale, dkacc[c][3] * G.g.scale);
+                w.x = pack2bf(dkacc[c][0] * (1.0f / LOG2E), dkacc[c][1] * (1.0f / LOG2E));
+                w.y = pack2bf(dkacc[c][2] * (1.0f / LOG2E), dkacc[c][3] * (1.0f / LOG2E));
                 *reinterpret_cast<uint2*>(dkrow + c * 16) = w;
             }
         }
