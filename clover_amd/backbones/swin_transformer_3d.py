@@ -116,7 +116,8 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
-        self.fc1.weight._clv_want_t = self.fc2.weight._clv_want_t = True      # engine keeps W^T for the input gradients
+        for lin in (self.fc1, self.fc2):                 # engine keeps W^T where the input gradient's kernel takes it
+            lin.weight._clv_want_t = ops.wants_transposed(lin.out_features, lin.in_features)
 
     def forward(self, x):
         if (type(self.act) is GELU and self.drop.p == 0.0 and self.fc1.bias is not None
@@ -145,7 +146,8 @@ class WindowAttention3D(nn.Module):
         self.register_buffer('relative_position_index', build_relative_position_index(window_size))
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = Linear(dim, dim)
-        self.qkv.weight._clv_want_t = self.proj.weight._clv_want_t = True     # engine keeps W^T for the input gradients
+        for lin in (self.qkv, self.proj):                # engine keeps W^T where the input gradient's kernel takes it
+            lin.weight._clv_want_t = ops.wants_transposed(lin.out_features, lin.in_features)
         self.proj_drop = nn.Dropout(proj_drop)
         trunc_normal_(self.relative_position_bias_table, std=.02)
 
@@ -255,7 +257,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.dim = dim
         self.reduction = Linear(4 * dim, 2 * dim, bias=False)
-        self.reduction.weight._clv_want_t = True
+        self.reduction.weight._clv_want_t = ops.wants_transposed(2 * dim, 4 * dim)
         self.norm = norm_layer(4 * dim)
 
     @staticmethod

@@ -172,6 +172,13 @@ def own_gemm_ok(a, N, K):
             and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
 
 
+def wants_transposed(out_features, in_features):
+    """Does the input gradient of a Linear(in, out) run on a kernel that takes W^T as a K-contiguous operand
+    (linear_dgrad: the row-streaming GEMM of the stage-0 widths, clv_gemm_nt for contractions <= 576)?  Modules flag
+    such weights (``_clv_want_t``) and the engine keeps their bf16 transposes fresh."""
+    return out_features <= 576 or (in_features <= 128 and out_features <= 384)
+
+
 def _wt(weight, wb):
     """bf16 W^T [K,N]: the engine's transposed shadow (refreshed once per step) or a transpose on the spot."""
     wt = getattr(weight, '_clv_shadow_t', None) if weight is not None else None
@@ -553,7 +560,7 @@ def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
     else:
         nout = 2 if epilogue == GEMM_EPI_BIAS_GELU else 1
         nin = 1 if epilogue == GEMM_EPI_DGELU else 0
-        with _Timed(f'gemm_nt_kernel<{128 if (N % 128 == 0 or N > 640) else 64}, {int(epilogue)}>', 2 * M * N * K,
+        with _Timed(f'gemm_nt_kernel<128, 128, 2, 2, 2, {int(epilogue)}>', 2 * M * N * K,
                     (M * K + N * K + (nout + nin) * M * N) * 2):
             check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
     return (c, c2) if epilogue == GEMM_EPI_BIAS_GELU else c
