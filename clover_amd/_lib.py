@@ -25,6 +25,14 @@ class ClvAttnGeom(C.Structure):
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
+class ClvFoldEntry(C.Structure):
+    _fields_ = [('partial', _p), ('dw', _p), ('db', _p), ('nk', _i64), ('e2', _i64), ('splits', _i32),
+                ('sg_shift', _i32), ('block_begin', _i32), ('pad', _i32)]
+
+
+FOLD_MAX = 64
+
+
 class ClvLnExtra(C.Structure):
     """Mirror of ``struct ClvLnExtra`` (include/clover_hip.h)."""
     _fields_ = [('xscale', _p), ('rows_per_sample', _i32), ('drop_p', _f), ('seed', _p), ('dy2', _p), ('dres', _p),
@@ -67,6 +75,8 @@ SIGNATURES = {
     'clv_gemm_nt_supported': (C.c_int, [_i64, _i32, _i32]),
     'clv_gemm_nt': (C.c_int, [_p] * 6 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p]),
     'clv_transpose_batch': (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    'clv_linear_wgrad_splits': (C.c_int, [_i64, _i32, _i32]),
+    'clv_wgrad_fold_batch': (C.c_int, [_p, _i32, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),
     'clv_adamw_step_dev': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
 }

@@ -577,6 +577,63 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restr
     *reinterpret_cast<float4*>(dst) = o;
 }
 
+// Batched fold: the partials of up to CLV_FOLD_MAX weight-gradient launches are folded into their dW / db in ONE launch
+// (the table travels as a kernel argument) — a backward pass otherwise pays ~44 launch-bound 5-7 us fold kernels.
+// Block = 256 threads = EG element groups (of 4 floats) x SG slice-lanes, SG = 1 << sg_shift per entry.
+struct FoldTable {
+    ClvFoldEntry e[CLV_FOLD_MAX];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) fold_batch_kernel(FoldTable tab) {
+    __shared__ float4 sh[256];
+    int idx = 0;
+    for (int i = 1; i < tab.n; ++i)
+        if ((int)blockIdx.x >= tab.e[i].block_begin) idx = i;
+    const ClvFoldEntry& en = tab.e[idx];
+    const float* partial = static_cast<const float*>(en.partial);
+    float* dw = static_cast<float*>(en.dw);
+    float* db = static_cast<float*>(en.db);
+    const int sg_shift = en.sg_shift, SG = 1 << sg_shift, EG = 256 >> sg_shift;
+    const int el = threadIdx.x & (EG - 1), sg = threadIdx.x >> (8 - sg_shift);
+    const int64_t e = ((int64_t)(blockIdx.x - en.block_begin) * EG + el) * 4;
+    const int64_t NK = en.nk, E2 = en.e2, Eeff = db ? E2 : NK;
+    const int splits = en.splits;
+    const bool in = e < Eeff;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+        int sp = sg;
+        for (; sp + 3 * SG < splits; sp += 4 * SG) {
+            const float4 v0 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 0 * SG) * E2 + e);
+            const float4 v1 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 1 * SG) * E2 + e);
+            const float4 v2 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 2 * SG) * E2 + e);
+            const float4 v3 = *reinterpret_cast<const float4*>(partial + (int64_t)(sp + 3 * SG) * E2 + e);
+            a.x += (v0.x + v1.x) + (v2.x + v3.x);
+            a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z);
+            a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < splits; sp += SG) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)sp * E2 + e);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    if (SG > 1) {                                             // block-uniform
+        sh[threadIdx.x] = a;
+        __syncthreads();
+        if (sg != 0) return;
+        for (int k = 1; k < SG; ++k) {
+            const float4 v = sh[k * EG + el];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    if (!in) return;
+    float* dst = e < NK ? dw + e : db + (e - NK);
+    float4 o = *reinterpret_cast<const float4*>(dst);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(dst) = o;
+}
+
 // db[n] += sum_m dy[m][n] for the library-GEMM layers (M of a few hundred..thousand rows): block = 64
 // columns (8 lanes x 16 B) x 32 row-lanes, rows additionally split over blockIdx.y; LDS tree + atomics.
 __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int64_t M,
@@ -702,5 +759,29 @@ extern "C" int clv_colsum(const void* dy, float* db, int64_t M, int32_t N, int32
     if (ys < 1) ys = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3(xb, (unsigned)ys), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, db,
                        M, (int)N, (int)ld);
+    return clv_check_launch();
+}
+
+extern "C" int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K) {
+    const int tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
+    return pick_splits(M, tiles);
+}
+
+extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream) {
+    if (!entries || n <= 0 || n > CLV_FOLD_MAX) return CLV_ERR_ARG;
+    static_assert(sizeof(ClvFoldEntry) == 56, "ClvFoldEntry layout is part of the ABI");
+    FoldTable tab;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ClvFoldEntry en = entries[i];
+        if (!en.partial || !en.dw || en.splits <= 0 || (en.nk & 3) || ((en.e2 - en.nk) & 3)) return CLV_ERR_ARG;
+        const int64_t groups = ((en.db ? en.e2 : en.nk) + 3) / 4;
+        en.sg_shift = (groups >= (1 << 17) || en.splits < 8) ? 0 : (groups >= (1 << 15) || en.splits < 32) ? 2 : 4;
+        en.block_begin = blocks;
+        blocks += (int)((groups + (256 >> en.sg_shift) - 1) / (256 >> en.sg_shift));
+        tab.e[i] = en;
+    }
+    tab.n = n;
+    hipLaunchKernelGGL(fold_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
     return clv_check_launch();
 }

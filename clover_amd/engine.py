@@ -266,7 +266,7 @@ class CloverEngine:
         gradient reducer's hook calibration and leaves weights, Adam moments, step counts and the LR index untouched
         (gradients are zeroed again)."""
         out = self.model.train_step(batch, None)
-        out['loss'].backward()
+        self._backward(lambda: out['loss'].backward())
         self.reducer.finish()
         for seg in self.segments:
             seg.flat_g.zero_()
@@ -286,10 +286,20 @@ class CloverEngine:
             out = self._graphed_forward_backward(batch)
         else:
             out = self.model.train_step(batch, None)
-            out['loss'].backward()
+            self._backward(lambda: out['loss'].backward())
         self.reducer.finish()
         self.optimizer_step()
         return out
+
+    def _backward(self, run):
+        """Run a backward pass / segment with the weight-gradient folds deferred to ONE batched launch at its end —
+        unless gradient-ready hooks put buckets on the wire from inside the pass (eager data-parallel mode), where a
+        gradient must be final when its hook fires."""
+        if (self.reducer.active and self.reducer.enabled) or os.environ.get('CLOVER_DEFER_FOLDS', '1') != '1':
+            run()
+        else:
+            with ops.defer_folds():
+                run()
 
     # ------------------------------------------------------------------ hipGraph mode
     _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
@@ -384,7 +394,7 @@ class CloverEngine:
             return [emb] + ([mlm] if mlm is not None else []), [demb] + ([dmlm] if mlm is not None else [])
 
         def bwd_cut(cuts):
-            torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
+            self._backward(lambda: torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts]))
 
         def bwd_video(cuts):                   # output cut first, then the in-encoder cut (backward order)
             for c in reversed(cuts):
@@ -398,8 +408,8 @@ class CloverEngine:
                 vcuts = [] if cut_ok else None
                 tcuts = [] if text_ok else None
                 emb, mlm = encode(vcuts, tcuts)
-                torch.autograd.backward(*roots(emb, mlm, torch.zeros_like(emb),
-                                               torch.zeros_like(mlm) if mlm is not None else None))
+                self._backward(lambda: torch.autograd.backward(*roots(emb, mlm, torch.zeros_like(emb),
+                                                                      torch.zeros_like(mlm) if mlm is not None else None)))
                 if vcuts:
                     bwd_video(vcuts)
                 if tcuts:
@@ -422,7 +432,7 @@ class CloverEngine:
         self._static_demb = torch.zeros_like(emb)
         self._static_dmlm = torch.zeros_like(mlm) if mlm is not None else None
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
-            torch.autograd.backward(*roots(emb, mlm, self._static_demb, self._static_dmlm))
+            self._backward(lambda: torch.autograd.backward(*roots(emb, mlm, self._static_demb, self._static_dmlm)))
         if cut_ok:
             gb2 = []
             for c in reversed(vcuts):

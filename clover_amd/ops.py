@@ -133,10 +133,16 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
         args = (_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(work), M, N, K, dy2.stride(0), x2.stride(0),
                 _ptr(xstats[0] if xstats else None), _ptr(xstats[1] if xstats else None))
+        slices = L.clv_linear_wgrad_splits(M, N, K)
+        needs_fold = slices > 1 or xstats is not None       # one slice without standardisation: atomics straight into dW
         if PROF is None:
-            check(L.clv_linear_wgrad(*args, 0, _stream()), 'clv_linear_wgrad')
+            if FOLD_DEFER is not None and sink and needs_fold:
+                # partial kernel now, its fold in the ONE batched launch that closes this backward segment
+                check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
+                FOLD_DEFER.append((work, dw, db, N, K, slices))
+            else:
+                check(L.clv_linear_wgrad(*args, 0, _stream()), 'clv_linear_wgrad')
         else:                                  # one event pair per device kernel
-            slices = work.numel() // (N * K + N)             # one slice: atomics straight into dW (gemm_wgrad.hip)
             kname = 'wgrad_kernel' if xstats else f"wgrad_dma2_kernel<{'true' if slices == 1 else 'false'}>"
             with _Timed(kname, 2 * M * N * K, M * (N + K) * 2):
                 check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
@@ -155,6 +161,37 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         torch.addmm(dw_out, dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
         return None, None
     return torch.mm(dy2.t(), x2, out_dtype=torch.float32), db
+
+
+FOLD_DEFER = None           # list while a backward segment defers its weight-gradient folds (defer_folds())
+
+
+class defer_folds:
+    """Context: the weight-gradient launches inside write their fp32 partials only; ONE clv_wgrad_fold_batch launch on
+    exit adds them into the gradient slabs (a backward pass otherwise pays ~44 launch-bound 5-7 us fold kernels).
+    Only for gradients nobody reads before the context closes (the engine wraps whole backward segments)."""
+
+    def __enter__(self):
+        global FOLD_DEFER
+        self.prev, FOLD_DEFER = FOLD_DEFER, []
+        return self
+
+    def __exit__(self, *exc):
+        global FOLD_DEFER
+        pending, FOLD_DEFER = FOLD_DEFER, self.prev
+        if exc[0] is None:
+            flush_folds(pending)
+        return False
+
+
+def flush_folds(pending):
+    for i in range(0, len(pending), _lib.FOLD_MAX):
+        chunk = pending[i:i + _lib.FOLD_MAX]
+        arr = (_lib.ClvFoldEntry * len(chunk))()
+        for e, (work, dw, db, N, K, slices) in zip(arr, chunk):
+            e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+            e.nk, e.e2, e.splits = N * K, N * K + N, slices
+        check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
 
 
 def _rowgemm_fwd_ok(x, N, K):

@@ -190,7 +190,21 @@ int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad(const void* dy, const void* x, float* dw, float* db, float* work, int64_t M,
                      int32_t N, int32_t K, int32_t ldy, int32_t ldx, const float* xmean,
                      const float* xrstd, int32_t stages, void* stream);
-/* stages: 0 = both kernels; bit 1 = split-M partial kernel, bit 2 = fold of the partials (profiling). */
+/* stages: 0 = both kernels; bit 1 = split-M partial kernel, bit 2 = fold of the partials (profiling, or a deferred
+ * fold: a backward pass may run its weight-gradient launches with stages = 1 and fold all their partials at once).
+ * clv_linear_wgrad_splits: the number of M-slices (= fp32 partial slabs [N*K dW | N db] in work) the launch uses; a fold
+ * is needed when it is > 1 or xmean is given.  clv_wgrad_fold_batch: dw[e] += sum_s partial[s][e], db likewise, for up
+ * to CLV_FOLD_MAX launches in one kernel (entries is a HOST array; sg_shift / block_begin are filled in by the callee). */
+#define CLV_FOLD_MAX 64
+typedef struct ClvFoldEntry {
+    const void* partial;   /* work of that clv_linear_wgrad call */
+    void* dw;              /* float [N][K], accumulated into */
+    void* db;              /* float [N] or NULL */
+    int64_t nk, e2;        /* N*K and N*K + N */
+    int32_t splits, sg_shift, block_begin, pad;
+} ClvFoldEntry;
+int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
+int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------ token-parallel projections
  * Y[M][N] = epilogue( prologue(X)[M][K] * Wt[N][K]^T + bias ) — the QKV / proj / fc1 / fc2 Linears of
