@@ -392,9 +392,9 @@ class _FusedLNLinear(torch.autograd.Function):
         a2 = _c(a).view(-1, K)
         r2 = _c(r).view(-1, K) if r is not None else None
         wt, bf = fold_layernorm(weight, bias, ln_weight, ln_bias)
-        out = rowgemm(a2, wt, bf, res=r2, standardise=True, eps=eps)
+        out = rowgemm(a2, wt, bf, res=r2, standardise=True, eps=eps, want_xhat=any(ctx.needs_input_grad))
         xs = out['sum'] if r is not None else a2
-        ctx.save_for_backward(xs, out['mean'], out['rstd'], wt)
+        ctx.save_for_backward(xs, out['mean'], out['rstd'], wt, out['xhat'])
         ctx.has_res = r is not None
         ctx.shape = a.shape
         ctx.prefs = (weight, bias, ln_weight, ln_bias)
@@ -403,14 +403,15 @@ class _FusedLNLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, ds):
-        xs, mean, rstd, wt = ctx.saved_tensors
+        xs, mean, rstd, wt, xhat = ctx.saved_tensors
         N, K = wt.shape
         dy2 = _c(dy.reshape(-1, N))
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         dxhat = linear_dgrad(dy2, wt)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
-        dwf, dbf = linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
+        # the forward kept the standardised rows: the weight gradient runs on the LDS-DMA kernel
+        dwf, dbf = linear_wgrad(dy2, xhat, True) if xhat is not None else linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
         weight, bias, gamma, beta = ctx.prefs
         dw, db, dg, dbt = _unfold_grads(dwf, dbf, weight, bias, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None
@@ -434,7 +435,7 @@ class _FusedMLP(torch.autograd.Function):
         a2 = _c(a).view(-1, K)
         r2 = _c(r).view(-1, K) if r is not None else None
         wt1, bf1 = fold_layernorm(w1, b1, ln_weight, ln_bias)
-        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps)
+        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps, want_xhat=any(ctx.needs_input_grad))
         xs = o1['sum'] if r is not None else a2
         w2b = getattr(w2, '_clv_shadow', None)
         if w2b is None:
@@ -445,7 +446,7 @@ class _FusedMLP(torch.autograd.Function):
             if b2b is None:
                 b2b = b2.to(BF16)
         out = torch.nn.functional.linear(o1['y'], w2b, b2b)
-        ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b)
+        ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b, o1['xhat'])
         ctx.has_res = r is not None
         ctx.shape = a.shape
         ctx.w2ref, ctx.b2ref = w2, b2
@@ -454,7 +455,7 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, ds):
-        xs, mean, rstd, wt1, pre, act, w2b = ctx.saved_tensors
+        xs, mean, rstd, wt1, pre, act, w2b, xhat = ctx.saved_tensors
         C_, Hd = w2b.shape                              # fc2: [C, 4C]
         do2 = _c(dout.reshape(-1, C_))
         if do2.dtype != BF16:
@@ -483,7 +484,7 @@ class _FusedMLP(torch.autograd.Function):
         # fc1 + LayerNorm
         dxhat = linear_dgrad(dpre, wt1)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
-        dwf1, dbf1 = linear_wgrad(dpre, xs, True, xstats=(mean, rstd))
+        dwf1, dbf1 = linear_wgrad(dpre, xhat, True) if xhat is not None else linear_wgrad(dpre, xs, True, xstats=(mean, rstd))
         w1, b1, gamma, beta = ctx.prefs
         dw1, db1, dg, dbt = _unfold_grads(dwf1, dbf1, w1, b1, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None
@@ -627,7 +628,7 @@ def rowgemm_supported(N, K, standardise=False):
     return bool(_lib.lib().clv_rowgemm_supported(int(N), int(K), int(bool(standardise))))
 
 
-def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=None, eps=1e-5):
+def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=None, eps=1e-5, want_xhat=False):
     """Raw launcher of clv_rowgemm (no autograd).  x bf16 [M,K]; wt bf16 [N,K]; bias fp32 [N] | None.
     Returns dict(y, sum, mean, rstd, pre) (entries None when not produced)."""
     _need_gpu(x, wt)
@@ -640,10 +641,11 @@ def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=No
     rstd = torch.empty_like(mean) if standardise else None
     pre = torch.empty_like(y) if epilogue == 1 else None
     bf = _c(bias.float()) if bias is not None else None
-    check(_lib.lib().clv_rowgemm(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(wt), _ptr(bf),
+    xhat = torch.empty_like(x) if (want_xhat and standardise and os.environ.get('CLOVER_XHAT', '1') == '1') else None
+    check(_lib.lib().clv_rowgemm(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(xhat), _ptr(wt), _ptr(bf),
                                  _ptr(pre_in), _ptr(y), _ptr(pre), M, N, K, x.stride(0), N, int(bool(standardise)),
                                  int(epilogue), float(eps), _stream()), 'clv_rowgemm')
-    return dict(y=y, sum=ssum, mean=mean, rstd=rstd, pre=pre)
+    return dict(y=y, sum=ssum, mean=mean, rstd=rstd, pre=pre, xhat=xhat)
 
 
 # --------------------------------------------------------------------------- LayerNorm

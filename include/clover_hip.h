@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 2
+#define CLV_ABI_VERSION 3
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -213,15 +213,16 @@ int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);
  * memory-bound ops folded in:
  *   prologue  standardise != 0: x = X (+ res; the sum is written to sum_out), then (x - mean) * rstd —
  *             nn.LayerNorm (:450,483) with its affine part folded into Wt/bias by the caller; mean, rstd
- *             (float [M]) are outputs;
+ *             (float [M]) are outputs; xhat_out (bf16 [M][K], row stride ldx, or NULL) receives the standardised rows —
+ *             the operand of the weight gradient dW = dY^T x_hat;
  *   epilogue  0: + bias;  1: + bias, erf-GELU (:264), the pre-activation goes to pre_out;
  *             2: multiply by gelu'(pre_in) (GELU backward fused into the fc2 input-gradient GEMM).
  * X, res, sum_out bf16 [M][K] (row stride ldx); Wt bf16 [N][K] contiguous; bias float [N] or NULL;
  * Y, pre_in, pre_out bf16 [M][N] (row stride ldy).  K in {96,128,192,256,288,384,512,576,768}
  * (<= 256 with standardise), N % 8 == 0: query clv_rowgemm_supported(). */
 int clv_rowgemm_supported(int32_t N, int32_t K, int32_t standardise);
-int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, const void* wt,
-                const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
+                const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
                 int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
                 void* stream);
 
