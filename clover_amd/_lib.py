@@ -33,10 +33,15 @@ class ClvFoldEntry(C.Structure):
 FOLD_MAX = 64
 
 
+class ClvLnReduceEntry(C.Structure):
+    _fields_ = [('partial', _p), ('dgamma', _p), ('dbeta', _p), ('nblk', _i32), ('C', _i32), ('block_begin', _i32),
+                ('pad', _i32)]
+
+
 class ClvLnExtra(C.Structure):
     """Mirror of ``struct ClvLnExtra`` (include/clover_hip.h)."""
     _fields_ = [('xscale', _p), ('rows_per_sample', _i32), ('drop_p', _f), ('seed', _p), ('dy2', _p), ('dres', _p),
-                ('x_is_sum', _i32), ('gather_c', _i32), ('gather_h2', _i32), ('gather_w2', _i32)]
+                ('x_is_sum', _i32), ('gather_c', _i32), ('gather_h2', _i32), ('gather_w2', _i32), ('no_reduce', _i32)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
@@ -75,6 +80,8 @@ SIGNATURES = {
     'clv_gemm_nt_supported': (C.c_int, [_i64, _i32, _i32]),
     'clv_gemm_nt': (C.c_int, [_p] * 6 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p]),
     'clv_transpose_batch': (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    'clv_layernorm_bwd_needs_reduce': (C.c_int, [_i64, _i32]),
+    'clv_ln_reduce_batch': (C.c_int, [_p, _i32, _p]),
     'clv_linear_wgrad_splits': (C.c_int, [_i64, _i32, _i32]),
     'clv_wgrad_fold_batch': (C.c_int, [_p, _i32, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),

@@ -745,10 +745,66 @@ extern "C" int clv_layernorm_bwd(const void* dy, const void* x, const void* res,
         }
     }
     int rc = clv_check_launch();
-    if (rc || direct) return rc;
+    if (rc || direct || (extra && extra->no_reduce)) return rc;
     const int ysplit = grid >= 256 ? 8 : 1;      // > 1: atomics into dgamma/dbeta (caller zeroes them)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((C + 63) / 64, ysplit), dim3(1024), 0, st, partial, dgamma, dbeta,
                        grid, (int)C);
+    return clv_check_launch();
+}
+
+extern "C" int clv_layernorm_bwd_needs_reduce(int64_t rows, int32_t C) { return clv_layernorm_bwd_blocks(rows, C) > 256; }
+
+namespace {
+struct LnReduceTable {
+    ClvLnReduceEntry e[CLV_LN_REDUCE_MAX];
+    int n;
+};
+// block = 64 channels x 16 row-lanes of one entry (see ln_bwd_reduce_kernel); 4 block rows per (entry, channel group)
+__global__ void __launch_bounds__(1024) ln_reduce_batch_kernel(LnReduceTable tab) {
+    __shared__ float sa[16][64], sb[16][64];
+    int idx = 0;
+    for (int i = 1; i < tab.n; ++i)
+        if ((int)blockIdx.x >= tab.e[i].block_begin) idx = i;
+    const ClvLnReduceEntry& en = tab.e[idx];
+    const int lb = blockIdx.x - en.block_begin, cb = lb >> 2, ys = lb & 3;
+    const int cl = threadIdx.x & 63, sp = threadIdx.x >> 6;
+    const int c = cb * 64 + cl, C = en.C, nblk = en.nblk;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        for (int i = ys * 16 + sp; i < nblk; i += 64) {
+            a += en.partial[(int64_t)i * C + c];
+            b += en.partial[((int64_t)nblk + i) * C + c];
+        }
+    }
+    sa[sp][cl] = a;
+    sb[sp][cl] = b;
+    __syncthreads();
+    if (sp == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            a += sa[k][cl];
+            b += sb[k][cl];
+        }
+        atomicAdd(en.dgamma + c, a);
+        atomicAdd(en.dbeta + c, b);
+    }
+}
+}  // namespace
+
+extern "C" int clv_ln_reduce_batch(const ClvLnReduceEntry* entries, int32_t n, void* stream) {
+    if (!entries || n <= 0 || n > CLV_LN_REDUCE_MAX) return CLV_ERR_ARG;
+    static_assert(sizeof(ClvLnReduceEntry) == 40, "ClvLnReduceEntry layout is part of the ABI");
+    LnReduceTable tab;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ClvLnReduceEntry en = entries[i];
+        if (!en.partial || !en.dgamma || !en.dbeta || en.nblk <= 0 || en.C <= 0) return CLV_ERR_ARG;
+        en.block_begin = blocks;
+        blocks += 4 * ((en.C + 63) / 64);
+        tab.e[i] = en;
+    }
+    tab.n = n;
+    hipLaunchKernelGGL(ln_reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, tab);
     return clv_check_launch();
 }
 

@@ -164,6 +164,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
 
 
 FOLD_DEFER = None           # list while a backward segment defers its weight-gradient folds (defer_folds())
+LN_DEFER = None             # ... and the reductions of its LayerNorm-backward partials
 
 
 class defer_folds:
@@ -172,15 +173,18 @@ class defer_folds:
     Only for gradients nobody reads before the context closes (the engine wraps whole backward segments)."""
 
     def __enter__(self):
-        global FOLD_DEFER
+        global FOLD_DEFER, LN_DEFER
         self.prev, FOLD_DEFER = FOLD_DEFER, []
+        self.prev_ln, LN_DEFER = LN_DEFER, ([] if os.environ.get('CLOVER_DEFER_LN', '1') == '1' else None)
         return self
 
     def __exit__(self, *exc):
-        global FOLD_DEFER
+        global FOLD_DEFER, LN_DEFER
         pending, FOLD_DEFER = FOLD_DEFER, self.prev
+        pending_ln, LN_DEFER = LN_DEFER, self.prev_ln
         if exc[0] is None:
             flush_folds(pending)
+            flush_ln_reduces(pending_ln or [])
         return False
 
 
@@ -192,6 +196,15 @@ def flush_folds(pending):
             e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
             e.nk, e.e2, e.splits = N * K, N * K + N, slices
         check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
+
+
+def flush_ln_reduces(pending):
+    for i in range(0, len(pending), 64):
+        chunk = pending[i:i + 64]
+        arr = (_lib.ClvLnReduceEntry * len(chunk))()
+        for e, (partial, dg, db, nblk, C_) in zip(arr, chunk):
+            e.partial, e.dgamma, e.dbeta, e.nblk, e.C = partial.data_ptr(), dg.data_ptr(), db.data_ptr(), nblk, C_
+        check(_lib.lib().clv_ln_reduce_batch(arr, len(chunk), _stream()), 'clv_ln_reduce_batch')
 
 
 def _rowgemm_fwd_ok(x, N, K):
@@ -654,7 +667,7 @@ def _ln_extra(xscale, rows_per_sample, drop_p, seed, dy2=None, dres=None, x_is_s
     if xscale is None and not drop_p and dy2 is None and dres is None:
         return None
     return _lib.ClvLnExtra(_ptr(xscale), int(rows_per_sample), float(drop_p or 0.0), _ptr(seed), _ptr(dy2),
-                           _ptr(dres), int(x_is_sum), 0, 0, 0)
+                           _ptr(dres), int(x_is_sum), 0, 0, 0, 0)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -739,6 +752,12 @@ class _LayerNorm(torch.autograd.Function):
             dg = torch.zeros(C_, device=x2.device, dtype=torch.float32)
             db = torch.zeros_like(dg)
         ex = _ln_extra(xs, ctx.rps, ctx.drop_p, seed, dyf2, dres, ctx.x_is_sum)
+        if LN_DEFER is not None and sink and L.clv_layernorm_bwd_needs_reduce(rows, C_):
+            # leave the per-block partials; ONE batched launch reduces them when the backward segment closes
+            if ex is None:
+                ex = _lib.ClvLnExtra(None, 1, 0.0, None, None, None, int(ctx.x_is_sum), 0, 0, 0, 0)
+            ex.no_reduce = 1
+            LN_DEFER.append((partial, dg, db, nblk, C_))
         check(L.clv_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(r2), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(ds2),
                                   _ptr(dx), _ptr(dg), _ptr(db), _ptr(partial), rows, C_,
                                   int(x2.dtype == torch.float32), C.byref(ex) if ex is not None else None,

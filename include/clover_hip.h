@@ -126,6 +126,10 @@ typedef struct ClvLnExtra {
      * x / res [.., 2*gather_h2, 2*gather_w2, gather_c]; rows = .. * gather_h2 * gather_w2; y stays [rows][C]; the
      * backward writes dx / dres in the un-gathered layout (every element exactly once).  No sum_out / dsum / dropout. */
     int32_t gather_c, gather_h2, gather_w2;
+    /* backward: leave the per-block partials in `partial` and skip the reduction launch — the caller folds the
+     * partials of many LayerNorms into their dgamma / dbeta with ONE clv_ln_reduce_batch launch (needs_reduce tells
+     * whether this launch wrote partials at all: up to 256 blocks add into dgamma / dbeta directly) */
+    int32_t no_reduce;
 } ClvLnExtra;
 int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                       void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,
@@ -137,6 +141,18 @@ int clv_layernorm_bwd_blocks(int64_t rows, int32_t C);
 int clv_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                       const float* mean, const float* rstd, const void* dsum, void* dx, float* dgamma, float* dbeta,
                       float* partial, int64_t rows, int32_t C, int32_t is_f32, const ClvLnExtra* extra, void* stream);
+
+/* Batched reduction of LayerNorm-backward partials (launches made with extra->no_reduce): dgamma[c] += sum_i
+ * partial[0][i][c], dbeta[c] += sum_i partial[1][i][c] for up to CLV_LN_REDUCE_MAX entries (HOST array) in one launch. */
+#define CLV_LN_REDUCE_MAX 64
+typedef struct ClvLnReduceEntry {
+    const float* partial;      /* [2][nblk][C] */
+    float* dgamma;
+    float* dbeta;
+    int32_t nblk, C, block_begin, pad;
+} ClvLnReduceEntry;
+int clv_layernorm_bwd_needs_reduce(int64_t rows, int32_t C);
+int clv_ln_reduce_batch(const ClvLnReduceEntry* entries, int32_t n, void* stream);
 
 /* LayerNorm affine folded into the following Linear (the fused LN + projection kernels, clv_rowgemm with
  * standardise = 1, consume standardised rows):  wf[n][k] = bf16(w[n][k] * gamma[k]),  bf[n] = b[n] + sum_k w[n][k] beta[k]
