@@ -662,12 +662,11 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     }
 }
 
-// d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key], in three kernels and without atomics:
+// d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key], in two kernels and without atomics:
 //   sum     partial[s][h][q tile][key tile][lane][4] (fp32) = sum over group slice s of the dQ kernel's bf16 scratch
 //           (same fragment order; one thread = 4 scores; streaming, HBM-bound)
-//   fold    dense = sum of the slices' partials
 //   gather  one WAVE per (head, table row): its lanes share the <= N (query, key) pairs that map to the row
-//           (query coords = key coords + the row's offset), add the partial sums, wave-reduce, one writer per row
+//           (query coords = key coords + the row's offset), add the slices' partial sums, wave-reduce, one writer per row
 __global__ void __launch_bounds__(256) dbias_sum_kernel(const bf16_t* __restrict__ ds, float4* __restrict__ partial,
                                                         int groups, int64_t E2) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over nH * nqt * nkt * 32: 8 scores each
@@ -686,22 +685,8 @@ __global__ void __launch_bounds__(256) dbias_sum_kernel(const bf16_t* __restrict
     out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// dense[e] = sum over the slices of partial[s][e]
-__global__ void __launch_bounds__(256) dbias_fold_kernel(const float4* __restrict__ partial, float4* __restrict__ dense,
-                                                         int nsplit, int64_t E) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    float4 a = partial[e];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float4 b = partial[(int64_t)sp * E + e];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    dense[e] = a;
-}
-
-__global__ void __launch_bounds__(256) dbias_gather_kernel(const float* __restrict__ dense, float* __restrict__ dtable,
-                                                           int nkt, Geom G) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;    // wave id over tlen * nH
+__device__ __forceinline__ void dbias_gather_wave(const float* __restrict__ dense, float* __restrict__ dtable, int nkt,
+                                                  const Geom& G, int nsplit, int64_t split_stride, int w, int lane) {
     if (w >= G.tlen * G.g.nH) return;
     const int slot = w / G.g.nH, h = w - slot * G.g.nH;
     // slot = (dz + bwd-1) * ts_d + (dy + bwh-1) * ts_h + (dx + bww-1):  query coords = key coords + (dz, dy, dx)
@@ -717,10 +702,16 @@ __global__ void __launch_bounds__(256) dbias_gather_kernel(const float* __restri
         const int qn = (qz * G.g.bwh + qy) * G.g.bww + qx;
         if (qn >= G.g.N) continue;
         // fragment address of (qn, key): q tile qn>>4, key tile key>>4, lane = (key&15)>>2 << 4 | qn&15, r = key&3
-        a += dh[(((int64_t)(qn >> 4) * nkt + (key >> 4)) * 64 + ((((key & 15) >> 2) << 4) | (qn & 15))) * 4 + (key & 3)];
+        const float* pe = dh + (((int64_t)(qn >> 4) * nkt + (key >> 4)) * 64 + ((((key & 15) >> 2) << 4) | (qn & 15))) * 4 + (key & 3);
+        for (int sp = 0; sp < nsplit; ++sp) a += pe[sp * split_stride];      // the slices' partial sums (was a fold launch)
     }
     a = wave_sum(a);
     if (lane == 0) dtable[w] += a;
+}
+
+__global__ void __launch_bounds__(256) dbias_gather_kernel(const float* __restrict__ dense, float* __restrict__ dtable,
+                                                           int nkt, Geom G, int nsplit, int64_t split_stride) {
+    dbias_gather_wave(dense, dtable, nkt, G, nsplit, split_stride, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------- host side
@@ -857,9 +848,9 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         float* dense = partial + (int64_t)splits * E * 4;
         hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
                            (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(dense), splits, E);
-        hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, dense, dbias, NKT, G);
+        (void)dense;
+        hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias, NKT, G,
+                           splits, E * 4);
         rc = clv_check_launch();
         if (rc) return rc;
     }
@@ -932,3 +923,4 @@ extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const v
     if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st) }
     DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st)
 }
+

@@ -560,7 +560,7 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELU) && !bias) return CLV_ERR_ARG;
     if (epilogue == GN_EPI_GELU && !c2) return CLV_ERR_ARG;
     if (epilogue == GN_EPI_DGELU && !aux) return CLV_ERR_ARG;
-    const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8", "256x128w4"
+    const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8"
     if (force && (!strcmp(force, "lean") || !strcmp(force, "lean64"))) {     // one tile per workgroup (measured 5-15 % behind)
         // 4 GiB of addressable operand per tile row block (32-bit lane offsets)
         if ((int64_t)128 * lda * 2 >= (1ll << 31) || (int64_t)128 * ldb * 2 >= (1ll << 31)) return CLV_ERR_UNSUPPORTED;
@@ -594,7 +594,6 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
                 lda, ldb, ldc, tilesN, nmblk
     if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
-    if (BM == 256 && BN == 128 && W == 4) return gn_launch<256, 128, 2, 2, 3>(GN_ARGS);   // wave tile 128 x 64
     if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4
 #undef GN_ARGS
     return CLV_ERR_UNSUPPORTED;
