@@ -110,6 +110,36 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return fmaf(x * 0.3989422804014327f, ex, cdf);
 }
 
+// Two-at-a-time versions on packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of polynomial per
+// instruction; rcp / exp2 / selects stay scalar) for the GELU epilogues of the GEMM kernels, whose VALU work otherwise
+// equals their MFMA time at the stage-2 widths.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& ex) {
+    const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t){0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f},
+                                                (f32x2_t){1.0f, 1.0f});
+    const f32x2_t t = {__frcp_rn(d.x), __frcp_rn(d.y)};
+    const f32x2_t xx = x * x * (f32x2_t){-0.72134752044448170f, -0.72134752044448170f};
+    ex = (f32x2_t){__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
+    f32x2_t poly = __builtin_elementwise_fma((f32x2_t){1.061405429f, 1.061405429f}, t, (f32x2_t){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){0.254829592f, 0.254829592f});
+    const f32x2_t h = poly * t * ex * (f32x2_t){0.5f, 0.5f};             // 0.5 (1 - erf(z))
+    const f32x2_t oh = (f32x2_t){1.0f, 1.0f} - h;
+    cdf = (f32x2_t){x.x >= 0.f ? oh.x : h.x, x.y >= 0.f ? oh.y : h.y};
+}
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    f32x2_t cdf, ex;
+    gelu_parts2(x, cdf, ex);
+    return x * cdf;
+}
+__device__ __forceinline__ f32x2_t gelu_erf_grad2(f32x2_t x) {
+    f32x2_t cdf, ex;
+    gelu_parts2(x, cdf, ex);
+    return __builtin_elementwise_fma(x * (f32x2_t){0.3989422804014327f, 0.3989422804014327f}, ex, cdf);
+}
+
 static inline int clv_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CLV_OK : CLV_ERR_LAUNCH;

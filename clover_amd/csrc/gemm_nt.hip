@@ -252,14 +252,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                     *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                                                    pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t r = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+                        v[e] = r.x; v[e + 1] = r.y;
+                    }
                 }
                 if (EPI == GN_EPI_DGELU) {
                     const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
                     const uint32_t pv[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[e] *= gelu_erf_grad((e & 1) ? gn_hi(pv[e >> 1]) : gn_lo(pv[e >> 1]));
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t r = gelu_erf_grad2((f32x2_t){gn_lo(pv[e >> 1]), gn_hi(pv[e >> 1])});
+                        v[e] *= r.x; v[e + 1] *= r.y;
+                    }
                 }
                 *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                                               pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
@@ -444,13 +449,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_lean_kernel(const bf16_t* __re
                 *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                                                pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2_t r = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+                    v[e] = r.x; v[e + 1] = r.y;
+                }
             }
             if (EPI == GN_EPI_DGELU) {
                 const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
                 const uint32_t pv[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((e & 1) ? gn_hi(pv[e >> 1]) : gn_lo(pv[e >> 1]));
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2_t r = gelu_erf_grad2((f32x2_t){gn_lo(pv[e >> 1]), gn_hi(pv[e >> 1])});
+                    v[e] *= r.x; v[e + 1] *= r.y;
+                }
             }
             *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                                           pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));

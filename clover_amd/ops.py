@@ -242,7 +242,7 @@ def linear_dgrad(dy2, wb, weight=None, pre=None):
     N, K = wb.shape
     if pre is None and dy2.is_cuda and (N <= 288 or K <= 128 and N <= 384) and rowgemm_supported(K, N) and dy2.stride(1) == 1:
         return rowgemm(dy2, _wt(weight, wb), None)['y']
-    if own_gemm_ok(dy2, K, N):
+    if own_gemm_ok(dy2, K, N) and (pre is None or os.environ.get('CLOVER_DGELU_FUSE', '1') == '1'):
         return gemm_nt(dy2, _wt(weight, wb), aux=pre, epilogue=GEMM_EPI_DGELU if pre is not None else GEMM_EPI_NONE)
     dx = torch.mm(dy2, wb)
     if pre is not None:
