@@ -33,6 +33,14 @@ class ClvFoldEntry(C.Structure):
 FOLD_MAX = 64
 
 
+class ClvWgradEntry(C.Structure):
+    _fields_ = [('dy', _p), ('x', _p), ('work', _p), ('M', _i64), ('work_floats', _i64), ('N', _i32), ('K', _i32),
+                ('ldy', _i32), ('ldx', _i32), ('want_bias', _i32), ('splits', _i32)]
+
+
+WGRAD_GROUP_MAX = 40
+
+
 class ClvLnReduceEntry(C.Structure):
     _fields_ = [('partial', _p), ('dgamma', _p), ('dbeta', _p), ('nblk', _i32), ('C', _i32), ('block_begin', _i32),
                 ('pad', _i32)]
@@ -82,6 +90,8 @@ SIGNATURES = {
     'clv_transpose_batch': (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     'clv_layernorm_bwd_needs_reduce': (C.c_int, [_i64, _i32]),
     'clv_ln_reduce_batch': (C.c_int, [_p, _i32, _p]),
+    'clv_linear_wgrad_batch_plan': (C.c_int, [_p, _i32]),
+    'clv_linear_wgrad_batch': (C.c_int, [_p, _i32, _p]),
     'clv_linear_wgrad_splits': (C.c_int, [_i64, _i32, _i32]),
     'clv_wgrad_fold_batch': (C.c_int, [_p, _i32, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),

@@ -338,23 +338,21 @@ __device__ __forceinline__ void dma4(unsigned lds_wave_base, unsigned voff_y0, u
 }
 
 template <bool ACCUM>
-__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
-                                                                   const bf16_t* __restrict__ x,
-                                                                   float* __restrict__ out, float* __restrict__ out_b,
-                                                                   int64_t M, int N, int K, int ldy, int ldx, int tiles,
-                                                                   int tilesK, int nsplits, int64_t rows_per_split,
-                                                                   int want_bias) {
-    __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
+__device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], const int bid,
+                                                const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                float* __restrict__ out, float* __restrict__ out_b, int64_t M, int N, int K,
+                                                int ldy, int ldx, int tiles, int tilesK, int nsplits,
+                                                int64_t rows_per_split, int want_bias) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     int split, tile;
     if (nsplits > 0) {                                                       // see wgrad_dma_kernel
-        const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+        const int xcd = bid & 7, xslot = bid >> 3;
         split = xcd + 8 * (xslot / tiles);
         tile = xslot % tiles;
         if (split >= nsplits) return;
     } else {
-        split = blockIdx.x / tiles;
-        tile = blockIdx.x - split * tiles;
+        split = bid / tiles;
+        tile = bid - split * tiles;
     }
     const int tn = tile / tilesK, tk = tile - tn * tilesK;
     const int n0 = tn * TN, k0 = tk * TK;
@@ -525,6 +523,45 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t*
             if (do_bias && lg == 0) pb[n] = bacc[i][0];       // all-ones operand: every r holds the column sum
         }
     }
+}
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
+                                                                   const bf16_t* __restrict__ x,
+                                                                   float* __restrict__ out, float* __restrict__ out_b,
+                                                                   int64_t M, int N, int K, int ldy, int ldx, int tiles,
+                                                                   int tilesK, int nsplits, int64_t rows_per_split,
+                                                                   int want_bias) {
+    __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
+    wgrad_dma2_body<ACCUM>(ring, blockIdx.x, dy, x, out, out_b, M, N, K, ldy, ldx, tiles, tilesK, nsplits, rows_per_split,
+                           want_bias);
+}
+
+// Grouped launch: the weight gradients of a whole backward segment (they have no consumer before the optimizer) as ONE
+// grid — workgroup b belongs to the problem whose [block_begin, next block_begin) holds b.  On their own these kernels
+// are latency-bound (one workgroup per CU walking 50-100 stages behind 7 us of launch + prologue); together they keep
+// every CU at two workgroups from different problems, need far fewer M-slices each (less partial traffic), and leave
+// the dgrad chain of the backward pass uninterrupted.
+constexpr int WG_GROUP_MAX = 40;
+struct WgProblem {
+    const bf16_t* dy;
+    const bf16_t* x;
+    float* work;
+    int64_t M, rows_per_split;
+    int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin;
+};
+struct WgGroup {
+    WgProblem p[WG_GROUP_MAX];
+    int n;
+};
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_group_kernel(WgGroup grp) {
+    __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];
+    int idx = 0;
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) idx = i;
+    const WgProblem& pr = grp.p[idx];
+    wgrad_dma2_body<false>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M, pr.N, pr.K, pr.ldy,
+                           pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias);
 }
 
 // dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N): a thread owns 4 consecutive e (16-byte
@@ -783,5 +820,60 @@ extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void
     }
     tab.n = n;
     hipLaunchKernelGGL(fold_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
+    return clv_check_launch();
+}
+
+// Slices of one problem inside a grouped launch of n problems: enough workgroups in total (~8 per CU) rather than per
+// problem, at least 256 rows per slice.
+static int group_splits(int64_t M, int tiles, int n) {
+    int64_t target = 2048 / (n > 0 ? n : 1);
+    if (target < 64) target = 64;
+    int64_t s = (target + tiles - 1) / tiles;
+    const int64_t max_by_rows = (M + 255) / 256;
+    if (s > max_by_rows) s = max_by_rows;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
+    if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        ClvWgradEntry& e = entries[i];
+        if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
+        const int tiles = ((e.N + TN - 1) / TN) * ((e.K + TK - 1) / TK);
+        e.splits = group_splits(e.M, tiles, n);
+        e.work_floats = (int64_t)e.splits * ((int64_t)e.N * e.K + e.N);
+    }
+    return CLV_OK;
+}
+
+extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream) {
+    if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
+    static_assert(sizeof(WgGroup) <= 4000, "kernel-argument budget");
+    WgGroup grp;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ClvWgradEntry& e = entries[i];
+        if (!e.dy || !e.x || !e.work || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7)) return CLV_ERR_ARG;
+        WgProblem& p = grp.p[i];
+        const int tilesN = (e.N + TN - 1) / TN, tilesK = (e.K + TK - 1) / TK;
+        p.dy = (const bf16_t*)e.dy;
+        p.x = (const bf16_t*)e.x;
+        p.work = (float*)e.work;
+        p.M = e.M;
+        p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
+        p.tiles = tilesN * tilesK;
+        p.tilesK = tilesK;
+        int64_t rows = (e.M + e.splits - 1) / e.splits;
+        p.rows_per_split = (rows + TM - 1) / TM * TM;
+        const bool xcd_map = e.splits >= 8 && p.tiles >= 4;
+        p.nsplits = xcd_map ? e.splits : -1;
+        p.want_bias = e.want_bias;
+        p.block_begin = blocks;
+        int g = xcd_map ? 8 * p.tiles * ((e.splits + 7) / 8) : p.tiles * e.splits;
+        blocks += (g + 7) / 8 * 8;                           // keep every problem's block ids aligned to the 8 XCDs
+    }
+    grp.n = n;
+    hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(WG_THREADS), 0, (hipStream_t)stream, grp);
     return clv_check_launch();
 }

@@ -128,6 +128,11 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         xstats = None
     if _wgrad_custom(M, N, K):
         L = _lib.lib()
+        if WGRAD_DEFER is not None and sink and xstats is None and PROF is None and M > 1024:
+            # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
+            # backward segment (dy2 / x2 stay alive in the list until then)
+            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K))
+            return None, None
         dw = dw_out if sink else torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
         db = (db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)) if want_bias else None
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
@@ -165,6 +170,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
 
 FOLD_DEFER = None           # list while a backward segment defers its weight-gradient folds (defer_folds())
 LN_DEFER = None             # ... and the reductions of its LayerNorm-backward partials
+WGRAD_DEFER = None          # ... and whole weight-gradient launches (grouped into one grid)
 
 
 class defer_folds:
@@ -173,19 +179,45 @@ class defer_folds:
     Only for gradients nobody reads before the context closes (the engine wraps whole backward segments)."""
 
     def __enter__(self):
-        global FOLD_DEFER, LN_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER
         self.prev, FOLD_DEFER = FOLD_DEFER, []
         self.prev_ln, LN_DEFER = LN_DEFER, ([] if os.environ.get('CLOVER_DEFER_LN', '1') == '1' else None)
+        self.prev_wg, WGRAD_DEFER = WGRAD_DEFER, ([] if os.environ.get('CLOVER_GROUP_WGRAD', '1') == '1' else None)
         return self
 
     def __exit__(self, *exc):
-        global FOLD_DEFER, LN_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER
         pending, FOLD_DEFER = FOLD_DEFER, self.prev
         pending_ln, LN_DEFER = LN_DEFER, self.prev_ln
+        pending_wg, WGRAD_DEFER = WGRAD_DEFER, self.prev_wg
         if exc[0] is None:
+            pending = pending + flush_wgrads(pending_wg or [])
             flush_folds(pending)
             flush_ln_reduces(pending_ln or [])
         return False
+
+
+def flush_wgrads(pending):
+    """The deferred weight gradients as grouped launches (clv_linear_wgrad_batch, <= 40 problems each); returns the
+    fold entries of their partials."""
+    folds = []
+    L = _lib.lib()
+    for i in range(0, len(pending), _lib.WGRAD_GROUP_MAX):
+        chunk = pending[i:i + _lib.WGRAD_GROUP_MAX]
+        arr = (_lib.ClvWgradEntry * len(chunk))()
+        for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
+            e.dy, e.x, e.M, e.N, e.K = dy2.data_ptr(), x2.data_ptr(), M, N, K
+            e.ldy, e.ldx, e.want_bias = dy2.stride(0), x2.stride(0), int(db is not None)
+        check(L.clv_linear_wgrad_batch_plan(arr, len(chunk)), 'clv_linear_wgrad_batch_plan')
+        work = torch.empty(sum(e.work_floats for e in arr), device=chunk[0][0].device, dtype=torch.float32)
+        off = 0
+        for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
+            w = work[off:off + e.work_floats]
+            e.work = w.data_ptr()
+            folds.append((w, dw, db, N, K, e.splits))
+            off += e.work_floats
+        check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
+    return folds
 
 
 def flush_folds(pending):

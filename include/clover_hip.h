@@ -219,6 +219,20 @@ typedef struct ClvFoldEntry {
     int64_t nk, e2;        /* N*K and N*K + N */
     int32_t splits, sg_shift, block_begin, pad;
 } ClvFoldEntry;
+/* Grouped launch: the weight gradients of up to 40 Linear layers (a whole backward segment: nothing reads a weight
+ * gradient before the optimizer) as ONE grid.  clv_linear_wgrad_batch_plan fills splits and work_floats of every entry
+ * (fewer M-slices per problem than a stand-alone launch needs); the caller points `work` at work_floats floats,
+ * clv_linear_wgrad_batch writes the fp32 partials [splits][N*K dW | N db] there, and clv_wgrad_fold_batch (entries with
+ * the same work / splits) adds them into dW / db.  entries are HOST arrays. */
+typedef struct ClvWgradEntry {
+    const void* dy;            /* bf16 [M][N], row stride ldy */
+    const void* x;             /* bf16 [M][K], row stride ldx */
+    void* work;                /* float [work_floats] */
+    int64_t M, work_floats;
+    int32_t N, K, ldy, ldx, want_bias, splits;
+} ClvWgradEntry;
+int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n);
+int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream);
 int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
 int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);
 

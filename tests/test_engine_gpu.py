@@ -46,8 +46,10 @@ def test_engine_matches_torch_adamw_and_clip():
     for n, p in named:
         d = (p1[n].detach() - p.detach()).abs().max().item()
         worst = max(worst, d / (p.detach().abs().max().item() + 1e-6))
-    # identical math on bf16-noisy gradients: Adam's sign-like update makes tiny grads flip, so compare loosely
-    assert worst < 0.1, worst
+    # identical math on bf16-noisy gradients: Adam's sign-like update makes tiny grads flip — the key part of a q|k|v
+    # bias has a mathematically ZERO gradient (softmax is invariant to it), so its update is pure rounding noise and two
+    # correct implementations may move it in opposite directions: 2 * 3 steps * lr = 6e-3 on parameters of size 0.05
+    assert worst < 0.13, worst
 
 
 def test_engine_lr_mult_and_fractional_decay_match_torch_param_groups():

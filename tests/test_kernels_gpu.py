@@ -485,6 +485,34 @@ def test_linear_and_mlp_on_the_hip_gemm(M, C, Hd):
     assert rel(xg2.grad, xr2.grad) < 2e-2 and rel(wg.grad, wr.grad) < 2e-2 and rel(bg.grad, br.grad) < 2e-2
 
 
+def test_grouped_weight_gradients_and_batched_fold():
+    """ops.defer_folds(): the weight gradients of several Linear layers as ONE grouped launch + one batched fold must
+    equal the fp32 reference of each (ragged M, N, K; with and without bias; gradients ACCUMULATED into the sinks)."""
+    shapes = [(12544, 384, 384, True), (3136, 768, 768, True), (50176, 192, 96, False), (2000, 136, 104, True),
+              (1500, 768, 3072, True), (200704 // 8, 96, 288, True)]
+    probs = []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dy = rnd(M, N, seed=400 + i).to(BF)
+        x = rnd(M, K, seed=420 + i).to(BF)
+        dw0 = rnd(N, K, seed=440 + i)
+        db0 = rnd(N, seed=460 + i) if bias else None
+        probs.append((dy, x, dw0, db0))
+    sinks = []
+    with ops().defer_folds():
+        for dy, x, dw0, db0 in probs:
+            dw, db = dw0.clone().to(DEV), (db0.clone().to(DEV) if db0 is not None else None)
+            r = ops().linear_wgrad(dy.to(DEV), x.to(DEV), db is not None, dw, db)
+            assert r == (None, None)
+            sinks.append((dw, db))
+        assert len(ops().WGRAD_DEFER) == 4                  # deferred, not launched yet (the two mid-size M shapes take
+                                                            # the library path at once)
+    for (dy, x, dw0, db0), (dw, db) in zip(probs, sinks):
+        ref = dw0 + dy.float().t() @ x.float()
+        assert rel(dw, ref) < 2e-5
+        if db0 is not None:
+            assert rel(db, db0 + dy.float().sum(0)) < 2e-5
+
+
 def test_transpose_batch():
     shapes = [(384, 1536), (96, 288), (100, 72), (64, 64), (30522 // 6, 768), (7, 5)]
     src = torch.zeros(sum(r * c for r, c in shapes) + 64, dtype=BF)
