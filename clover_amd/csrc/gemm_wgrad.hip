@@ -337,7 +337,7 @@ __device__ __forceinline__ void dma4(unsigned lds_wave_base, unsigned voff_y0, u
         : "memory", "scc");
 }
 
-template <bool ACCUM>
+template <bool ACCUM, bool RMW = false>
 __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], const int bid,
                                                 const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                 float* __restrict__ out, float* __restrict__ out_b, int64_t M, int N, int K,
@@ -345,7 +345,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
                                                 int64_t rows_per_split, int want_bias, int xcd_rot = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     int split, tile;
-    if (nsplits > 0) {                                                       // see wgrad_dma_kernel
+    if (nsplits > 0 && xcd_rot >= 0) {                                       // see wgrad_dma_kernel
         const int xcd = (bid - xcd_rot) & 7, xslot = bid >> 3;               // grouped launches rotate the XCDs per problem
         split = xcd + 8 * (xslot / tiles);
         tile = xslot % tiles;
@@ -353,6 +353,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
     } else {
         split = bid / tiles;
         tile = bid - split * tiles;
+        if (nsplits > 0 && split >= nsplits) return;                         // a grouped problem's padding blocks
     }
     const int tn = tile / tilesK, tk = tile - tn * tilesK;
     const int n0 = tn * TN, k0 = tk * TK;
@@ -443,9 +444,9 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = ACCUM ? mfma16(a[i], b[j], acc[i][j])      // D[n][k]: atomics coalesce along k across lanes
-                                  : mfma16(b[j], a[i], acc[i][j]);     // swapped, D[k][n]: 4 consecutive k per lane
-            if (do_bias) bacc[i] = ACCUM ? mfma16(a[i], ones, bacc[i]) : mfma16(ones, a[i], bacc[i]);
+                acc[i][j] = (ACCUM && !RMW) ? mfma16(a[i], b[j], acc[i][j])   // D[n][k]: atomics coalesce along k across lanes
+                                            : mfma16(b[j], a[i], acc[i][j]);  // swapped, D[k][n]: 4 consecutive k per lane
+            if (do_bias) bacc[i] = (ACCUM && !RMW) ? mfma16(a[i], ones, bacc[i]) : mfma16(ones, a[i], bacc[i]);
         }
     };
 
@@ -490,7 +491,31 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
     wait_vm<0>();
     float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
     float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
-    if (ACCUM) {
+    if (ACCUM && RMW) {
+        // one M-slice: this workgroup is the only writer of its dW elements in this launch (and the engine orders the
+        // launches that share a parameter), so "+=" is a 16-byte load / add / store per lane in the swapped layout —
+        // 2 x 4 B of traffic per element instead of a memory-side atomic each (~190 G/s: 12 us for a 768 x 3072 matrix)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn + i * 16 + lr;
+            if (n >= N) continue;
+            float4 old[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + j * 16 + lg * 4;
+                if (k < K) old[j] = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wk + j * 16 + lg * 4;
+                if (k < K)
+                    *reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]) =
+                        make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2],
+                                    old[j].w + acc[i][j][3]);
+            }
+            if (do_bias && lg == 0) pb[n] += bacc[i][0];
+        }
+    } else if (ACCUM) {
         // acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]: this workgroup is the only writer of the
         // element; the no-return L2 atomic is a fire-and-forget "+=", one instruction = 4 rows x 64 contiguous bytes
 #pragma unroll
@@ -525,7 +550,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
     }
 }
 
-template <bool ACCUM>
+template <bool ACCUM, bool RMW = false>
 __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
                                                                    const bf16_t* __restrict__ x,
                                                                    float* __restrict__ out, float* __restrict__ out_b,
@@ -533,7 +558,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t*
                                                                    int tilesK, int nsplits, int64_t rows_per_split,
                                                                    int want_bias) {
     __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];   // [slot][dY | X]
-    wgrad_dma2_body<ACCUM>(ring, blockIdx.x, dy, x, out, out_b, M, N, K, ldy, ldx, tiles, tilesK, nsplits, rows_per_split,
+    wgrad_dma2_body<ACCUM, RMW>(ring, blockIdx.x, dy, x, out, out_b, M, N, K, ldy, ldx, tiles, tilesK, nsplits, rows_per_split,
                            want_bias);
 }
 
@@ -759,7 +784,10 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
             else
                 hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
                                    M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
-        } else if (atomic_acc) {           // few M-slices: accumulate straight into dW / db, no partials, no fold
+        } else if (atomic_acc && splits == 1 && !getenv("CLV_WGRAD_NORMW")) {   // one M-slice: dW += in place, no fold
+            hipLaunchKernelGGL((wgrad_dma2_kernel<true, true>), dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+                               (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
+        } else if (atomic_acc) {           // A/B switches: atomics straight into dW / db
             hipLaunchKernelGGL(wgrad_dma2_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
                                (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else {
@@ -828,7 +856,11 @@ extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void
 static int group_splits(int64_t M, int tiles, int n) {
     int64_t target = 2048 / (n > 0 ? n : 1);
     if (target < 64) target = 64;
+    static const int env_target = getenv("CLV_WGRAD_GROUP_TARGET") ? atoi(getenv("CLV_WGRAD_GROUP_TARGET")) : 0;
+    static const int env_rows = getenv("CLV_WGRAD_GROUP_ROWS") ? atoi(getenv("CLV_WGRAD_GROUP_ROWS")) : 0;
+    if (env_target > 0) target = env_target;
     int64_t s = (target + tiles - 1) / tiles;
+    if (env_rows > 0) s = (M + env_rows - 1) / env_rows;
     const int64_t max_by_rows = (M + 255) / 256;
     if (s > max_by_rows) s = max_by_rows;
     if (s < 1) s = 1;
@@ -870,10 +902,10 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
         // from that L2 — without this a grouped launch ran at the Infinity-Cache rate (6.9 TB/s of LDS-DMA traffic).
         // Slices beyond nsplits exit at once; the XCD a problem's first slice uses rotates with the slices placed so far.
         const bool xcd_map = p.tiles >= 2;
-        p.nsplits = xcd_map ? e.splits : -1;
+        p.nsplits = e.splits;
         p.want_bias = e.want_bias;
         p.block_begin = blocks;
-        p.xcd_rot = rot & 7;
+        p.xcd_rot = xcd_map ? (rot & 7) : -1;                // -1: plain (slice-major) block order
         if (xcd_map) rot += e.splits;
         int g = xcd_map ? 8 * p.tiles * ((e.splits + 7) / 8) : p.tiles * e.splits;
         blocks += (g + 7) / 8 * 8;                           // keep every problem's block ids aligned to the 8 XCDs
