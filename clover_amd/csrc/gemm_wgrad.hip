@@ -571,9 +571,10 @@ constexpr int WG_GROUP_MAX = 40;
 struct WgProblem {
     const bf16_t* dy;
     const bf16_t* x;
-    float* work;
+    float* work;                                             // partials, or dW itself (in_place)
+    float* db;                                               // in_place only
     int64_t M, rows_per_split;
-    int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin, xcd_rot;
+    int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin, xcd_rot, in_place, pad;
 };
 struct WgGroup {
     WgProblem p[WG_GROUP_MAX];
@@ -585,8 +586,14 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_group_kernel(WgGroup
     for (int i = 1; i < grp.n; ++i)
         if ((int)blockIdx.x >= grp.p[i].block_begin) idx = i;
     const WgProblem& pr = grp.p[idx];
-    wgrad_dma2_body<false>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M, pr.N, pr.K, pr.ldy,
-                           pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias, pr.xcd_rot);
+    if (pr.in_place)                                         // few-row problems: one slice, dW += in place
+        wgrad_dma2_body<true, true>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N, pr.K,
+                                    pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
+                                    pr.xcd_rot);
+    else
+        wgrad_dma2_body<false>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M, pr.N, pr.K,
+                               pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
+                               pr.xcd_rot);
 }
 
 // dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N): a thread owns 4 consecutive e (16-byte
@@ -873,6 +880,11 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
         ClvWgradEntry& e = entries[i];
         if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
         const int tiles = ((e.N + TN - 1) / TN) * ((e.K + TK - 1) / TK);
+        if (e.M <= 1024) {                                   // few rows: one slice accumulated straight into dw / db
+            e.splits = 1;
+            e.work_floats = 0;
+            continue;
+        }
         e.splits = group_splits(e.M, tiles, n);
         e.work_floats = (int64_t)e.splits * ((int64_t)e.N * e.K + e.N);
     }
@@ -886,12 +898,17 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
     int blocks = 0, rot = 0;
     for (int i = 0; i < n; ++i) {
         const ClvWgradEntry& e = entries[i];
-        if (!e.dy || !e.x || !e.work || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7)) return CLV_ERR_ARG;
+        const bool in_place = e.work_floats == 0;
+        if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7)) return CLV_ERR_ARG;
+        if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
         WgProblem& p = grp.p[i];
         const int tilesN = (e.N + TN - 1) / TN, tilesK = (e.K + TK - 1) / TK;
         p.dy = (const bf16_t*)e.dy;
         p.x = (const bf16_t*)e.x;
-        p.work = (float*)e.work;
+        p.work = in_place ? e.dw : (float*)e.work;
+        p.db = in_place ? e.db : nullptr;
+        p.in_place = in_place;
+        p.pad = 0;
         p.M = e.M;
         p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
         p.tiles = tilesN * tilesK;
@@ -901,7 +918,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
         // The tiles of one M-slice always share an XCD (consecutive slots of it), so the dY / X rows they all read come
         // from that L2 — without this a grouped launch ran at the Infinity-Cache rate (6.9 TB/s of LDS-DMA traffic).
         // Slices beyond nsplits exit at once; the XCD a problem's first slice uses rotates with the slices placed so far.
-        const bool xcd_map = p.tiles >= 2;
+        const bool xcd_map = p.tiles >= 2 && !in_place;      // one slice: its tiles over all XCDs
         p.nsplits = e.splits;
         p.want_bias = e.want_bias;
         p.block_begin = blocks;

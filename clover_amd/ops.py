@@ -128,7 +128,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         xstats = None
     if _wgrad_custom(M, N, K):
         L = _lib.lib()
-        if WGRAD_DEFER is not None and sink and xstats is None and PROF is None and M > 1024:
+        if WGRAD_DEFER is not None and sink and xstats is None and PROF is None:
             # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
             # backward segment (dy2 / x2 stay alive in the list until then)
             WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K))
@@ -202,16 +202,31 @@ def flush_wgrads(pending):
     fold entries of their partials."""
     folds = []
     L = _lib.lib()
-    for i in range(0, len(pending), _lib.WGRAD_GROUP_MAX):
-        chunk = pending[i:i + _lib.WGRAD_GROUP_MAX]
+    # few-row problems (M <= 1024) add into dW in place, without atomics: two of them with the SAME dW (a Linear applied
+    # twice in the segment) must not share a launch
+    chunks, cur, seen = [], [], set()
+    for item in pending:
+        key = item[2].data_ptr() if item[4] <= 1024 else None
+        if len(cur) == _lib.WGRAD_GROUP_MAX or (key is not None and key in seen):
+            chunks.append(cur)
+            cur, seen = [], set()
+        cur.append(item)
+        if key is not None:
+            seen.add(key)
+    if cur:
+        chunks.append(cur)
+    for chunk in chunks:
         arr = (_lib.ClvWgradEntry * len(chunk))()
         for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
             e.dy, e.x, e.M, e.N, e.K = dy2.data_ptr(), x2.data_ptr(), M, N, K
             e.ldy, e.ldx, e.want_bias = dy2.stride(0), x2.stride(0), int(db is not None)
         check(L.clv_linear_wgrad_batch_plan(arr, len(chunk)), 'clv_linear_wgrad_batch_plan')
-        work = torch.empty(sum(e.work_floats for e in arr), device=chunk[0][0].device, dtype=torch.float32)
+        work = torch.empty(max(1, sum(e.work_floats for e in arr)), device=chunk[0][0].device, dtype=torch.float32)
         off = 0
         for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
+            if e.work_floats == 0:                   # few-row problem: accumulated in place, nothing to fold
+                e.dw, e.db = dw.data_ptr(), (db.data_ptr() if db is not None else None)
+                continue
             w = work[off:off + e.work_floats]
             e.work = w.data_ptr()
             folds.append((w, dw, db, N, K, e.splits))

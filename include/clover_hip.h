@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 3
+#define CLV_ABI_VERSION 4
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -228,6 +228,8 @@ typedef struct ClvWgradEntry {
     const void* dy;            /* bf16 [M][N], row stride ldy */
     const void* x;             /* bf16 [M][K], row stride ldx */
     void* work;                /* float [work_floats] */
+    float* dw;                 /* work_floats == 0 only (few-row problems, M <= 1024: one slice, no partials, no fold): */
+    float* db;                 /*   float [N][K] / [N] (or NULL) gradients, accumulated in place                        */
     int64_t M, work_floats;
     int32_t N, K, ldy, ldx, want_bias, splits;
 } ClvWgradEntry;

@@ -489,7 +489,8 @@ def test_grouped_weight_gradients_and_batched_fold():
     """ops.defer_folds(): the weight gradients of several Linear layers as ONE grouped launch + one batched fold must
     equal the fp32 reference of each (ragged M, N, K; with and without bias; gradients ACCUMULATED into the sinks)."""
     shapes = [(12544, 384, 384, True), (3136, 768, 768, True), (50176, 192, 96, False), (2000, 136, 104, True),
-              (1500, 768, 3072, True), (200704 // 8, 96, 288, True)]
+              (1500, 768, 3072, True), (200704 // 8, 96, 288, True),
+              (512, 768, 3072, True), (512, 3072, 768, False), (1000, 264, 200, True), (77, 136, 72, True)]   # few rows: in place
     probs = []
     for i, (M, N, K, bias) in enumerate(shapes):
         dy = rnd(M, N, seed=400 + i).to(BF)
@@ -504,13 +505,30 @@ def test_grouped_weight_gradients_and_batched_fold():
             r = ops().linear_wgrad(dy.to(DEV), x.to(DEV), db is not None, dw, db)
             assert r == (None, None)
             sinks.append((dw, db))
-        assert len(ops().WGRAD_DEFER) == 4                  # deferred, not launched yet (the two mid-size M shapes take
+        assert len(ops().WGRAD_DEFER) == 8                  # deferred, not launched yet (the two mid-size M shapes take
                                                             # the library path at once)
     for (dy, x, dw0, db0), (dw, db) in zip(probs, sinks):
         ref = dw0 + dy.float().t() @ x.float()
         assert rel(dw, ref) < 2e-5
         if db0 is not None:
             assert rel(db, db0 + dy.float().sum(0)) < 2e-5
+
+
+def test_grouped_weight_gradients_shared_sink():
+    """A Linear applied twice in one backward segment: both few-row weight gradients add into the SAME dW / db in place
+    (no atomics) — flush_wgrads must not put them into one launch.  Plus a many-row use of the same weight (partials)."""
+    N, K = 768, 768
+    dw0, db0 = rnd(N, K, seed=480), rnd(N, seed=481)
+    dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
+    ref_w, ref_b = dw0.clone(), db0.clone()
+    with ops().defer_folds():
+        for i, M in enumerate((512, 512, 640, 3136)):
+            dy, x = rnd(M, N, seed=482 + i).to(BF), rnd(M, K, seed=490 + i).to(BF)
+            assert ops().linear_wgrad(dy.to(DEV), x.to(DEV), True, dw, db) == (None, None)
+            ref_w += dy.float().t() @ x.float()
+            ref_b += dy.float().sum(0)
+        assert len(ops().WGRAD_DEFER) == 4
+    assert rel(dw, ref_w) < 2e-5 and rel(db, ref_b) < 2e-5
 
 
 def test_transpose_batch():
