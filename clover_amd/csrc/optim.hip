@@ -158,9 +158,12 @@ __global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, c
     }
 }
 
-int grid_for(int64_t n4) {
+// Streaming kernels: ONE float4 per thread for the optimizer update (160 M parameters: 785 us = 6.1 TB/s of its 30 B per
+// parameter, against 930-1050 us for 2048 persistent blocks striding 8 MB apart — tools/probes/adam_rate.py); the
+// norm kernel ends in one atomic per block and keeps a bounded grid.
+int grid_for(int64_t n4, int64_t cap = (1 << 20)) {
     int64_t b = (n4 + 255) / 256;
-    if (b > 2048) b = 2048;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -173,7 +176,8 @@ extern "C" int clv_sumsq(const float* g, float* acc, int64_t n, void* stream) {
     if (!g || !acc || n < 0) return CLV_ERR_ARG;
     if (n == 0) return CLV_OK;
     if (((uintptr_t)g) & 15) return CLV_ERR_ARG;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, acc, n);
+    static const int sumsq_cap = getenv("CLV_SUMSQ_GRID") ? atoi(getenv("CLV_SUMSQ_GRID")) : 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4, sumsq_cap)), dim3(256), 0, (hipStream_t)stream, g, acc, n);
     return clv_check_launch();
 }
 
