@@ -596,6 +596,219 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_group_kernel(WgGroup
                                pr.xcd_rot);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide-tile version of the grouped kernel: a (128 PN) x (128 PK) output tile per workgroup of 4 PN PK waves (each wave
+// still 64 x 64), stage = PN + PK panels of [32 rows][128 columns] (8 KiB each, same swizzle), ring of BIG_RING slots
+// in dynamic LDS.  The 128 x 128 kernel re-reads every dY / X row once per tile that needs it; in a grouped launch the
+// tiles of a slice drift apart on their XCD (L2 hit rate 40 %, 4.2 GB fetched for 2.2 GB of operands) and the launch
+// runs at the fabric rate: identical time with the MFMAs removed (tools/probes/wgrad_group.py, build_wg_variants.sh).
+// A 256 x 256 tile moves half the bytes per MFMA and has a quarter of the tiles to keep in step.
+constexpr int BIG_RING = 4;
+__device__ __forceinline__ void dma1(unsigned lds_byte, unsigned voff, const bf16_t* base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[b]\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [lds] "s"(lds_byte), [v] "v"(voff), [b] "s"(base)
+                 : "memory");
+}
+
+template <int PN, int PK, bool ACCUM>
+__device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bid, const bf16_t* __restrict__ dy,
+                                               const bf16_t* __restrict__ x, float* __restrict__ out,
+                                               float* __restrict__ out_b, int64_t M, int N, int K, int ldy, int ldx,
+                                               int tiles, int tilesK, int nsplits, int64_t rows_per_split, int want_bias,
+                                               int xcd_rot) {
+    constexpr int P = PN + PK, W = 4 * PN * PK, IPW = 8 * P / W, GB = 2 * PK, R = BIG_RING;
+    // LDS image: [panel][slot][8 KiB] — a wave's transpose reads of all slots then lie within the 64 KiB reach of the
+    // ds immediate offset from ONE address register (slot-major order needed a register set per slot: spills)
+    constexpr int SLOT = 8192;                               // bytes between the slots of one panel
+    static_assert(8 * P % W == 0, "DMA instructions must divide evenly over the waves");
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, lr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                // scalar: piece tables, panel choices
+    int split, tile;
+    if (xcd_rot >= 0) {
+        const int xcd = (bid - xcd_rot) & 7, xslot = bid >> 3;
+        split = xcd + 8 * (xslot / tiles);
+        tile = xslot % tiles;
+    } else {
+        split = bid / tiles;
+        tile = bid - split * tiles;
+    }
+    if (split >= nsplits) return;
+    const int tn = tile / tilesK, tk = tile - tn * tilesK;
+    const int n0 = tn * 128 * PN, k0 = tk * 128 * PK;
+    const int wa = wave / GB, wb = wave - wa * GB;           // this wave's 64 x 64 block of the tile
+    const int wn = wa * 64, wk = wb * 64;
+    const int64_t m_begin = (int64_t)split * rows_per_split;
+    int64_t m_end = m_begin + rows_per_split;
+    if (m_end > M) m_end = M;
+    const bool do_bias = want_bias && tk == 0 && wb == 0;
+    const int rows = (int)(m_end - m_begin);
+    const int nst = (rows + SM - 1) / SM;
+    const int nfull = rows / SM;
+
+    // this wave's IPW pieces of a stage: piece q = wave * IPW + e -> panel q >> 3, rows (q & 7) * 4 .. + 4 of it
+    unsigned voff[IPW], loff[IPW];
+    int rowe[IPW];
+    bool isx[IPW];
+#pragma unroll
+    for (int e = 0; e < IPW; ++e) {
+        const int q = wave * IPW + e, panel = q >> 3, sub = q & 7;
+        const int r = sub * 4 + (lane >> 4), c = ((lane & 15) ^ ((r & 7) << 1)) * 8;
+        rowe[e] = r;
+        isx[e] = panel >= PN;
+        loff[e] = (unsigned)(panel * R * 8192 + sub * 1024);
+        if (panel < PN) {
+            int col = n0 + panel * 128 + c;
+            col = col < N ? col : N - 8;
+            voff[e] = (unsigned)((r * ldy + col) * 2);
+        } else {
+            int col = k0 + (panel - PN) * 128 + c;
+            col = col < K ? col : K - 8;
+            voff[e] = (unsigned)((r * ldx + col) * 2);
+        }
+    }
+    const bf16_t* by = dy + m_begin * ldy;
+    const bf16_t* bx = x + m_begin * ldx;
+    const int64_t step_y = (int64_t)SM * ldy, step_x = (int64_t)SM * ldx;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    int issued = 0;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+    auto issue_slow = [&](int slot) {
+        if (issued < nst) {
+#pragma unroll
+            for (int e = 0; e < IPW; ++e) {
+                const bool in = issued * SM + rowe[e] < rows;
+                const char* base = reinterpret_cast<const char*>(isx[e] ? bx : by);
+                dma16(in ? reinterpret_cast<const bf16_t*>(base + voff[e]) : zero, lds0 + (unsigned)(slot * SLOT) + loff[e]);
+            }
+            by += step_y;
+            bx += step_x;
+        }
+        ++issued;
+    };
+
+    f32x4_t acc[4][4];
+    // bias on the VALU (registers are what limits this kernel at 4 waves per SIMD: an MFMA against all-ones costs 20):
+    // a lane's dY fragment of block i is 8 rows of ONE column; the 4 lane groups meet at the end
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read offsets (bf16 elements) inside this wave's dY / X panel, as in wgrad_dma2_body
+    int ry[4], rx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lg * 4 + (lr >> 2);
+        ry[i] = (wa >> 1) * R * 4096 + r * 128 + ((((((wa & 1) * 64 + i * 16) >> 4) ^ (r & 7)) << 4) | ((lr & 3) << 2));
+        rx[i] = (PN + (wb >> 1)) * R * 4096 + r * 128 + ((((((wb & 1) * 64 + i * 16) >> 4) ^ (r & 7)) << 4) | ((lr & 3) << 2));
+    }
+    auto tr = [](const bf16_t* p) {
+        const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+        union { v4s_t v; uint2 u; } cv;
+        cv.v = v;
+        return cv.u;
+    };
+    auto compute = [&](const bf16_t* S) {
+        Frag8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i].u2[0] = tr(S + ry[i]);
+            a[i].u2[1] = tr(S + ry[i] + 16 * 128);
+            b[i].u2[0] = tr(S + rx[i]);
+            b[i].u2[1] = tr(S + rx[i] + 16 * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // swapped: 4 consecutive k per lane
+            if (do_bias) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    bsum[i] += __uint_as_float(a[i].u[u] << 16) + __uint_as_float(a[i].u[u] & 0xffff0000u);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d) issue_slow(d);
+    int st = 0;
+    for (; issued + R <= nfull; st += R, issued += R) {
+#pragma unroll
+        for (int sl = 0; sl < R; ++sl) {
+            wait_vm<(R - 2) * IPW>();
+            __builtin_amdgcn_s_barrier();
+#ifndef WG_ABL_NODMA
+#pragma unroll
+            for (int e = 0; e < IPW; ++e)
+                dma1(lds0 + (unsigned)(((sl + R - 1) % R) * SLOT) + loff[e], voff[e], isx[e] ? bx : by);
+#endif
+            by += step_y;
+            bx += step_x;
+#ifndef WG_ABL_NOCOMPUTE
+            compute(reinterpret_cast<const bf16_t*>(smem + sl * SLOT));
+#endif
+        }
+    }
+    int slot = 0;
+    for (; st < nst; ++st) {
+        if (issued - st == R - 1 && issued <= nst) wait_vm<(R - 2) * IPW>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_slow(slot == 0 ? R - 1 : slot - 1);
+        compute(reinterpret_cast<const bf16_t*>(smem + slot * SLOT));
+        slot = slot == R - 1 ? 0 : slot + 1;
+    }
+    wait_vm<0>();
+    float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
+    float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn + i * 16 + lr;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk + j * 16 + lg * 4;
+            if (k >= K) continue;
+            float4* dst = reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]);
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (ACCUM) {
+                const float4 o = *dst;
+                v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+            }
+            *dst = v;
+        }
+        if (do_bias) {
+            const float bs = grp4_sum(bsum[i]);
+            if (lg == 0) {
+                if (ACCUM) pb[n] += bs;
+                else pb[n] = bs;
+            }
+        }
+    }
+}
+
+template <int PN, int PK>
+__global__ void __launch_bounds__(256 * PN * PK) wgrad_big_group_kernel(WgGroup grp) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char big_smem[];
+    int idx = 0;
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) idx = i;
+    const WgProblem& pr = grp.p[idx];
+    if (pr.in_place)
+        wgrad_big_body<PN, PK, true>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N,
+                                     pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
+                                     pr.want_bias, pr.xcd_rot);
+    else
+        wgrad_big_body<PN, PK, false>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M,
+                                      pr.N, pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
+                                      pr.want_bias, pr.xcd_rot);
+}
+
 // dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N): a thread owns 4 consecutive e (16-byte
 // loads, every wave load 1 KiB contiguous) for every SG-th slice, 4 loads in flight; the SG (1, 4 or 16) slice-lanes of
 // an element group are 64 threads apart and meet in LDS.  SG grows as the matrix shrinks, so that the launch has enough
@@ -860,9 +1073,11 @@ extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void
 
 // Slices of one problem inside a grouped launch of n problems: enough workgroups in total (~8 per CU) rather than per
 // problem, at least 256 rows per slice.
-static int group_splits(int64_t M, int tiles, int n) {
-    int64_t target = 2048 / (n > 0 ? n : 1);
-    if (target < 64) target = 64;
+static int group_splits(int64_t M, int tiles, int n, int cls = 0) {
+    int64_t target = (cls ? 1024 : 2048) / (n > 0 ? n : 1);
+    if (target < (cls ? 24 : 64)) target = cls ? 24 : 64;
+    static const int env_big = getenv("CLV_WGRAD_BIG_TARGET") ? atoi(getenv("CLV_WGRAD_BIG_TARGET")) : 0;
+    if (cls && env_big > 0) target = env_big;
     static const int env_target = getenv("CLV_WGRAD_GROUP_TARGET") ? atoi(getenv("CLV_WGRAD_GROUP_TARGET")) : 0;
     static const int env_rows = getenv("CLV_WGRAD_GROUP_ROWS") ? atoi(getenv("CLV_WGRAD_GROUP_ROWS")) : 0;
     if (env_target > 0) target = env_target;
@@ -874,18 +1089,42 @@ static int group_splits(int64_t M, int tiles, int n) {
     return (int)s;
 }
 
+// Tile class of a grouped problem: 1 = 256 x 256 tiles (wgrad_big_group_kernel<2, 2>: half the staged bytes per MFMA)
+// for outputs that such tiles cover without overhang; everything else keeps 128 x 128 tiles — with overhang the wide
+// tiles spend 30-80 % more MFMA / LDS time on clamped columns, and the compute side alone (479 us of the 760 us launch)
+// then exceeds what the DMA side saves (measured: 813 us with every shape that staged >= 20 % fewer bytes on wide tiles).
+static int wg_class(int N, int K) {
+    static const int big = getenv("CLV_WGRAD_BIG") ? atoi(getenv("CLV_WGRAD_BIG")) : 1;
+    return big && N % 256 == 0 && K % 256 == 0;
+}
+// One M-slice accumulated straight into dW / db (no partials, no fold): few rows, or an output so large that every extra
+// slice costs more partial traffic (write + fold read of N x K floats) than it saves in workgroup length.
+static bool wg_in_place(int64_t M, int N, int K) {
+    return M <= 1024 || (wg_class(N, K) == 1 && (int64_t)N * K > (1 << 20));
+}
+extern "C" int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K) { return wg_in_place(M, N, K) ? 1 : 0; }
+static int wg_tiles(int N, int K, int cls) {
+    const int t = cls ? 256 : 128;
+    return ((N + t - 1) / t) * ((K + t - 1) / t);
+}
+
 extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
+    int ncls[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const ClvWgradEntry& e = entries[i];
+        if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
+        ++ncls[wg_class(e.N, e.K)];
+    }
     for (int i = 0; i < n; ++i) {
         ClvWgradEntry& e = entries[i];
-        if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
-        const int tiles = ((e.N + TN - 1) / TN) * ((e.K + TK - 1) / TK);
-        if (e.M <= 1024) {                                   // few rows: one slice accumulated straight into dw / db
+        const int cls = wg_class(e.N, e.K);
+        if (wg_in_place(e.M, e.N, e.K)) {
             e.splits = 1;
             e.work_floats = 0;
             continue;
         }
-        e.splits = group_splits(e.M, tiles, n);
+        e.splits = group_splits(e.M, wg_tiles(e.N, e.K, cls), ncls[cls], cls);
         e.work_floats = (int64_t)e.splits * ((int64_t)e.N * e.K + e.N);
     }
     return CLV_OK;
@@ -894,40 +1133,58 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
 extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
     static_assert(sizeof(WgGroup) <= 4000, "kernel-argument budget");
-    WgGroup grp;
-    int blocks = 0, rot = 0;
-    for (int i = 0; i < n; ++i) {
-        const ClvWgradEntry& e = entries[i];
-        const bool in_place = e.work_floats == 0;
-        if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7)) return CLV_ERR_ARG;
-        if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
-        WgProblem& p = grp.p[i];
-        const int tilesN = (e.N + TN - 1) / TN, tilesK = (e.K + TK - 1) / TK;
-        p.dy = (const bf16_t*)e.dy;
-        p.x = (const bf16_t*)e.x;
-        p.work = in_place ? e.dw : (float*)e.work;
-        p.db = in_place ? e.db : nullptr;
-        p.in_place = in_place;
-        p.pad = 0;
-        p.M = e.M;
-        p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
-        p.tiles = tilesN * tilesK;
-        p.tilesK = tilesK;
-        int64_t rows = (e.M + e.splits - 1) / e.splits;
-        p.rows_per_split = (rows + TM - 1) / TM * TM;
-        // The tiles of one M-slice always share an XCD (consecutive slots of it), so the dY / X rows they all read come
-        // from that L2 — without this a grouped launch ran at the Infinity-Cache rate (6.9 TB/s of LDS-DMA traffic).
-        // Slices beyond nsplits exit at once; the XCD a problem's first slice uses rotates with the slices placed so far.
-        const bool xcd_map = p.tiles >= 2 && !in_place;      // one slice: its tiles over all XCDs
-        p.nsplits = e.splits;
-        p.want_bias = e.want_bias;
-        p.block_begin = blocks;
-        p.xcd_rot = xcd_map ? (rot & 7) : -1;                // -1: plain (slice-major) block order
-        if (xcd_map) rot += e.splits;
-        int g = xcd_map ? 8 * p.tiles * ((e.splits + 7) / 8) : p.tiles * e.splits;
-        blocks += (g + 7) / 8 * 8;                           // keep every problem's block ids aligned to the 8 XCDs
+    for (int cls = 0; cls < 2; ++cls) {
+        WgGroup grp;
+        int blocks = 0, rot = 0, cnt = 0;
+        const int T = cls ? 256 : 128;
+        for (int i = 0; i < n; ++i) {
+            const ClvWgradEntry& e = entries[i];
+            const bool in_place = e.work_floats == 0;
+            if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7) || e.N <= 0 || e.K <= 0) return CLV_ERR_ARG;
+            if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
+            if (wg_class(e.N, e.K) != cls) continue;
+            WgProblem& p = grp.p[cnt++];
+            const int tilesN = (e.N + T - 1) / T, tilesK = (e.K + T - 1) / T;
+            p.dy = (const bf16_t*)e.dy;
+            p.x = (const bf16_t*)e.x;
+            p.work = in_place ? e.dw : (float*)e.work;
+            p.db = in_place ? e.db : nullptr;
+            p.in_place = in_place;
+            p.pad = 0;
+            p.M = e.M;
+            p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
+            p.tiles = tilesN * tilesK;
+            p.tilesK = tilesK;
+            int64_t rows = (e.M + e.splits - 1) / e.splits;
+            p.rows_per_split = (rows + TM - 1) / TM * TM;
+            // The tiles of one M-slice always share an XCD (consecutive slots of it), so the dY / X rows they all read
+            // come from that L2 — without this a grouped launch ran at the Infinity-Cache rate (6.9 TB/s of LDS-DMA
+            // traffic).  Slices beyond nsplits exit at once; the XCD a problem's first slice uses rotates with the
+            // slices placed so far.
+            const bool xcd_map = p.tiles >= 2 && !in_place;  // one slice: its tiles over all XCDs
+            p.nsplits = e.splits;
+            p.want_bias = e.want_bias;
+            p.block_begin = blocks;
+            p.xcd_rot = xcd_map ? (rot & 7) : -1;            // -1: plain (slice-major) block order
+            if (xcd_map) rot += e.splits;
+            int g = xcd_map ? 8 * p.tiles * ((e.splits + 7) / 8) : p.tiles * e.splits;
+            blocks += (g + 7) / 8 * 8;                       // keep every problem's block ids aligned to the 8 XCDs
+        }
+        if (!cnt) continue;
+        grp.n = cnt;
+        if (cls == 0) {
+            hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(WG_THREADS), 0, (hipStream_t)stream,
+                               grp);
+        } else {
+            constexpr int LDS = BIG_RING * 4 * 8192;
+            static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_group_kernel<2, 2>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+            (void)attr;
+            hipLaunchKernelGGL((wgrad_big_group_kernel<2, 2>), dim3((unsigned)blocks), dim3(1024), LDS,
+                               (hipStream_t)stream, grp);
+        }
+        const int rc = clv_check_launch();
+        if (rc) return rc;
     }
-    grp.n = n;
-    hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(WG_THREADS), 0, (hipStream_t)stream, grp);
-    return clv_check_launch();
+    return CLV_OK;
 }

@@ -112,7 +112,11 @@ def _wgrad_custom(M, N, K):
     """Shapes the split-M kernel takes: token-parallel ones (huge M, small N x K — the library GEMM
     under-fills the chip) and few-row ones (M <= 1024: one M-slice accumulated straight into the fp32
     gradient, replacing library GEMM + fp32 add + column sum)."""
-    return (M >= 2048 and N * K <= (1 << 20) or M <= 1024) and N % 8 == 0 and K % 8 == 0
+    if N % 8 or K % 8:
+        return False
+    if M >= 2048 and N % 256 == 0 and K % 256 == 0 and os.environ.get('CLOVER_WGRAD_WIDE', '1') == '1':
+        return True                        # 256 x 256 tiles in the grouped launch: also the large stage-3 / fusion outputs
+    return M >= 2048 and N * K <= (1 << 20) or M <= 1024
 
 
 def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
@@ -202,11 +206,11 @@ def flush_wgrads(pending):
     fold entries of their partials."""
     folds = []
     L = _lib.lib()
-    # few-row problems (M <= 1024) add into dW in place, without atomics: two of them with the SAME dW (a Linear applied
-    # twice in the segment) must not share a launch
+    # in-place problems (few rows / very large outputs) add into dW without atomics: two of them with the SAME dW (a
+    # Linear applied twice in the segment) must not share a launch
     chunks, cur, seen = [], [], set()
     for item in pending:
-        key = item[2].data_ptr() if item[4] <= 1024 else None
+        key = item[2].data_ptr() if L.clv_linear_wgrad_in_place(item[4], item[5], item[6]) else None
         if len(cur) == _lib.WGRAD_GROUP_MAX or (key is not None and key in seen):
             chunks.append(cur)
             cur, seen = [], set()

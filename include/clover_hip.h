@@ -228,12 +228,15 @@ typedef struct ClvWgradEntry {
     const void* dy;            /* bf16 [M][N], row stride ldy */
     const void* x;             /* bf16 [M][K], row stride ldx */
     void* work;                /* float [work_floats] */
-    float* dw;                 /* work_floats == 0 only (few-row problems, M <= 1024: one slice, no partials, no fold): */
+    float* dw;                 /* work_floats == 0 only (few rows, or a very large output: one slice, no partials, no fold): */
     float* db;                 /*   float [N][K] / [N] (or NULL) gradients, accumulated in place                        */
     int64_t M, work_floats;
     int32_t N, K, ldy, ldx, want_bias, splits;
 } ClvWgradEntry;
 int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n);
+/* 1 if the plan gives this problem work_floats == 0 (one slice added into dw / db in place, without atomics): two such
+ * problems with the SAME dw must not share a clv_linear_wgrad_batch call. */
+int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream);
 int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
 int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);

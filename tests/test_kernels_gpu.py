@@ -490,7 +490,8 @@ def test_grouped_weight_gradients_and_batched_fold():
     equal the fp32 reference of each (ragged M, N, K; with and without bias; gradients ACCUMULATED into the sinks)."""
     shapes = [(12544, 384, 384, True), (3136, 768, 768, True), (50176, 192, 96, False), (2000, 136, 104, True),
               (1500, 768, 3072, True), (200704 // 8, 96, 288, True),
-              (512, 768, 3072, True), (512, 3072, 768, False), (1000, 264, 200, True), (77, 136, 72, True)]   # few rows: in place
+              (512, 768, 3072, True), (512, 3072, 768, False), (1000, 264, 200, True), (77, 136, 72, True),   # few rows: in place
+              (3136, 768, 768, True), (3648, 768, 3072, True), (3136, 2304, 768, False), (2500, 256, 512, True)]   # 256 x 256 tiles
     probs = []
     for i, (M, N, K, bias) in enumerate(shapes):
         dy = rnd(M, N, seed=400 + i).to(BF)
@@ -505,8 +506,8 @@ def test_grouped_weight_gradients_and_batched_fold():
             r = ops().linear_wgrad(dy.to(DEV), x.to(DEV), db is not None, dw, db)
             assert r == (None, None)
             sinks.append((dw, db))
-        assert len(ops().WGRAD_DEFER) == 8                  # deferred, not launched yet (the two mid-size M shapes take
-                                                            # the library path at once)
+        assert len(ops().WGRAD_DEFER) == 12                 # deferred, not launched yet (two shapes take the library path
+                                                            # at once: (1500, 768, 3072) and ... see _wgrad_custom)
     for (dy, x, dw0, db0), (dw, db) in zip(probs, sinks):
         ref = dw0 + dy.float().t() @ x.float()
         assert rel(dw, ref) < 2e-5

@@ -1,4 +1,4 @@
 set -u
-for t in 32 64 128 256; do echo "target $t"; CLV_WGRAD_GROUP_TARGET=$t python tools/probes/wgrad_group.py; done
-for r in 784 1568 3136 6272; do echo "rows $r"; CLV_WGRAD_GROUP_ROWS=$r python tools/probes/wgrad_group.py; done
-echo bigfirst; ORDER=bigfirst python tools/probes/wgrad_group.py
+python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "grouped or wgrad" 2>&1 | tail -2
+for b in 0 1; do echo "BIG=$b"; CLV_WGRAD_BIG=$b python tools/probes/wgrad_group.py 2>&1 | grep problems; done
+for t in 12 24 48 96; do echo "BIG target $t"; CLV_WGRAD_BIG_TARGET=$t python tools/probes/wgrad_group.py 2>&1 | grep problems; done
