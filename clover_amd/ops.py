@@ -175,6 +175,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
 FOLD_DEFER = None           # list while a backward segment defers its weight-gradient folds (defer_folds())
 LN_DEFER = None             # ... and the reductions of its LayerNorm-backward partials
 WGRAD_DEFER = None          # ... and whole weight-gradient launches (grouped into one grid)
+POST_DEFER = None           # ... and what consumes a deferred weight gradient (the LayerNorm un-fold), run after the folds
 
 
 class defer_folds:
@@ -183,20 +184,24 @@ class defer_folds:
     Only for gradients nobody reads before the context closes (the engine wraps whole backward segments)."""
 
     def __enter__(self):
-        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER
         self.prev, FOLD_DEFER = FOLD_DEFER, []
         self.prev_ln, LN_DEFER = LN_DEFER, ([] if os.environ.get('CLOVER_DEFER_LN', '1') == '1' else None)
         self.prev_wg, WGRAD_DEFER = WGRAD_DEFER, ([] if os.environ.get('CLOVER_GROUP_WGRAD', '1') == '1' else None)
+        self.prev_post, POST_DEFER = POST_DEFER, []
         return self
 
     def __exit__(self, *exc):
-        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER
         pending, FOLD_DEFER = FOLD_DEFER, self.prev
         pending_ln, LN_DEFER = LN_DEFER, self.prev_ln
         pending_wg, WGRAD_DEFER = WGRAD_DEFER, self.prev_wg
+        pending_post, POST_DEFER = POST_DEFER, self.prev_post
         if exc[0] is None:
             pending = pending + flush_wgrads(pending_wg or [])
             flush_folds(pending)
+            for fn in pending_post:
+                fn()
             flush_ln_reduces(pending_ln or [])
         return False
 
@@ -443,6 +448,26 @@ def _unfold_grads(dwf, dbf, weight, bias, gamma, beta):
             dbt.to(beta.dtype))
 
 
+def _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta):
+    """Weight gradient of a LayerNorm-folded projection and its un-fold into (d weight, d bias, d gamma, d beta).  Inside
+    defer_folds() with engine-managed parameters both are deferred: the GEMM joins the grouped launch (into a zeroed
+    temporary), the un-fold kernel runs after the folds."""
+    ps = (weight, bias, gamma, beta)
+    if (WGRAD_DEFER is not None and POST_DEFER is not None and xhat is not None and PROF is None
+            and os.environ.get('CLOVER_DEFER_UNFOLD', '1') == '1'
+            and all(getattr(q, '_clv_grad', None) is not None and q._clv_grad.dtype == torch.float32
+                    for q in ps if q is not None)):
+        (M, N), K = dy2.shape, xhat.shape[1]
+        if _wgrad_custom(M, N, K):
+            tmp = torch.zeros(N * K + N, device=dy2.device, dtype=torch.float32)
+            dwf, dbf = tmp[:N * K].view(N, K), tmp[N * K:]
+            WGRAD_DEFER.append((dy2, xhat, dwf, dbf, M, N, K))
+            POST_DEFER.append(lambda: _unfold_grads(dwf, dbf, weight, bias, gamma, beta))
+            return None, None, None, None
+    dwf, dbf = linear_wgrad(dy2, xhat, True) if xhat is not None else linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
+    return _unfold_grads(dwf, dbf, weight, bias, gamma, beta)
+
+
 class _FusedLNLinear(torch.autograd.Function):
     """(y, s) = (Linear(LayerNorm(a [+ r])),  a + r) in ONE row-streaming kernel: residual add, LayerNorm statistics +
     standardisation and the projection, the norm's affine part folded into the weights (swin_transformer_3d.py:450
@@ -475,9 +500,8 @@ class _FusedLNLinear(torch.autograd.Function):
         dxhat = linear_dgrad(dy2, wt)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
         # the forward kept the standardised rows: the weight gradient runs on the LDS-DMA kernel
-        dwf, dbf = linear_wgrad(dy2, xhat, True) if xhat is not None else linear_wgrad(dy2, xs, True, xstats=(mean, rstd))
         weight, bias, gamma, beta = ctx.prefs
-        dw, db, dg, dbt = _unfold_grads(dwf, dbf, weight, bias, gamma, beta)
+        dw, db, dg, dbt = _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None
 
 
@@ -548,9 +572,8 @@ class _FusedMLP(torch.autograd.Function):
         # fc1 + LayerNorm
         dxhat = linear_dgrad(dpre, wt1)
         dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
-        dwf1, dbf1 = linear_wgrad(dpre, xhat, True) if xhat is not None else linear_wgrad(dpre, xs, True, xstats=(mean, rstd))
         w1, b1, gamma, beta = ctx.prefs
-        dw1, db1, dg, dbt = _unfold_grads(dwf1, dbf1, w1, b1, gamma, beta)
+        dw1, db1, dg, dbt = _wgrad_folded(dpre, xhat, xs, mean, rstd, w1, b1, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None
 
 
