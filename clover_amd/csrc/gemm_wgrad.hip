@@ -1093,8 +1093,10 @@ static int group_splits(int64_t M, int tiles, int n, int cls = 0) {
 // for outputs that such tiles cover without overhang; everything else keeps 128 x 128 tiles — with overhang the wide
 // tiles spend 30-80 % more MFMA / LDS time on clamped columns, and the compute side alone (479 us of the 760 us launch)
 // then exceeds what the DMA side saves (measured: 813 us with every shape that staged >= 20 % fewer bytes on wide tiles).
-static int wg_class(int N, int K) {
+static int wg_class(int N, int K, int64_t M = 1 << 20) {
     static const int big = getenv("CLV_WGRAD_BIG") ? atoi(getenv("CLV_WGRAD_BIG")) : 1;
+    static const int small_m = getenv("CLV_WGRAD_BIG_SMALLM") ? atoi(getenv("CLV_WGRAD_BIG_SMALLM")) : 0;   // few-row problems: 128 x 128 tiles (A/B: 0.05 ms better)
+    if (M <= 1024 && !small_m) return 0;
     return big && N % 256 == 0 && K % 256 == 0;
 }
 // One M-slice accumulated straight into dW / db (no partials, no fold): few rows, or an output so large that every extra
@@ -1114,11 +1116,11 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
     for (int i = 0; i < n; ++i) {
         const ClvWgradEntry& e = entries[i];
         if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
-        ++ncls[wg_class(e.N, e.K)];
+        ++ncls[wg_class(e.N, e.K, e.M)];
     }
     for (int i = 0; i < n; ++i) {
         ClvWgradEntry& e = entries[i];
-        const int cls = wg_class(e.N, e.K);
+        const int cls = wg_class(e.N, e.K, e.M);
         if (wg_in_place(e.M, e.N, e.K)) {
             e.splits = 1;
             e.work_floats = 0;
@@ -1142,7 +1144,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
             const bool in_place = e.work_floats == 0;
             if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7) || e.N <= 0 || e.K <= 0) return CLV_ERR_ARG;
             if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
-            if (wg_class(e.N, e.K) != cls) continue;
+            if (wg_class(e.N, e.K, e.M) != cls) continue;
             WgProblem& p = grp.p[cnt++];
             const int tilesN = (e.N + T - 1) / T, tilesK = (e.K + T - 1) / T;
             p.dy = (const bf16_t*)e.dy;
