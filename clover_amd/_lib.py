@@ -92,6 +92,7 @@ SIGNATURES = {
     'clv_layernorm_bwd_needs_reduce': (C.c_int, [_i64, _i32]),
     'clv_ln_reduce_batch': (C.c_int, [_p, _i32, _p]),
     'clv_linear_wgrad_in_place': (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
+    'clv_linear_wgrad_class': (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     'clv_linear_wgrad_batch_plan': (C.c_int, [_p, _i32]),
     'clv_linear_wgrad_batch': (C.c_int, [_p, _i32, _p]),
     'clv_linear_wgrad_splits': (C.c_int, [_i64, _i32, _i32]),

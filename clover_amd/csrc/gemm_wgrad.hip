@@ -1105,6 +1105,7 @@ static bool wg_in_place(int64_t M, int N, int K) {
     return M <= 1024 || (wg_class(N, K) == 1 && (int64_t)N * K > (1 << 20));
 }
 extern "C" int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K) { return wg_in_place(M, N, K) ? 1 : 0; }
+extern "C" int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K) { return wg_class(N, K, M); }
 static int wg_tiles(int N, int K, int cls) {
     const int t = cls ? 256 : 128;
     return ((N + t - 1) / t) * ((K + t - 1) / t);

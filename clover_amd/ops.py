@@ -132,7 +132,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         xstats = None
     if _wgrad_custom(M, N, K):
         L = _lib.lib()
-        if WGRAD_DEFER is not None and sink and xstats is None and PROF is None:
+        if WGRAD_DEFER is not None and sink and xstats is None:
             # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
             # backward segment (dy2 / x2 stay alive in the list until then)
             WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K))
@@ -240,7 +240,16 @@ def flush_wgrads(pending):
             e.work = w.data_ptr()
             folds.append((w, dw, db, N, K, e.splits))
             off += e.work_floats
-        check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
+        if PROF is None:
+            check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
+        else:                                        # one event pair per device kernel: the tile classes one by one
+            for cls, kname in ((0, 'wgrad_dma2_group_kernel'), (1, 'wgrad_big_group_kernel<2, 2>')):
+                sub = [e for e in arr if L.clv_linear_wgrad_class(e.M, e.N, e.K) == cls]
+                if not sub:
+                    continue
+                sarr = (_lib.ClvWgradEntry * len(sub))(*sub)
+                with _Timed(kname, sum(2 * e.M * e.N * e.K for e in sub), sum(e.M * (e.N + e.K) * 2 for e in sub)):
+                    check(L.clv_linear_wgrad_batch(sarr, len(sub), _stream()), 'clv_linear_wgrad_batch')
     return folds
 
 
@@ -453,7 +462,7 @@ def _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta):
     defer_folds() with engine-managed parameters both are deferred: the GEMM joins the grouped launch (into a zeroed
     temporary), the un-fold kernel runs after the folds."""
     ps = (weight, bias, gamma, beta)
-    if (WGRAD_DEFER is not None and POST_DEFER is not None and xhat is not None and PROF is None
+    if (WGRAD_DEFER is not None and POST_DEFER is not None and xhat is not None
             and os.environ.get('CLOVER_DEFER_UNFOLD', '1') == '1'
             and all(getattr(q, '_clv_grad', None) is not None and q._clv_grad.dtype == torch.float32
                     for q in ps if q is not None)):
@@ -1509,6 +1518,8 @@ def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0):
 
 def adamw_step_dev(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay):
     _need_gpu(p, g, m, v, state)
-    check(_lib.lib().clv_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(state), p.numel(),
-                                        float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                        _stream()), 'clv_adamw_step_dev')
+    # algorithmic traffic: p, g, m, v read + p, m, v written (fp32) + the bf16 compute copy
+    with _Timed('adamw_dev_kernel', 12 * p.numel(), (28 + (2 if shadow is not None else 0)) * p.numel()):
+        check(_lib.lib().clv_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(state), p.numel(),
+                                            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                            _stream()), 'clv_adamw_step_dev')

@@ -237,6 +237,9 @@ int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n);
 /* 1 if the plan gives this problem work_floats == 0 (one slice added into dw / db in place, without atomics): two such
  * problems with the SAME dw must not share a clv_linear_wgrad_batch call. */
 int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K);
+/* Tile class clv_linear_wgrad_batch gives the problem: 0 = wgrad_dma2_group_kernel (128 x 128 tiles), 1 =
+ * wgrad_big_group_kernel<2, 2> (256 x 256); one launch per class present in the call. */
+int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream);
 int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
 int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);
