@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const bf16_t* __re
 // and the transpose reads apply the same involution: 32-B pair p of row r lives at pair p ^ (r & 7).
 constexpr int SM = 32;                                    // rows per stage
 constexpr int STAGE = SM * 128;                           // bf16 elements per tensor per stage (8 KiB)
-constexpr int RING = 4;                                   // ring slots (16 KiB each); RING-1 stages in flight
+#ifndef WG_RING
+#define WG_RING 4
+#endif
+constexpr int RING = WG_RING;                             // ring slots (16 KiB each); RING-1 stages in flight
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of out-of-range chunks
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_byte .. +1 KiB), asynchronously.
@@ -475,7 +478,9 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         WG2_STAGE(0)
         WG2_STAGE(1)
         WG2_STAGE(2)
+#if WG_RING == 4
         WG2_STAGE(3)
+#endif
     }
 #undef WG2_STAGE
     // ---- generic tail: at most 2 * RING - 1 stages (the last complete ones, the ragged one, the drain)
@@ -580,7 +585,7 @@ struct WgGroup {
     WgProblem p[WG_GROUP_MAX];
     int n;
 };
-__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_group_kernel(WgGroup grp) {
+__global__ void __launch_bounds__(WG_THREADS, WG_RING == 3 ? 3 : 2) wgrad_dma2_group_kernel(WgGroup grp) {
     __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];
     int idx = 0;
     for (int i = 1; i < grp.n; ++i)
@@ -1096,9 +1101,16 @@ static int group_splits(int64_t M, int tiles, int n, int cls = 0) {
 static int wg_class(int N, int K, int64_t M = 1 << 20) {
     static const int big = getenv("CLV_WGRAD_BIG") ? atoi(getenv("CLV_WGRAD_BIG")) : 1;
     static const int small_m = getenv("CLV_WGRAD_BIG_SMALLM") ? atoi(getenv("CLV_WGRAD_BIG_SMALLM")) : 0;   // few-row problems: 128 x 128 tiles (A/B: 0.05 ms better)
+    static const int rect = getenv("CLV_WGRAD_RECT") ? atoi(getenv("CLV_WGRAD_RECT")) : 0;   // probe: 128 x 256 / 256 x 128 classes (+0.25 ms on the step: two more launches, one 8-wave workgroup per CU)
     if (M <= 1024 && !small_m) return 0;
-    return big && N % 256 == 0 && K % 256 == 0;
+    if (!big) return 0;
+    if (N % 256 == 0 && K % 256 == 0) return 1;
+    if (rect && N % 128 == 0 && K % 256 == 0) return 2;      // 128 x 256 tiles, 8 waves
+    if (rect && N % 256 == 0 && K % 128 == 0) return 3;      // 256 x 128
+    return 0;
 }
+constexpr int WG_CLASSES = 4;
+static const int wg_tn[WG_CLASSES] = {128, 256, 128, 256}, wg_tk[WG_CLASSES] = {128, 256, 256, 128};
 // One M-slice accumulated straight into dW / db (no partials, no fold): few rows, or an output so large that every extra
 // slice costs more partial traffic (write + fold read of N x K floats) than it saves in workgroup length.
 static bool wg_in_place(int64_t M, int N, int K) {
@@ -1107,13 +1119,12 @@ static bool wg_in_place(int64_t M, int N, int K) {
 extern "C" int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K) { return wg_in_place(M, N, K) ? 1 : 0; }
 extern "C" int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K) { return wg_class(N, K, M); }
 static int wg_tiles(int N, int K, int cls) {
-    const int t = cls ? 256 : 128;
-    return ((N + t - 1) / t) * ((K + t - 1) / t);
+    return ((N + wg_tn[cls] - 1) / wg_tn[cls]) * ((K + wg_tk[cls] - 1) / wg_tk[cls]);
 }
 
 extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
-    int ncls[2] = {0, 0};
+    int ncls[WG_CLASSES] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         const ClvWgradEntry& e = entries[i];
         if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
@@ -1136,10 +1147,9 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
 extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
     static_assert(sizeof(WgGroup) <= 4000, "kernel-argument budget");
-    for (int cls = 0; cls < 2; ++cls) {
+    for (int cls = 0; cls < WG_CLASSES; ++cls) {
         WgGroup grp;
         int blocks = 0, rot = 0, cnt = 0;
-        const int T = cls ? 256 : 128;
         for (int i = 0; i < n; ++i) {
             const ClvWgradEntry& e = entries[i];
             const bool in_place = e.work_floats == 0;
@@ -1147,7 +1157,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
             if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
             if (wg_class(e.N, e.K, e.M) != cls) continue;
             WgProblem& p = grp.p[cnt++];
-            const int tilesN = (e.N + T - 1) / T, tilesK = (e.K + T - 1) / T;
+            const int tilesN = (e.N + wg_tn[cls] - 1) / wg_tn[cls], tilesK = (e.K + wg_tk[cls] - 1) / wg_tk[cls];
             p.dy = (const bf16_t*)e.dy;
             p.x = (const bf16_t*)e.x;
             p.work = in_place ? e.dw : (float*)e.work;
@@ -1178,13 +1188,26 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
         if (cls == 0) {
             hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(WG_THREADS), 0, (hipStream_t)stream,
                                grp);
-        } else {
+        } else if (cls == 1) {
             constexpr int LDS = BIG_RING * 4 * 8192;
             static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_group_kernel<2, 2>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
             (void)attr;
             hipLaunchKernelGGL((wgrad_big_group_kernel<2, 2>), dim3((unsigned)blocks), dim3(1024), LDS,
                                (hipStream_t)stream, grp);
+        } else {
+            constexpr int LDS = BIG_RING * 3 * 8192;
+            static const bool attr12 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_group_kernel<1, 2>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+            static const bool attr21 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_group_kernel<2, 1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+            (void)attr12; (void)attr21;
+            if (cls == 2)
+                hipLaunchKernelGGL((wgrad_big_group_kernel<1, 2>), dim3((unsigned)blocks), dim3(512), LDS,
+                                   (hipStream_t)stream, grp);
+            else
+                hipLaunchKernelGGL((wgrad_big_group_kernel<2, 1>), dim3((unsigned)blocks), dim3(512), LDS,
+                                   (hipStream_t)stream, grp);
         }
         const int rc = clv_check_launch();
         if (rc) return rc;
