@@ -22,6 +22,8 @@ import os
 
 import torch
 import torch.distributed as dist
+
+from .utils.dist import collectives_active
 import torch.nn as nn
 
 from . import ops
@@ -303,7 +305,7 @@ class CloverEngine:
 
     # ------------------------------------------------------------------ hipGraph mode
     _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
-                       '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts')
+                       '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts', 'graph_loss', '_loss_io')
 
     @staticmethod
     def _signature(batch):
@@ -321,14 +323,32 @@ class CloverEngine:
             if batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
         self.graph.replay()
-        emb = self._static_emb.detach().requires_grad_()
-        mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
-        losses = self.model.contrastive_losses(emb, mlm)
-        loss, log_vars = self.model._parse_losses(losses)
-        loss.backward()
-        self._static_demb.copy_(emb.grad)
-        if mlm is not None:
-            self._static_dmlm.copy_(mlm.grad)
+        if getattr(self, 'graph_loss', None) is not None:
+            # the loss section as a graph of its own: only the feature all-gather (and the all-reduce of the logged
+            # scalars) stay eager — ~60 launch-bound kernels otherwise paced by the host
+            g_static, names, packed, loss = self._loss_io
+            with torch.no_grad():
+                if collectives_active():
+                    from .utils.gather_loss import gather_rows
+                    g_static.copy_(gather_rows(self._static_emb.float(), equal_sizes=True))
+                else:
+                    g_static.copy_(self._static_emb)
+            self.graph_loss.replay()
+            if collectives_active():
+                packed = packed / self.world
+                dist.all_reduce(packed)
+            from .recognizers.base import LazyLogVars
+            log_vars = LazyLogVars(names, packed)
+            loss = loss.detach()
+        else:
+            emb = self._static_emb.detach().requires_grad_()
+            mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
+            losses = self.model.contrastive_losses(emb, mlm)
+            loss, log_vars = self.model._parse_losses(losses)
+            loss.backward()
+            self._static_demb.copy_(emb.grad)
+            if mlm is not None:
+                self._static_dmlm.copy_(mlm.grad)
         self._replay_backward()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
 
@@ -450,10 +470,53 @@ class CloverEngine:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit
         self.graph, self.graph_bwd, self.graph_bwd_video, self.graph_bwd_text = gf, gb, gb2, gb3
         self._static_emb, self._static_mlm = emb, mlm
+        self.graph_loss, self._loss_io = self._capture_loss_graph()
         self._static_cuts = (vcuts, tcuts)
         self._active_sig = self._signature(batch)
         self._captures[self._active_sig] = tuple(getattr(self, f) for f in self._CAPTURE_FIELDS)
         return True
+
+    def _capture_loss_graph(self):
+        """The section between the two encode graphs — contrastive / rank losses on the gathered embeddings, the loss
+        sum and its backward down to d emb / d mlm — as a hipGraph over a static gathered tensor.  The all-gather that
+        fills it and the all-reduce of the logged scalars stay eager (no RCCL call is ever captured); the gather's
+        backward is the local slice (gather_loss.py:64-72), taken inside the graph."""
+        import inspect
+        model = self.model
+        if (os.environ.get('CLOVER_LOSS_GRAPH', '0') != '1' or not hasattr(model, 'contrastive_losses')
+                or 'gathered' not in inspect.signature(model.contrastive_losses).parameters
+                or not getattr(getattr(model, 'ssl_loss', None), 'equal_batch', False)):
+            return None, None
+        emb = self._static_emb
+        B = emb.shape[0]
+        g_static = torch.zeros((self.world * B,) + tuple(emb.shape[1:]), device=emb.device, dtype=torch.float32)
+        g_static[self.rank * B:(self.rank + 1) * B].copy_(emb)
+        out = {}
+
+        def run():
+            g = g_static.detach().requires_grad_()
+            mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
+            losses = model.contrastive_losses(None, mlm, gathered=g)
+            loss, names, packed = model._parse_losses(losses, reduce=False)
+            loss.backward()
+            self._static_demb.copy_(g.grad[self.rank * B:(self.rank + 1) * B])
+            if mlm is not None:
+                self._static_dmlm.copy_(mlm.grad)
+            out.update(names=names, packed=packed, loss=loss.detach())
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # a pool of its own: it is captured after the backward graphs but replays BEFORE them — in the shared pool its
+        # temporaries would land on blocks the backward capture released, i.e. on the activations the backward still reads
+        gl = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gl, capture_error_mode='thread_local'):
+            run()
+        return gl, (g_static, out['names'], out['packed'], out['loss'])
 
     def optimizer_step(self):
         """Global-norm clip + AdamW on the slabs; no host synchronisation.  The clip coefficient, Adam's bias

@@ -131,7 +131,7 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
     def forward_test(self, imgs):
         """Defines the computation performed at every call when evaluation and testing."""
 
-    def _parse_losses(self, losses):
+    def _parse_losses(self, losses, reduce=True):
         """loss = sum of every entry whose key contains 'loss'; log_vars = all entries (+ 'loss'),
         averaged over ranks (reference :254-288)."""
         vals = OrderedDict()
@@ -149,6 +149,8 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         loss = stacked.sum() if len(pick) == len(names) else stacked[pick].sum()
         names.append('loss')
         packed = torch.cat([stacked.detach(), loss.detach().reshape(1)])
+        if not reduce:                                   # inside a hipGraph capture: the caller averages over the ranks
+            return loss, names, packed
         if collectives_active():
             packed = packed / dist.get_world_size()
             dist.all_reduce(packed)

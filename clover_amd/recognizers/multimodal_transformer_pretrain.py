@@ -155,12 +155,14 @@ class CloverPretrain(BaseRecognizer):
             object.__setattr__(self, '_txt_stream', st)
         return st
 
-    def contrastive_losses(self, emb, mlm_loss):
+    def contrastive_losses(self, emb, mlm_loss, gathered=None):
         """The cross-rank part of the step (:147-169): ONE all-gather of the six embeddings (backward = the local
         slice, gather_loss.py:64-72), then the two exclusive-InfoNCE / ranking evaluations read their four slots
         of the gathered [G, 6, D] tensor in place.  emb [B, 6, D] in EMB_NAMES order."""
         from ..utils.gather_loss import gather_rows
-        g = gather_rows(emb.float(), equal_sizes=self.ssl_loss.equal_batch).contiguous()
+        # gathered: the [G, 6, D] fp32 tensor already in hand (the engine's loss graph gathers outside the capture)
+        g = (gathered if gathered is not None
+             else gather_rows(emb.float(), equal_sizes=self.ssl_loss.equal_batch).contiguous())
         V, T, MW, MVR, MV, MWR = range(6)                      # EMB_NAMES order
         losses = dict(mlm_loss=mlm_loss)
         losses.update(self.ssl_loss.forward_gathered(g, (V, T, MW, MVR)))                              # :151
