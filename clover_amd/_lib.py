@@ -19,7 +19,8 @@ class ClvAttnGeom(C.Structure):
     """Mirror of ``struct ClvAttnGeom`` (include/clover_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in
                 ('mode', 'groups', 'N', 'nH', 'hd', 'D', 'H', 'W', 'wd', 'wh', 'ww', 'sd', 'sh', 'sw',
-                 'ldq', 'ldk', 'ldv', 'ldo', 'bwd', 'bwh', 'bww')] + [('scale', C.c_float), ('dropout_p', C.c_float)]
+                 'ldq', 'ldk', 'ldv', 'ldo', 'bwd', 'bwh', 'bww')] + [('scale', C.c_float), ('dropout_p', C.c_float),
+                                                                      ('dbias_index', C.c_void_p)]
 
 
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -58,6 +59,8 @@ SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_attn_bwd_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_dbias_index_count': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_dbias_index': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),
     'clv_softmax_rows_fwd': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _f, _f, _p]),
     'clv_softmax_rows_bwd': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _f, _f, _p]),

@@ -714,6 +714,51 @@ __global__ void __launch_bounds__(256) dbias_gather_kernel(const float* __restri
     dbias_gather_wave(dense, dtable, nkt, G, nsplit, split_stride, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
+// Table-driven gather: the fragment offset of every (table row, key) pair is a pure function of the window geometry, so
+// it is built ONCE per geometry (dbias_index_kernel -> int32 [tlen][NK], -1 = no pair) and the per-step gather is loads
+// only (the arithmetic version above spends ~2 integer divisions per key and wave: 21-43 us per launch).
+__global__ void __launch_bounds__(256) dbias_index_kernel(int* __restrict__ tab, int nkt, Geom G) {
+    const int NK = nkt * 16;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= G.tlen * NK) return;
+    const int slot = e / NK, key = e - slot * NK;
+    int off = -1;
+    if (key < G.g.N) {
+        const int dz = slot / G.ts_d - (G.g.bwd - 1), rem = slot % G.ts_d;
+        const int dy = rem / G.ts_h - (G.g.bwh - 1), dx = rem % G.ts_h - (G.g.bww - 1);
+        const int hw = G.g.bwh * G.g.bww;
+        const int kz = key / hw, kr = key - kz * hw, ky = kr / G.g.bww, kx = kr - ky * G.g.bww;
+        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
+        const int qn = (qz * G.g.bwh + qy) * G.g.bww + qx;
+        if (qz >= 0 && qz < G.g.bwd && qy >= 0 && qy < G.g.bwh && qx >= 0 && qx < G.g.bww && qn < G.g.N)
+            off = (((qn >> 4) * nkt + (key >> 4)) * 64 + ((((key & 15) >> 2) << 4) | (qn & 15))) * 4 + (key & 3);
+    }
+    tab[e] = off;
+}
+
+__global__ void __launch_bounds__(256) dbias_gather_tab_kernel(const float* __restrict__ dense, float* __restrict__ dtable,
+                                                               const int* __restrict__ tab, int nkt, Geom G, int nsplit,
+                                                               int64_t split_stride) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= G.tlen * G.g.nH) return;
+    const int slot = w / G.g.nH, h = w - slot * G.g.nH;
+    const int NK = nkt * 16, nqt = (G.g.N + 15) >> 4;
+    const float* dh = dense + (int64_t)h * nqt * nkt * 256;
+    const int* trow = tab + slot * NK;
+    float a = 0.f;
+    for (int kb = lane; kb < NK; kb += 64) {
+        const int off = trow[kb];
+        if (off < 0) continue;
+        const float* pe = dh + off;
+        int sp = 0;
+        for (; sp + 4 <= nsplit; sp += 4)
+            a += (pe[sp * split_stride] + pe[(sp + 1) * split_stride]) + (pe[(sp + 2) * split_stride] + pe[(sp + 3) * split_stride]);
+        for (; sp < nsplit; ++sp) a += pe[sp * split_stride];
+    }
+    a = wave_sum(a);
+    if (lane == 0) dtable[w] += a;
+}
+
 // ------------------------------------------------------------------------- host side
 bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (!g) return false;
@@ -849,8 +894,12 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
                            (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
         (void)dense;
-        hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias, NKT, G,
-                           splits, E * 4);
+        if (G.g.dbias_index)
+            hipLaunchKernelGGL(dbias_gather_tab_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias,
+                               G.g.dbias_index, NKT, G, splits, E * 4);
+        else
+            hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias, NKT, G,
+                               splits, E * 4);
         rc = clv_check_launch();
         if (rc) return rc;
     }
@@ -904,6 +953,21 @@ extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
     const int nkt = pick_nkt(G.g.N);
     if (nkt < 0) return 0;
     return ds_scratch_bytes(G, nkt) + (int64_t)(DBIAS_SPLITS + 1) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;   // + fp32 partials, dense
+}
+
+extern "C" int64_t clv_attn_dbias_index_count(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0) return 0;
+    return (int64_t)G.tlen * pick_nkt(G.g.N) * 16;
+}
+
+extern "C" int clv_attn_dbias_index(const ClvAttnGeom* geom, int32_t* out, void* stream) {
+    Geom G;
+    if (!out || !make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0) return CLV_ERR_ARG;
+    const int nkt = pick_nkt(G.g.N);
+    const int64_t n = (int64_t)G.tlen * nkt * 16;
+    hipLaunchKernelGGL(dbias_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, nkt, G);
+    return clv_check_launch();
 }
 
 extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,

@@ -58,6 +58,29 @@ class _Timed:
             PROF.setdefault(self.key, []).append((self.s, self.e, self.flops, self.nbytes))
 
 
+_DBIAS_INDEX = {}
+
+
+def _dbias_index(g, device):
+    """Device pointer of the (bias-table row, key) -> dS-fragment offset table of this window geometry, built on first
+    use (outside hipGraph captures) and kept for the life of the process; None = the kernel does the index arithmetic."""
+    if os.environ.get('CLOVER_DBIAS_INDEX', '1') != '1':
+        return None
+    key = (str(device), g.N, g.bwd, g.bwh, g.bww)
+    t = _DBIAS_INDEX.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        L = _lib.lib()
+        n = L.clv_attn_dbias_index_count(C.byref(g))
+        if n <= 0:
+            return None
+        t = torch.empty(n, device=device, dtype=torch.int32)
+        check(L.clv_attn_dbias_index(C.byref(g), _ptr(t), _stream()), 'clv_attn_dbias_index')
+        _DBIAS_INDEX[key] = t
+    return t.data_ptr()
+
+
 def _kname(kernel, g):
     """Device-kernel name as rocprofv3 prints it: template <HD, NKT, DROP, MODE> (attention.hip CLV_PICK)."""
     need = (g.N + 15) // 16
@@ -1050,6 +1073,7 @@ class _Attention(torch.autograd.Function):
                 sink = None
             dtab = sink if sink is not None else torch.zeros_like(tab)
             work = torch.empty(L.clv_attn_bwd_work_bytes(C.byref(g)), device=qkv.device, dtype=torch.uint8)
+            g.dbias_index = _dbias_index(g, qkv.device)
         b, d = qkv.data_ptr(), dqkv.data_ptr()
         args = (C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim), _ptr(o), _ptr(doc), _ptr(lse),
                 _ptr(tab), _ptr(rid), _ptr(kmask), C.c_void_p(d), C.c_void_p(d + 2 * Cdim),

@@ -63,6 +63,8 @@ typedef struct ClvAttnGeom {
     int32_t bwd, bwh, bww;  /* window the bias table was built for: the table has (2bwd-1)(2bwh-1)(2bww-1) rows; 0,0,0 = none */
     float scale;            /* head_dim^-0.5 */
     float dropout_p;        /* dropout on the attention probabilities (HF attention_probs_dropout_prob), 0 = off */
+    const int32_t* dbias_index; /* backward, optional: the device table clv_attn_dbias_index() built for this window
+                                   geometry (N, bwd, bwh, bww) — the table-gradient gather then does no index arithmetic */
 } ClvAttnGeom;
 
 /* lse: float [groups][nH][N].  bias: the module's relative_position_bias_table, float [rows][nH], or NULL.  rid: int32 [nW][N] region
@@ -78,6 +80,10 @@ int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * work: scratch of clv_attn_bwd_work_bytes() bytes (the bf16 dS of every (group, head), summed over the groups
  * and scattered into dbias by a second kernel), required iff bias != NULL. */
 int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom_host);
+/* int32 [clv_attn_dbias_index_count()]: fragment offset of the (query, key) pair of every (bias-table row, key), -1 = none;
+ * depends on (N, bwd, bwh, bww) only — build once, pass in ClvAttnGeom.dbias_index of every backward call. */
+int64_t clv_attn_dbias_index_count(const ClvAttnGeom* geom_host);
+int clv_attn_dbias_index(const ClvAttnGeom* geom_host, int32_t* out, void* stream);
 int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                  const float* lse, const float* bias, const int32_t* rid, const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* work,
