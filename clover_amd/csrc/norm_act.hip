@@ -567,9 +567,10 @@ inline bool lnv_config(int C, LnvCfg& cfg) {
     }
     return true;
 }
-inline int lnv_blocks(int64_t rows, int group) {
+inline int lnv_blocks(int64_t rows, int group, bool fwd = false) {
     const int rpb = LN_WAVES * (64 / group);           // rows per block per pass
-    static const int cap = env_cap("CLV_LNV_GRID", 2048);
+    static const int cap_b = env_cap("CLV_LNV_GRID", 2048), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);   // forward: one pass per wave (-0.08 ms); backward: bounded (dgamma / dbeta partials)
+    const int cap = fwd ? cap_f : cap_b;
     int64_t b = (rows + rpb - 1) / rpb;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -677,7 +678,7 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
         return CLV_ERR_ARG;
     LnvCfg cfg;
     if (lnv_config(C, cfg)) {
-        const int grid = lnv_blocks(rows, cfg.group);
+        const int grid = lnv_blocks(rows, cfg.group, true);
         if (is_f32) {
             LNV_DISPATCH(lnv_fwd_kernel, float, XF, grid, (const float*)x, (const float*)res, gamma, beta, (float*)y,
                          (float*)sum_out, mean, rstd, rows, (int)C, eps, xf)
