@@ -90,7 +90,7 @@ __device__ __forceinline__ Frag8 gn_frag(const unsigned char* oper, int r, int k
 }
 
 enum { GN_EPI_NONE = CLV_GEMM_EPI_NONE, GN_EPI_BIAS = CLV_GEMM_EPI_BIAS, GN_EPI_GELU = CLV_GEMM_EPI_BIAS_GELU,
-       GN_EPI_DGELU = CLV_GEMM_EPI_DGELU };
+       GN_EPI_DGELU = CLV_GEMM_EPI_DGELU, GN_EPI_GELUD = CLV_GEMM_EPI_BIAS_GELU_D, GN_EPI_MUL = CLV_GEMM_EPI_MUL };
 
 __device__ __forceinline__ float gn_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float gn_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -114,8 +114,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int P = GnOper<BM, WAVES>::PIECES + GnOper<BN, WAVES>::PIECES;     // DMA pieces per wave and stage
-    constexpr int S = TM * (TN / 2) * (EPI == GN_EPI_GELU ? 2 : 1);      // store instructions per wave and epilogue
-    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU;
+    constexpr int S = TM * (TN / 2) * ((EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD) ? 2 : 1);      // store instructions per wave and epilogue
+    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD;
     static_assert((R - 2) * P + S <= 63, "vmcnt immediate");
     static_assert(TN % 2 == 0 && R >= 2, "tile shape");
     __shared__ __attribute__((aligned(1024))) unsigned char ring[R * STAGE + (HAS_BIAS ? GN_MAX_BIAS * 2 : 0)];
@@ -256,6 +256,27 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                         const f32x2_t r = gelu_erf2((f32x2_t){v[e], v[e + 1]});
                         v[e] = r.x; v[e + 1] = r.y;
                     }
+                }
+                if (EPI == GN_EPI_GELUD) {                    // c2 = GELU'(pre): cdf and exp(-x^2/2) are in hand already
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t x2 = {v[e], v[e + 1]};
+                        f32x2_t cdf, ex;
+                        gelu_parts2(x2, cdf, ex);
+                        const f32x2_t r = x2 * cdf;
+                        const f32x2_t dd = __builtin_elementwise_fma(x2 * (f32x2_t){0.3989422804014327f, 0.3989422804014327f}, ex, cdf);
+                        v[e] = r.x; v[e + 1] = r.y;
+                        d[e] = dd.x; d[e + 1] = dd.y;
+                    }
+                    *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]),
+                                                                   pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+                }
+                if (EPI == GN_EPI_MUL) {
+                    const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
+                    const uint32_t pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) { v[e] *= gn_lo(pv[e >> 1]); v[e + 1] *= gn_hi(pv[e >> 1]); }
                 }
                 if (EPI == GN_EPI_DGELU) {
                     const uint4 p = *reinterpret_cast<const uint4*>(aux + g);
@@ -549,6 +570,8 @@ int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf1
         case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
         case GN_EPI_GELU: GN_GO(GN_EPI_GELU); break;
         case GN_EPI_DGELU: GN_GO(GN_EPI_DGELU); break;
+        case GN_EPI_GELUD: GN_GO(GN_EPI_GELUD); break;
+        case GN_EPI_MUL: GN_GO(GN_EPI_MUL); break;
         default: return CLV_ERR_UNSUPPORTED;
     }
 #undef GN_GO
@@ -568,9 +591,9 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     if ((lda & 7) || (ldb & 7) || (ldc & 7) || lda < K || ldb < K || ldc < N) return CLV_ERR_ARG;
     if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)c2) | ((uintptr_t)aux) | ((uintptr_t)bias)) & 15)
         return CLV_ERR_ARG;
-    if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELU) && !bias) return CLV_ERR_ARG;
-    if (epilogue == GN_EPI_GELU && !c2) return CLV_ERR_ARG;
-    if (epilogue == GN_EPI_DGELU && !aux) return CLV_ERR_ARG;
+    if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELU || epilogue == GN_EPI_GELUD) && !bias) return CLV_ERR_ARG;
+    if ((epilogue == GN_EPI_GELU || epilogue == GN_EPI_GELUD) && !c2) return CLV_ERR_ARG;
+    if ((epilogue == GN_EPI_DGELU || epilogue == GN_EPI_MUL) && !aux) return CLV_ERR_ARG;
     const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8"
     if (force && (!strcmp(force, "lean") || !strcmp(force, "lean64"))) {     // one tile per workgroup (measured 5-15 % behind)
         // 4 GiB of addressable operand per tile row block (32-bit lane offsets)

@@ -652,8 +652,13 @@ class _MlpGelu(torch.autograd.Function):
         w1b = w1b if w1b is not None else w1.to(BF16)
         w2b = getattr(w2, '_clv_shadow', None)
         w2b = w2b if w2b is not None else w2.to(BF16)
-        act, pre = gemm_nt(x2, w1b, b1.detach(), epilogue=GEMM_EPI_BIAS_GELU)
+        # the second output is GELU'(pre) rather than pre when fc2's input gradient runs on clv_gemm_nt too: its
+        # epilogue then is one multiply per element (no erf / exp in the backward)
         Hd, C_ = w1b.shape[0], w2b.shape[0]
+        ctx.dgelu_saved = (os.environ.get('CLOVER_GELU_SAVE_GRAD', '1') == '1' and own_gemm_ok(x2, Hd, C_)
+                           and os.environ.get('CLOVER_DGELU_FUSE', '1') == '1')
+        act, pre = gemm_nt(x2, w1b, b1.detach(),
+                           epilogue=GEMM_EPI_BIAS_GELU_D if ctx.dgelu_saved else GEMM_EPI_BIAS_GELU)
         if own_gemm_ok(act, C_, Hd):
             out = gemm_nt(act, w2b, b2.detach() if b2 is not None else None,
                           epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
@@ -672,7 +677,10 @@ class _MlpGelu(torch.autograd.Function):
         do2 = _c(dout.reshape(-1, w2b.shape[0]))
         if do2.dtype != BF16:
             do2 = do2.to(BF16)
-        dpre = linear_dgrad(do2, w2b, w2, pre=pre)           # (d out . W2) * GELU'(pre)
+        if ctx.dgelu_saved:                                  # pre holds GELU'(pre)
+            dpre = gemm_nt(do2, _wt(w2, w2b), aux=pre, epilogue=GEMM_EPI_MUL)
+        else:
+            dpre = linear_dgrad(do2, w2b, w2, pre=pre)       # (d out . W2) * GELU'(pre)
         dw2, db2 = _param_grads(do2, act, w2, b2)
         dx = linear_dgrad(dpre, w1b, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = _param_grads(dpre, x2, w1, b1)
@@ -690,7 +698,7 @@ def mlp_gelu(x, w1, b1, w2, b2):
 
 
 # --------------------------------------------------------------------------- LDS-tiled GEMM with fused epilogues
-GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU = 0, 1, 2, 3
+GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU, GEMM_EPI_BIAS_GELU_D, GEMM_EPI_MUL = 0, 1, 2, 3, 4, 5
 
 
 def gemm_nt_supported(M, N, K):
@@ -700,13 +708,13 @@ def gemm_nt_supported(M, N, K):
 def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
     """Raw launcher of clv_gemm_nt (no autograd): c [M,N] = a [M,K] . b [N,K]^T with the epilogue fused.
     a, b bf16 with unit inner stride; bias fp32 [N]; aux bf16 [M,N] contiguous (DGELU: the pre-activation).
-    Returns c, or (c, pre) for GEMM_EPI_BIAS_GELU."""
+    Returns c, or (c, c2) for GEMM_EPI_BIAS_GELU (c2 = pre-activation) / GEMM_EPI_BIAS_GELU_D (c2 = GELU'(pre))."""
     _need_gpu(a, b)
     M, K = a.shape
     N = b.shape[0]
     assert a.dtype == BF16 and b.dtype == BF16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
     c = out if out is not None else torch.empty(M, N, device=a.device, dtype=BF16)
-    c2 = torch.empty_like(c) if epilogue == GEMM_EPI_BIAS_GELU else None
+    c2 = torch.empty_like(c) if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else None
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
     if aux is not None:
@@ -716,12 +724,12 @@ def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
     if PROF is None:
         check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
     else:
-        nout = 2 if epilogue == GEMM_EPI_BIAS_GELU else 1
-        nin = 1 if epilogue == GEMM_EPI_DGELU else 0
+        nout = 2 if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else 1
+        nin = 1 if epilogue in (GEMM_EPI_DGELU, GEMM_EPI_MUL) else 0
         with _Timed(f'gemm_nt_kernel<128, 128, 2, 2, 2, {int(epilogue)}>', 2 * M * N * K,
                     (M * K + N * K + (nout + nin) * M * N) * 2):
             check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
-    return (c, c2) if epilogue == GEMM_EPI_BIAS_GELU else c
+    return (c, c2) if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else c
 
 
 def transpose_batch(src_base, dst_base, table, n_entries, total_tiles):

@@ -346,11 +346,16 @@ int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, c
  *   CLV_GEMM_EPI_BIAS       c = acc + bias
  *   CLV_GEMM_EPI_BIAS_GELU  c2 = acc + bias (the pre-activation, kept for backward), c = GELU_erf(acc + bias)
  *   CLV_GEMM_EPI_DGELU      c = acc * GELU_erf'(aux)      (aux = the forward's pre-activation)
+ *   CLV_GEMM_EPI_BIAS_GELU_D  c2 = GELU_erf'(acc + bias) (what the backward needs of the pre-activation, computed where its
+ *                             erf / exp are in hand anyway), c = GELU_erf(acc + bias)
+ *   CLV_GEMM_EPI_MUL        c = acc * aux                 (aux = that c2: the GELU backward without a transcendental)
  * Needs N % 8 == 0, K % 64 == 0, 16-byte aligned pointers (clv_gemm_nt_supported); fp32 accumulation. */
 #define CLV_GEMM_EPI_NONE 0
 #define CLV_GEMM_EPI_BIAS 1
 #define CLV_GEMM_EPI_BIAS_GELU 2
 #define CLV_GEMM_EPI_DGELU 3
+#define CLV_GEMM_EPI_BIAS_GELU_D 4
+#define CLV_GEMM_EPI_MUL 5
 int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
 int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
                 int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream);

@@ -857,3 +857,21 @@ def test_fused_ln_linear_and_mlp(C, with_res):
         assert rel(gr, gr_ref) < 3e-2 and rel(o[2], o_ref[2]) < 1e-2
     for k in P:
         assert rel(gp[k], gp_ref[k]) < 3e-2, (k, rel(gp[k], gp_ref[k]))
+
+
+def test_gemm_nt_gelu_grad_epilogues():
+    """CLV_GEMM_EPI_BIAS_GELU_D (c2 = GELU'(pre)) and CLV_GEMM_EPI_MUL (c = acc * aux): the pair that keeps the GELU
+    backward free of transcendentals, against torch fp32."""
+    M, N, K = 12544, 1536, 384
+    x, w, b = rnd(M, K, seed=501).to(BF), rnd(N, K, scale=0.05, seed=502).to(BF), rnd(N, seed=503)
+    act, dg = ops().gemm_nt(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops().GEMM_EPI_BIAS_GELU_D)
+    pre = (x.float() @ w.float().t() + b.to(BF).float()).requires_grad_()
+    ref = F.gelu(pre)
+    ref.sum().backward()
+    assert rel(act, ref.detach()) < 1e-2
+    assert (dg.float().cpu() - pre.grad).abs().max().item() < 1.5e-2          # bf16 storage of values in [-0.13, 1.13]
+    dy = rnd(M, K, seed=504).to(BF)
+    wt = rnd(N, K, scale=0.05, seed=505).to(BF)
+    out = ops().gemm_nt(dy.to(DEV), wt.to(DEV), aux=dg, epilogue=ops().GEMM_EPI_MUL)
+    ref2 = (dy.float() @ wt.float().t()) * dg.float().cpu()
+    assert rel(out, ref2) < 1e-2
