@@ -304,13 +304,20 @@ def main():
                 res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
-        print(json.dumps(res))
     if args.tune_gemms and rank == 0:
         from clover_amd.utils.gemm_tuning import save_results
         save_results(args.tune_gemms)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio: push it out first so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
