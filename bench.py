@@ -197,6 +197,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    if rank != 0:                                        # only rank 0 reports: keep the other ranks' library banners off stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1 or os.environ.get('CLOVER_FORCE_COLLECTIVES') == '1':
