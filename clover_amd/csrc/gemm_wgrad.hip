@@ -1114,7 +1114,7 @@ static const int wg_tn[WG_CLASSES] = {128, 256, 128, 256}, wg_tk[WG_CLASSES] = {
 // One M-slice accumulated straight into dW / db (no partials, no fold): few rows, or an output so large that every extra
 // slice costs more partial traffic (write + fold read of N x K floats) than it saves in workgroup length.
 static bool wg_in_place(int64_t M, int N, int K) {
-    return M <= 1024 || (wg_class(N, K) == 1 && (int64_t)N * K > (1 << 20));
+    return M <= 1024 || (N % 256 == 0 && K % 256 == 0 && (int64_t)N * K > (1 << 20));
 }
 extern "C" int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K) { return wg_in_place(M, N, K) ? 1 : 0; }
 extern "C" int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K) { return wg_class(N, K, M); }
