@@ -316,6 +316,11 @@ class CloverEngine:
             setattr(self, f, v)
         self._active_sig = sig
 
+    def input_buffers(self):
+        """The static input tensors of the active hipGraphs (None before capture): a loader that writes its host-to-device
+        copies straight into them — and hands the same dict to step() — saves the per-step staging copy."""
+        return self._static_batch if self.graph is not None else None
+
     def _graphed_forward_backward(self, batch):
         """encode (hipGraph) -> gather + contrastive losses (eager: it holds the step's only forward
         collective) -> backward of the losses (eager, a handful of kernels) -> encode backward (hipGraph)."""
