@@ -23,7 +23,7 @@ constexpr int THREADS = WAVES * 64;
 // The backward kernels run 8 waves per workgroup from 14 key tiles up: twice as many waves share the staged K / V
 // (Q / dO), which is what limits the workgroups per CU (392-token windows: 72 KB -> two workgroups, -40 % per
 // kernel; 196-token windows: 50 KB -> three, -7 % / -13 %)
-constexpr int DKV_THREADS(int nkt) { return nkt >= 14 ? 512 : THREADS; }
+constexpr int DKV_THREADS(int nkt) { return nkt >= 13 ? 512 : THREADS; }
 
 struct Geom {
     ClvAttnGeom g;
@@ -300,17 +300,19 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
 #pragma unroll
         for (int c = 0; c < NC; ++c) oacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s2 = 0; s2 < NKT / 2; ++s2) {
+        for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) {
+            constexpr bool ODD = (NKT & 1) != 0;             // odd tile count (N = 196 -> 13): the last k-step is half empty
+            const bool tail = ODD && s2 == NKT / 2;
             Frag8 pf;
             pf.u[0] = pack2bf(p[2 * s2][0], p[2 * s2][1]);
             pf.u[1] = pack2bf(p[2 * s2][2], p[2 * s2][3]);
-            pf.u[2] = pack2bf(p[2 * s2 + 1][0], p[2 * s2 + 1][1]);
-            pf.u[3] = pack2bf(p[2 * s2 + 1][2], p[2 * s2 + 1][3]);
+            pf.u[2] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][0], p[tail ? 0 : 2 * s2 + 1][1]);
+            pf.u[3] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][2], p[tail ? 0 : 2 * s2 + 1][3]);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 Frag8 vf;   // A[hd c*16+lr][kappa] = V[key(kappa)][hd]
                 vf.u2[0] = tr4(Vs, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
-                vf.u2[1] = tr4(Vs, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
+                vf.u2[1] = tail ? make_uint2(0u, 0u) : tr4(Vs, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
                 oacc[c] = mfma16(vf, pf, oacc[c]);
             }
             // without dropout the softmax denominator is the sum of the SAME bf16 probabilities the P.V product uses:
@@ -427,7 +429,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
         bf16_t* dsfrag = (tb && ds_out)
             ? ds_out + ((((int64_t)grp * G.g.nH + h) * nqt + qt) * NKT * 64 + lane) * 4 : nullptr;
 
-        Frag8 dsf[NKT / 2];
+        Frag8 dsf[(NKT + 1) / 2];
+        if (NKT & 1) dsf[NKT / 2].u[2] = dsf[NKT / 2].u[3] = 0u;   // the missing second half of an odd tile count
         float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
 #pragma unroll
@@ -474,12 +477,13 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
 #pragma unroll
         for (int c = 0; c < NC; ++c) qacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s2 = 0; s2 < NKT / 2; ++s2)
+        for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 Frag8 kf;   // A[hd c*16+lr][kappa] = K[key(kappa)][hd]
                 kf.u2[0] = tr4(Ks, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
-                kf.u2[1] = tr4(Ks, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
+                kf.u2[1] = ((NKT & 1) && s2 == NKT / 2) ? make_uint2(0u, 0u)
+                                                         : tr4(Ks, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
                 qacc[c] = mfma16(kf, dsf[s2], qacc[c]);
             }
         if (qv) {
@@ -582,11 +586,13 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
             dkacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll 1
-        for (int qp = 0; qp < NKT / 2; ++qp) {
+        for (int qp = 0; qp < (NKT + 1) / 2; ++qp) {
             Frag8 pf, dsf;
+            pf.u[2] = pf.u[3] = dsf.u[2] = dsf.u[3] = 0u;   // odd tile count: the last pair has no second query tile
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = qp * 2 + half;
+                if ((NKT & 1) && qt >= NKT) break;
                 float pv[4], dsv[4];
                 const int qn0 = qt * 16 + lg * 4;
                 float4 bv = make_float4(kmv, kmv, kmv, kmv);
@@ -637,11 +643,12 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 Frag8 a;   // A[hd c*16+lr][kappa] = dO[query(kappa)][hd]
+                const bool tail = (NKT & 1) && 2 * qp + 1 >= NKT;       // no second tile staged: a zero operand, not LDS beyond it
                 a.u2[0] = tr4(dOs, LDR, (2 * qp) * 16 + lg * 4, c * 16, lr);
-                a.u2[1] = tr4(dOs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
+                a.u2[1] = tail ? make_uint2(0u, 0u) : tr4(dOs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
                 dvacc[c] = mfma16(a, pf, dvacc[c]);        // dVᵀ[hd (lg*4+r)][key lr]
                 a.u2[0] = tr4(Qs, LDR, (2 * qp) * 16 + lg * 4, c * 16, lr);
-                a.u2[1] = tr4(Qs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
+                a.u2[1] = tail ? make_uint2(0u, 0u) : tr4(Qs, LDR, (2 * qp + 1) * 16 + lg * 4, c * 16, lr);
                 dkacc[c] = mfma16(a, dsf, dkacc[c]);
             }
         }
@@ -914,7 +921,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
 // smallest instantiated key-tile count >= need
 int pick_nkt(int N) {
     const int need = (N + 15) / 16;
-    const int opts[] = {2, 8, 14, 16, 28};
+    const int opts[] = {2, 8, 13, 14, 16, 28};        // 13: the 196-token window (4 x 7 x 7) without a padding-only tile
     for (int o : opts) if (o >= need) return o;
     return -1;
 }
@@ -923,6 +930,7 @@ int pick_nkt(int N) {
     switch (nkt) {                                                   \
         case 2: return FN<HDV, 2>(__VA_ARGS__);                      \
         case 8: return FN<HDV, 8>(__VA_ARGS__);                      \
+        case 13: return FN<HDV, 13>(__VA_ARGS__);                    \
         case 14: return FN<HDV, 14>(__VA_ARGS__);                    \
         case 16: return FN<HDV, 16>(__VA_ARGS__);                    \
         case 28: return FN<HDV, 28>(__VA_ARGS__);                    \
