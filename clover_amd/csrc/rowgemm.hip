@@ -233,6 +233,8 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
         gx = 1536 / ny;
         if (gx < 256) gx = 256;
     }
+    static const int mult = getenv("CLV_RG_MULT") ? atoi(getenv("CLV_RG_MULT")) : 1;   // probe: finer row slices
+    gx *= mult;
     if (gx < 8) gx = 8;
     if (gx > row_blocks) gx = row_blocks;
     rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)(gx * ny)), dim3(RG_THREADS), lds, st>>>(
