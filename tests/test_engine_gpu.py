@@ -172,8 +172,10 @@ def test_engine_gradient_slab_equals_plain_autograd():
         assert err < 2e-2, (n, err)
 
 
-def test_graph_capture_equals_eager_and_loss_decreases():
+@pytest.mark.parametrize('loss_graph', ['0', '1'])         # the loss section eager / as a hipGraph of its own
+def test_graph_capture_equals_eager_and_loss_decreases(loss_graph, monkeypatch):
     from clover_amd.engine import CloverEngine
+    monkeypatch.setenv('CLOVER_LOSS_GRAPH', loss_graph)
     b = batch(4, 'eng4')
     traj = {}
     for mode in ('eager', 'graph'):
@@ -182,11 +184,16 @@ def test_graph_capture_equals_eager_and_loss_decreases():
         if mode == 'graph':
             eng.step(b)
             assert eng.capture(b)
+            assert (eng.graph_loss is not None) == (loss_graph == '1')
+            assert eng.input_buffers() is not None
+            b_run = eng.input_buffers()                      # a loader writing straight into the static buffers
         else:
             eng.step(b)
+            assert eng.input_buffers() is None
+            b_run = b
         losses = []
         for _ in range(6):
-            out = eng.step(b)
+            out = eng.step(b_run)
             losses.append(out['log_vars']['loss'])
         traj[mode] = losses
     print(traj)
