@@ -830,12 +830,13 @@ template <int HD, int NKT>
 size_t dkv_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 
 // Three compiled variants per (HD, NKT): window (bias/rid, no dropout), sequence, sequence + dropout.
-#define CLV_PICK(KERNEL, ...)                                                                          \
+#define CLV_PICK_N(KERNEL, NT, ...)                                                                    \
     do {                                                                                               \
-        if (G.g.mode == 1) { KERNEL<HD, NKT, false, 1> __VA_ARGS__; }                                  \
-        else if (G.drop_thresh) { KERNEL<HD, NKT, true, 0> __VA_ARGS__; }                              \
-        else { KERNEL<HD, NKT, false, 0> __VA_ARGS__; }                                                \
+        if (G.g.mode == 1) { KERNEL<HD, NT, false, 1> __VA_ARGS__; }                                   \
+        else if (G.drop_thresh) { KERNEL<HD, NT, true, 0> __VA_ARGS__; }                               \
+        else { KERNEL<HD, NT, false, 0> __VA_ARGS__; }                                                 \
     } while (0)
+#define CLV_PICK(KERNEL, ...) CLV_PICK_N(KERNEL, NKT, __VA_ARGS__)
 
 // dynamic LDS above 64 KB must be opted into per kernel; the request varies with the table length, so opt in to
 // the whole 160 KB once and pass the actual size at launch
@@ -851,9 +852,10 @@ void set_attrs() {
     CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 1>));
     CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, false, 0>));
     CLV_ATTR((attn_bwd_dq_kernel<HD, NKT, true, 0>));
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 1>));
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, false, 0>));
-    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKT, true, 0>));
+    constexpr int NKE = (NKT + 1) & ~1;                       // dK / dV: even tile count (see launch_bwd)
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 1>));
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 0>));
+    CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, true, 0>));
 #undef CLV_ATTR
 }
 
@@ -877,7 +879,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
                void* dk, void* dv, float* dbias, float* dsum, void* work, const unsigned long long* seed, int stages,
                const Geom& G, hipStream_t st) {
     const int bl = bias ? G.tls : 0;
-    const size_t lds_a = dq_lds<HD, NKT>(bl), lds_b = dkv_lds<HD, NKT>(bl);
+    // the dK / dV kernel walks query tiles in pairs inside a rolled loop: an odd count costs it more (zeroed half
+    // operands, a break) than the one padding tile of the next even count (392 tokens: 26 tiles 661 -> ~, 25 tiles 705 us)
+    constexpr int NKE = (NKT + 1) & ~1;
+    const size_t lds_a = dq_lds<HD, NKT>(bl), lds_b = dkv_lds<HD, NKE>(bl);
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
@@ -911,7 +916,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         if (rc) return rc;
     }
     if (stages & 4) {
-        CLV_PICK(attn_bwd_dkv_kernel, <<<dim3(nblk), dim3(DKV_THREADS(NKT)), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
+        CLV_PICK_N(attn_bwd_dkv_kernel, NKE, <<<dim3(nblk), dim3(DKV_THREADS(NKE)), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
                  (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
         rc = clv_check_launch();
     }
@@ -921,7 +926,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
 // smallest instantiated key-tile count >= need
 int pick_nkt(int N) {
     const int need = (N + 15) / 16;
-    const int opts[] = {2, 8, 13, 14, 16, 28};        // 13: the 196-token window (4 x 7 x 7) without a padding-only tile
+    // 13 / 25: the 196- and 392-token windows (4 x 7 x 7, 8 x 7 x 7), 15: the 228-token fusion sequence — no padding-only tiles
+    const int opts[] = {2, 8, 13, 14, 15, 16, 25, 28};
     for (int o : opts) if (o >= need) return o;
     return -1;
 }
@@ -932,7 +938,9 @@ int pick_nkt(int N) {
         case 8: return FN<HDV, 8>(__VA_ARGS__);                      \
         case 13: return FN<HDV, 13>(__VA_ARGS__);                    \
         case 14: return FN<HDV, 14>(__VA_ARGS__);                    \
+        case 15: return FN<HDV, 15>(__VA_ARGS__);                    \
         case 16: return FN<HDV, 16>(__VA_ARGS__);                    \
+        case 25: return FN<HDV, 25>(__VA_ARGS__);                    \
         case 28: return FN<HDV, 28>(__VA_ARGS__);                    \
         default: return CLV_ERR_UNSUPPORTED;                         \
     }

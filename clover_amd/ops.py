@@ -84,8 +84,10 @@ def _dbias_index(g, device):
 def _kname(kernel, g):
     """Device-kernel name as rocprofv3 prints it: template <HD, NKT, DROP, MODE> (attention.hip CLV_PICK)."""
     need = (g.N + 15) // 16
-    nkt = next((o for o in (2, 8, 13, 14, 16, 28) if o >= need), need)       # > 28: the C call reports UNSUPPORTED
+    nkt = next((o for o in (2, 8, 13, 14, 15, 16, 25, 28) if o >= need), need)       # > 28: the C call reports UNSUPPORTED
     drop = 'true' if (g.dropout_p > 0 and g.mode == 0) else 'false'
+    if kernel == 'attn_bwd_dkv_kernel':
+        nkt = (nkt + 1) & ~1                  # the dK / dV kernel runs the next even tile count (attention.hip launch_bwd)
     return f'{kernel}<{g.hd}, {nkt}, {drop}, {g.mode}>'
 
 
