@@ -745,10 +745,13 @@ __global__ void __launch_bounds__(256) dbias_index_kernel(int* __restrict__ tab,
 
 __global__ void __launch_bounds__(256) dbias_gather_tab_kernel(const float* __restrict__ dense, float* __restrict__ dtable,
                                                                const int* __restrict__ tab, int nkt, Geom G, int nsplit,
-                                                               int64_t split_stride) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (w >= G.tlen * G.g.nH) return;
-    const int slot = w / G.g.nH, h = w - slot * G.g.nH;
+                                                               int64_t split_stride, int slot0, int nslots) {
+    // rows [slot0, slot0 + nslots): the band of the table a window of depth wd <= bwd can reach at all (8-frame clips
+    // use 7 of the 15 temporal offsets of the (8, 7, 7) table) — the other rows have no (query, key) pair
+    const int wl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wl >= nslots * G.g.nH) return;
+    const int slot = slot0 + wl / G.g.nH, h = wl % G.g.nH;
+    const int w = slot * G.g.nH + h;
     const int NK = nkt * 16, nqt = (G.g.N + 15) >> 4;
     const float* dh = dense + (int64_t)h * nqt * nkt * 256;
     const int* trow = tab + slot * NK;
@@ -906,9 +909,15 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
                            (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
         (void)dense;
-        if (G.g.dbias_index)
-            hipLaunchKernelGGL(dbias_gather_tab_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias,
-                               G.g.dbias_index, NKT, G, splits, E * 4);
+        if (G.g.dbias_index) {
+            int slot0 = 0, nslots = G.tlen;
+            if (G.g.wd > 0 && G.g.wd < G.g.bwd) {            // temporal offsets |dz| <= wd - 1 only
+                slot0 = (G.g.bwd - G.g.wd) * G.ts_d;
+                nslots = (2 * G.g.wd - 1) * G.ts_d;
+            }
+            hipLaunchKernelGGL(dbias_gather_tab_kernel, dim3((nslots * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias,
+                               G.g.dbias_index, NKT, G, splits, E * 4, slot0, nslots);
+        }
         else
             hipLaunchKernelGGL(dbias_gather_kernel, dim3((G.tlen * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias, NKT, G,
                                splits, E * 4);
