@@ -209,7 +209,7 @@ class SwinTransformerBlock3D(nn.Module):
         if self._fused_ok(x):
             return self._forward_pending_fused(x, DropPath.apply_scale(branch, bscale) if branch is not None else None)
         if branch is None:
-            y1, s0 = self.norm1(x), x
+            y1, s0 = self.norm1(x, return_sum=True)          # s0 = x (a view): its gradient folds into norm1's backward
         else:
             y1, s0 = self.norm1(branch, residual=x, return_sum=True, x_scale=bscale)
         a = self.attn_part(y1)
@@ -232,9 +232,8 @@ class SwinTransformerBlock3D(nn.Module):
         ws, ss, rid = window_geometry((D, H, W), self.window_size, self.shift_size, x.device)
         at = self.attn
         if branch is None:
-            qkv, _ = ops.ln_linear(x, None, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
-                                   self.norm1.eps)
-            s0 = x
+            qkv, s0 = ops.ln_linear(x, None, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
+                                    self.norm1.eps, stream_out=True)
         else:
             qkv, s0 = ops.ln_linear(branch, x, self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias,
                                     self.norm1.eps)

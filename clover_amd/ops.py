@@ -509,7 +509,7 @@ class _FusedLNLinear(torch.autograd.Function):
     + :376).  Takes the raw parameters; the fold and its backward are one small kernel each."""
 
     @staticmethod
-    def forward(ctx, a, r, ln_weight, ln_bias, weight, bias, eps):
+    def forward(ctx, a, r, ln_weight, ln_bias, weight, bias, eps, stream_out=False):
         _need_gpu(a, weight)
         K = a.shape[-1]
         N = weight.shape[0]
@@ -523,6 +523,10 @@ class _FusedLNLinear(torch.autograd.Function):
         ctx.shape = a.shape
         ctx.prefs = (weight, bias, ln_weight, ln_bias)
         y = out['y'].view(a.shape[:-1] + (N,))
+        if r is None and stream_out:
+            # the input doubles as the residual stream of the block (first block of a stage): handing it out HERE makes the
+            # stream's gradient arrive as ds and fold into dx in the LayerNorm-backward kernel — no autograd add kernel
+            return y, a2.view(a.shape)
         return y, (out['sum'].view(a.shape) if r is not None else None)
 
     @staticmethod
@@ -537,12 +541,12 @@ class _FusedLNLinear(torch.autograd.Function):
         # the forward kept the standardised rows: the weight gradient runs on the LDS-DMA kernel
         weight, bias, gamma, beta = ctx.prefs
         dw, db, dg, dbt = _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta)
-        return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None
+        return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None, None
 
 
-def ln_linear(a, r, ln_weight, ln_bias, weight, bias, eps=1e-5):
-    """y = Linear(LayerNorm(a [+ r])), s = a + r (None without r)."""
-    return _FusedLNLinear.apply(a, r, ln_weight, ln_bias, weight, bias, eps)
+def ln_linear(a, r, ln_weight, ln_bias, weight, bias, eps=1e-5, stream_out=False):
+    """y = Linear(LayerNorm(a [+ r])), s = a + r (None without r; a itself with stream_out)."""
+    return _FusedLNLinear.apply(a, r, ln_weight, ln_bias, weight, bias, eps, stream_out)
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -811,7 +815,10 @@ class _LayerNorm(torch.autograd.Function):
         b = _c(beta.float())
         rows = x2.shape[0]
         y = torch.empty_like(x2)
-        ssum = torch.empty_like(x2) if want_sum else None
+        # want_sum without a residual or an operand transform: the "sum" IS the input — hand it out as a view (no copy), so
+        # that the gradient of the stream arrives as dsum and is folded into dx by the backward kernel
+        alias = bool(want_sum) and res is None and xscale is None and not drop_p
+        ssum = torch.empty_like(x2) if (want_sum and not alias) else None
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         xs = rps = seed = None
@@ -826,6 +833,8 @@ class _LayerNorm(torch.autograd.Function):
                                            _ptr(rstd), rows, C_, float(eps), int(f32),
                                            C.byref(ex) if ex is not None else None, _stream()),
               'clv_layernorm_fwd')
+        if alias:
+            ssum = x2
         if want_sum:
             ctx.save_for_backward(ssum, None, g, mean, rstd, xs, seed)    # f(x) + res is all the backward needs
         else:
