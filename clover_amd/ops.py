@@ -439,9 +439,11 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
         ds2 = _c(dsum).view(rows, C_)
         if ds2.dtype != BF16:
             ds2 = ds2.to(BF16)
+    ex = _lib.ClvLnExtra(None, 1, 0.0, None, None, None, 0, 0, 0, 0, 0)
+    ex.no_reduce = 1                        # nobody reads dgamma / dbeta of the affine-free norm: skip their reduction launch
     check(L.clv_layernorm_bwd(_ptr(dxhat), _ptr(x), _ptr(None), _ptr(ones), _ptr(mean), _ptr(rstd), _ptr(ds2),
                               _ptr(dx), _ptr(junk), C.c_void_p(junk.data_ptr() + 4 * C_), _ptr(partial), rows, C_, 0,
-                              None, _stream()), 'clv_layernorm_bwd')
+                              C.byref(ex), _stream()), 'clv_layernorm_bwd')
     return dx
 
 
