@@ -421,8 +421,15 @@ class _Linear(torch.autograd.Function):
 _NOAFFINE_CONST = {}
 
 
-def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
-    """dx = LayerNorm-backward of dxhat w.r.t. x for the affine-free standardisation (+ dsum)."""
+def _raw_bf16(w):
+    wb = getattr(w, '_clv_shadow', None)
+    return wb if wb is not None else w.detach().to(BF16)
+
+
+def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum, gamma=None):
+    """dx = LayerNorm-backward of dxhat w.r.t. x for the affine-free standardisation (+ dsum).  gamma: dxhat is the
+    gradient w.r.t. the AFFINE output (taken through the raw, un-folded weight): the kernel applies gamma itself —
+    d xhat = (dy W) * gamma == dy (W * gamma), so the backward needs no transpose of the folded weight."""
     rows, C_ = x.shape
     L = _lib.lib()
     nblk = L.clv_layernorm_bwd_blocks(rows, C_)
@@ -433,6 +440,8 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum):
         _NOAFFINE_CONST[key] = (torch.ones(C_, device=dev, dtype=torch.float32),
                                 torch.zeros(2 * C_, device=dev, dtype=torch.float32))
     ones, junk = _NOAFFINE_CONST[key]
+    if gamma is not None:
+        ones = _c(gamma.detach().float())
     dx = torch.empty_like(x)
     ds2 = None
     if dsum is not None:
@@ -538,10 +547,11 @@ class _FusedLNLinear(torch.autograd.Function):
         dy2 = _c(dy.reshape(-1, N))
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
-        dxhat = linear_dgrad(dy2, wt)
-        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
-        # the forward kept the standardised rows: the weight gradient runs on the LDS-DMA kernel
         weight, bias, gamma, beta = ctx.prefs
+        # through the raw weight (the engine keeps its transpose fresh); the norm's gamma is applied by the LN backward
+        dxhat = linear_dgrad(dy2, _raw_bf16(weight), weight)
+        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma).view(ctx.shape)
+        # the forward kept the standardised rows: the weight gradient runs on the LDS-DMA kernel
         dw, db, dg, dbt = _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw, db, None, None
 
@@ -591,7 +601,7 @@ class _FusedMLP(torch.autograd.Function):
             do2 = do2.to(BF16)
         # d pre = (d out . W2) * gelu'(pre)
         if rowgemm_supported(Hd, C_) and C_ <= 288:
-            dpre = rowgemm(do2, w2b.t().contiguous(), None, epilogue=2, pre_in=pre)['y']
+            dpre = rowgemm(do2, _wt(ctx.w2ref, w2b), None, epilogue=2, pre_in=pre)['y']
         else:
             dact = torch.mm(do2, w2b)
             dpre = torch.empty_like(dact)
@@ -611,9 +621,9 @@ class _FusedMLP(torch.autograd.Function):
             dw2 = dw2.to(w2.dtype)
             db2 = db2.to(b2.dtype) if db2 is not None else None
         # fc1 + LayerNorm
-        dxhat = linear_dgrad(dpre, wt1)
-        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds).view(ctx.shape)
         w1, b1, gamma, beta = ctx.prefs
+        dxhat = linear_dgrad(dpre, _raw_bf16(w1), w1)
+        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma).view(ctx.shape)
         dw1, db1, dg, dbt = _wgrad_folded(dpre, xhat, xs, mean, rstd, w1, b1, gamma, beta)
         return dx, (dx if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None
 
