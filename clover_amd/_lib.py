@@ -28,7 +28,7 @@ _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 class ClvFoldEntry(C.Structure):
     _fields_ = [('partial', _p), ('dw', _p), ('db', _p), ('nk', _i64), ('e2', _i64), ('splits', _i32),
-                ('sg_shift', _i32), ('block_begin', _i32), ('pad', _i32)]
+                ('sg_shift', _i32), ('block_begin', _i32), ('overwrite', _i32)]
 
 
 FOLD_MAX = 64

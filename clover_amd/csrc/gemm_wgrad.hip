@@ -916,7 +916,8 @@ __global__ void __launch_bounds__(256) fold_batch_kernel(FoldTable tab) {
     }
     if (!in) return;
     float* dst = e < NK ? dw + e : db + (e - NK);
-    float4 o = *reinterpret_cast<const float4*>(dst);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!en.overwrite) o = *reinterpret_cast<const float4*>(dst);   // overwrite: a fresh temporary, never read (nor zeroed)
     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     *reinterpret_cast<float4*>(dst) = o;
 }

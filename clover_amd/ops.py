@@ -251,19 +251,19 @@ def flush_wgrads(pending):
         chunks.append(cur)
     for chunk in chunks:
         arr = (_lib.ClvWgradEntry * len(chunk))()
-        for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
+        for e, (dy2, x2, dw, db, M, N, K, *_) in zip(arr, chunk):
             e.dy, e.x, e.M, e.N, e.K = dy2.data_ptr(), x2.data_ptr(), M, N, K
             e.ldy, e.ldx, e.want_bias = dy2.stride(0), x2.stride(0), int(db is not None)
         check(L.clv_linear_wgrad_batch_plan(arr, len(chunk)), 'clv_linear_wgrad_batch_plan')
         work = torch.empty(max(1, sum(e.work_floats for e in arr)), device=chunk[0][0].device, dtype=torch.float32)
         off = 0
-        for e, (dy2, x2, dw, db, M, N, K) in zip(arr, chunk):
+        for e, (dy2, x2, dw, db, M, N, K, *ow) in zip(arr, chunk):
             if e.work_floats == 0:                   # few-row problem: accumulated in place, nothing to fold
                 e.dw, e.db = dw.data_ptr(), (db.data_ptr() if db is not None else None)
                 continue
             w = work[off:off + e.work_floats]
             e.work = w.data_ptr()
-            folds.append((w, dw, db, N, K, e.splits))
+            folds.append((w, dw, db, N, K, e.splits, bool(ow and ow[0])))
             off += e.work_floats
         if PROF is None:
             check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
@@ -283,9 +283,10 @@ def flush_folds(pending):
     for i in range(0, len(pending), _lib.FOLD_MAX):
         chunk = pending[i:i + _lib.FOLD_MAX]
         arr = (_lib.ClvFoldEntry * len(chunk))()
-        for e, (work, dw, db, N, K, slices) in zip(arr, chunk):
+        for e, (work, dw, db, N, K, slices, *ow) in zip(arr, chunk):
             e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
             e.nk, e.e2, e.splits = N * K, N * K + N, slices
+            e.overwrite = int(bool(ow and ow[0]))
         check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
 
 
@@ -505,9 +506,11 @@ def _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta):
                     for q in ps if q is not None)):
         (M, N), K = dy2.shape, xhat.shape[1]
         if _wgrad_custom(M, N, K):
-            tmp = torch.zeros(N * K + N, device=dy2.device, dtype=torch.float32)
+            in_place = bool(_lib.lib().clv_linear_wgrad_in_place(M, N, K))
+            # partial slices + fold: the fold STORES into the temporary (no zero-fill launch); one in-place slice adds
+            tmp = (torch.zeros if in_place else torch.empty)(N * K + N, device=dy2.device, dtype=torch.float32)
             dwf, dbf = tmp[:N * K].view(N, K), tmp[N * K:]
-            WGRAD_DEFER.append((dy2, xhat, dwf, dbf, M, N, K))
+            WGRAD_DEFER.append((dy2, xhat, dwf, dbf, M, N, K, not in_place))
             POST_DEFER.append(lambda: _unfold_grads(dwf, dbf, weight, bias, gamma, beta))
             return None, None, None, None
     dwf, dbf = linear_wgrad(dy2, xhat, True) if xhat is not None else linear_wgrad(dy2, xs, True, xstats=(mean, rstd))

@@ -223,7 +223,8 @@ typedef struct ClvFoldEntry {
     void* dw;              /* float [N][K], accumulated into */
     void* db;              /* float [N] or NULL */
     int64_t nk, e2;        /* N*K and N*K + N */
-    int32_t splits, sg_shift, block_begin, pad;
+    int32_t splits, sg_shift, block_begin;
+    int32_t overwrite;     /* != 0: dw / db = the sum (an uninitialised temporary), instead of += */
 } ClvFoldEntry;
 /* Grouped launch: the weight gradients of up to 40 Linear layers (a whole backward segment: nothing reads a weight
  * gradient before the optimizer) as ONE grid.  clv_linear_wgrad_batch_plan fills splits and work_floats of every entry
