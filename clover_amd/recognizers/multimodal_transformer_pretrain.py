@@ -10,6 +10,8 @@ LayerNorm only — so batching passes along dim 0 changes no value):
   * MLM head only on the t_fusion half; all B*L rows go through the decoder and the fused
     focal kernel skips label == -100 rows (:134-139) — no data-dependent shapes, no host sync.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -117,9 +119,18 @@ class CloverPretrain(BaseRecognizer):
             text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
             txt_emb_both = self.ssl_head.forward_text(text_out)
 
-        # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack
-        vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
-        visual_emb, mask_visual_emb = vis_emb_both.view(2, B, -1).unbind(0)
+        # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack.
+        # The vision projection head (pool + 2 Linear + 2 LayerNorm + GELU: ~10 launch-bound kernels) feeds only the loss:
+        # it runs on the side stream under the fusion encoder (and, autograd replaying it there, its backward under the
+        # fusion encoder's backward) instead of between the video encoder and the fusion encoder.
+        heads_side = side is not None and os.environ.get('CLOVER_HEADS_SIDE', '1') == '1'
+        if heads_side:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                vis_both.record_stream(side)
+                vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
+        else:
+            vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
         mask_word_emb, text_emb = txt_emb_both.view(2, B, -1).unbind(0)
 
         # ---- fusion: block 0 = t_fusion (clean video, masked text) (:119); block 1 = v_fusion (masked video,
@@ -136,6 +147,10 @@ class CloverPretrain(BaseRecognizer):
 
         mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])                 # :148-149
         mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])          # :156-157
+        if heads_side:
+            main.wait_stream(side)
+            vis_emb_both.record_stream(main)
+        visual_emb, mask_visual_emb = vis_emb_both.view(2, B, -1).unbind(0)
         emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
                            mask_word_recon_emb], dim=1).float()
         return emb, mlm_loss
