@@ -140,16 +140,27 @@ class CloverPretrain(BaseRecognizer):
         t_all = fusion['t_last_hidden_state']
         t_last_hidden_state, v_fusion_t = t_all.unflatten(0, (2, B)).unbind(0)
 
+        # ---- the two reconstruction heads (:148-149, :156-157; a dozen launch-bound kernels) on the side stream, under
+        # the MLM decoder GEMM + focal loss
+        if heads_side:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                t_all.record_stream(side)
+                mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])
+                mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])
+
         # ---- MLM (:129-143): all B*L rows through the decoder, the fused focal kernel skips label == -100
         score = self.mlm_head(t_last_hidden_state)
         fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
         mlm_loss = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
 
-        mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])                 # :148-149
-        mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])          # :156-157
         if heads_side:
             main.wait_stream(side)
-            vis_emb_both.record_stream(main)
+            for t in (vis_emb_both, mask_visual_recon_emb, mask_word_recon_emb):
+                t.record_stream(main)
+        else:
+            mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])             # :148-149
+            mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])      # :156-157
         visual_emb, mask_visual_emb = vis_emb_both.view(2, B, -1).unbind(0)
         emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
                            mask_word_recon_emb], dim=1).float()
