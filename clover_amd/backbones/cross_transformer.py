@@ -51,6 +51,29 @@ class CrossModalTransformerFromPretrained(nn.Module):
             self.fc_in = Linear(img_in_size, hidden_size)
         self.fp16_enabled = False
 
+    def _text_and_pos(self, text_embeddings, T, S, D):
+        tt = self.token_type_embeddings.weight
+        # the two embedding additions as single bf16 kernels (the sums are rounded to bf16 either way; the addends'
+        # own rounding is 2^-9 of a ~0.02-sized embedding)
+        text = to_bf16(text_embeddings) + to_bf16(tt[1])
+        pos = (self.vis_space_pos + self.vis_tempor_pos[:, :T, :, :]).reshape(1, T * S, D) + tt[0]
+        return text, to_bf16(pos)
+
+    def prepare(self, text_input_embeds, text_input_mask, B, T, S):
+        """Everything of forward() that does not depend on the visual tokens — text + token-type embedding, the visual
+        position table, the multimodal key mask — so that a caller can run these ~10 launch-bound kernels early, on the
+        text encoder's stream, instead of between the video encoder and the first fusion layer."""
+        D = self.hidden_size
+        text = text_input_embeds
+        mask = text_input_mask
+        if text.shape[0] != B:
+            text = text.view(B, -1, text.shape[-1])
+            mask = mask.view(B, -1)
+        text, pos = self._text_and_pos(text, T, S, D)
+        n_vis = T * S + (1 if self.all_cls_token is not None else 0)
+        mm_mask = torch.cat([torch.ones(B, n_vis, dtype=mask.dtype, device=text.device), mask], dim=1)
+        return dict(key=(B, T, S), text=text, pos=pos, mask=mm_mask, ext_mask=extended_attention_mask(mm_mask))
+
     def forward(self, visual_token=None, text_input_ids=None, text_input_mask=None, text_input_embeds=None, **kwargs):
         """visual_token [B,T,S,Din]; returns mapping with last/t_/v_last_hidden_state (reference :64-124)."""
         if self.img_in_size != self.hidden_size:
@@ -64,12 +87,14 @@ class CrossModalTransformerFromPretrained(nn.Module):
         if text_embeddings.shape[0] != B:
             text_embeddings = text_embeddings.view(B, -1, text_embeddings.shape[-1])
             text_input_mask = text_input_mask.view(B, -1)
-        tt = self.token_type_embeddings.weight
-        # the two embedding additions as single bf16 kernels (the sums are rounded to bf16 either way; the addends'
-        # own rounding is 2^-9 of a ~0.02-sized embedding)
-        text_embeddings = to_bf16(text_embeddings) + to_bf16(tt[1])
-        pos = (self.vis_space_pos + self.vis_tempor_pos[:, :T, :, :]).reshape(1, T * S, D) + tt[0]
-        visual = self.norm(to_bf16(visual_token.reshape(B, T * S, D)) + to_bf16(pos))
+        prepared = kwargs.get('prepared')
+        if prepared is not None and prepared['key'] == (B, T, S) and not self.use_prompt:
+            text_embeddings, pos, mm_mask_p, ext_mask_p = (prepared['text'], prepared['pos'], prepared['mask'],
+                                                           prepared['ext_mask'])
+        else:
+            text_embeddings, pos = self._text_and_pos(text_embeddings, T, S, D)
+            mm_mask_p = ext_mask_p = None
+        visual = self.norm(to_bf16(visual_token.reshape(B, T * S, D)) + pos)
         if self.use_prompt:
             visual = torch.cat([visual, to_bf16(self.prompt_token).expand(B, -1, -1),
                                 to_bf16(self.all_cls_token).expand(B, -1, -1)], dim=1)
@@ -80,9 +105,13 @@ class CrossModalTransformerFromPretrained(nn.Module):
         else:
             n_vis = T * S
         feat = torch.cat([visual, text_embeddings], dim=1)
-        mm_mask = torch.cat([torch.ones(B, n_vis, dtype=text_input_mask.dtype, device=feat.device),
-                             text_input_mask], dim=1)
-        h = self.bert_encoder(feat, extended_attention_mask(mm_mask))
+        if mm_mask_p is not None:
+            mm_mask, ext_mask = mm_mask_p, ext_mask_p
+        else:
+            mm_mask = torch.cat([torch.ones(B, n_vis, dtype=text_input_mask.dtype, device=feat.device),
+                                 text_input_mask], dim=1)
+            ext_mask = extended_attention_mask(mm_mask)
+        h = self.bert_encoder(feat, ext_mask)
         out = {'last_hidden_state': h,
                't_last_hidden_state': h[:, n_vis:],
                'v_last_hidden_state': h[:, :T * S]}

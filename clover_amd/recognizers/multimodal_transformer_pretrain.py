@@ -100,6 +100,12 @@ class CloverPretrain(BaseRecognizer):
             with torch.cuda.stream(side):
                 text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
                 txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
+                fusion_prep = None
+                if os.environ.get('CLOVER_HEADS_SIDE', '1') == '1' and hasattr(self.multimodal_backbone, 'prepare'):
+                    # the video-independent part of the fusion encoder's input (text + type embeddings, position table,
+                    # key mask) here, behind the text encoder, not between the video encoder and the first fusion layer
+                    mb = self.multimodal_backbone
+                    fusion_prep = mb.prepare(text_out, text_mask2, 2 * B, (imgs.shape[2] + 1) // 2, mb.spacial_tokens)
 
         # ---- video encoder: clean (:91) + masked (:114) pass as one 2B-clip pass, channels-last [2B,T',h,w,Cf]
         vis_both = self.backbone.forward_both(imgs, v_token_mask, mid_cut=video_cut)
@@ -118,6 +124,7 @@ class CloverPretrain(BaseRecognizer):
         else:
             text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
             txt_emb_both = self.ssl_head.forward_text(text_out)
+            fusion_prep = None
 
         # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack.
         # The vision projection head (pool + 2 Linear + 2 LayerNorm + GELU: ~10 launch-bound kernels) feeds only the loss:
@@ -135,8 +142,13 @@ class CloverPretrain(BaseRecognizer):
 
         # ---- fusion: block 0 = t_fusion (clean video, masked text) (:119); block 1 = v_fusion (masked video,
         # clean text) (:117)
+        if side is not None and fusion_prep is not None:
+            for v_ in fusion_prep.values():
+                if torch.is_tensor(v_):
+                    v_.record_stream(main)
         fusion = self.multimodal_backbone(visual_token=vis_both.reshape(2 * B, T, h * w, D),
-                                          text_input_mask=text_mask2, text_input_embeds=text_out)
+                                          text_input_mask=text_mask2, text_input_embeds=text_out,
+                                          prepared=fusion_prep if side is not None else None)
         t_all = fusion['t_last_hidden_state']
         t_last_hidden_state, v_fusion_t = t_all.unflatten(0, (2, B)).unbind(0)
 
