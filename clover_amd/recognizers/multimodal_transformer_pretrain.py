@@ -90,14 +90,15 @@ class CloverPretrain(BaseRecognizer):
         #   text   text_out = [masked caption (:110)  ; un-masked caption (:99)]
         # so that row block 0 of the fusion pass is t_fusion = (clean video, masked text) (:119) and row block 1 is
         # v_fusion = (masked video, clean text) (:117) with both inputs used exactly as the encoders produced them.
-        input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
-        text_ids2 = torch.cat([token_ids, input_ssl_ids], 0)
-        text_mask2 = torch.cat([text_input_mask, text_input_mask], 0)
+        def text_inputs():
+            input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
+            return torch.cat([token_ids, input_ssl_ids], 0), torch.cat([text_input_mask, text_input_mask], 0)
         side = self._text_stream(imgs.device) if imgs.is_cuda and getattr(self, 'overlap_text', True) else None
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                text_ids2, text_mask2 = text_inputs()        # the text tower's own input glue: off the video encoder's stream
                 text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
                 txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
                 fusion_prep = None
@@ -121,7 +122,9 @@ class CloverPretrain(BaseRecognizer):
             main.wait_stream(side)
             text_out.record_stream(main)
             txt_emb_both.record_stream(main)
+            text_mask2.record_stream(main)
         else:
+            text_ids2, text_mask2 = text_inputs()
             text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
             txt_emb_both = self.ssl_head.forward_text(text_out)
             fusion_prep = None

@@ -83,7 +83,10 @@ def test_engine_lr_mult_and_fractional_decay_match_torch_param_groups():
         # compare the mean displacement — a wrong lr_mult shows as a 2-8x ratio
         mine = (p1[n].detach() - p0[n]).abs().mean().item()
         ref = (p.detach() - p0[n]).abs().mean().item()
-        assert 0.6 * ref - 1e-9 <= mine <= 1.6 * ref + 1e-9, (n, mine, ref, o[n])
+        # a key bias shifts every score of a softmax row equally: its exact gradient is zero, what Adam normalises
+        # there is rounding noise of either implementation, and the displacement ratio is not a statement about lr_mult
+        hi = 2.5 if n.endswith('key.bias') else 1.6
+        assert 0.6 * ref - 1e-9 <= mine <= hi * ref + 1e-9, (n, mine, ref, o[n])
         assert ref <= 3.3 * 1e-3 * o[n][1] + 1e-7, (n, ref, o[n])
 
 
