@@ -1308,6 +1308,7 @@ class _PatchEmbed(torch.autograd.Function):
                                              _ptr(clean), _ptr(masked), _ptr(z), _ptr(mean), _ptr(rstd), B, T, H, W,
                                              Cout, mh, mw, float(eps), _stream()), 'clv_patch_embed_fwd')
         ctx.save_for_backward(xc, z, mean, rstd, gf, vm)
+        ctx.prefs = (weight, bias, gamma, beta, mask_token)
         ctx.meta = (B, T, H, W, Cout, want_clean, want_masked, weight.shape,
                     mask_token.shape if mask_token is not None else None)
         ctx.stacked = bool(stacked)
@@ -1334,28 +1335,46 @@ class _PatchEmbed(torch.autograd.Function):
         dc = bf(dclean) if want_clean else None
         dm = bf(dmasked) if want_masked else None
         dmt = None
+        # engine-managed parameters: every gradient goes straight into its fp32 slab view (the conv weight's through the
+        # deferred grouped launch) — this backward closes the video encoder's chain, and a dozen zero-fill / add kernels of
+        # autograd's AccumulateGrad sat on the critical path here
+        weight, bias, gamma, beta, mask_token = ctx.prefs
+        ps = [q for q in (weight, bias, gamma, beta, mask_token if dm is not None else None) if q is not None]
+        sink = all(getattr(q, '_clv_grad', None) is not None and q._clv_grad.dtype == torch.float32
+                   and q._clv_grad.is_contiguous() for q in ps) and (gf is None) == (gamma is None)
         if dm is None:
             dyb = dc
         else:
             # dy = d_clean + d_masked (1 - w), d mask_token = sum d_masked w — one kernel (clv_patch_embed_blend_bwd)
             dyb = torch.empty(M, Cout, device=xc.device, dtype=BF16)
-            dmt = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
+            dmt = (mask_token._clv_grad.view(-1) if sink
+                   else torch.zeros(Cout, device=xc.device, dtype=torch.float32))
             check(L.clv_patch_embed_blend_bwd(_ptr(dc), _ptr(dm), _ptr(vm), _ptr(dyb), _ptr(dmt), B, T, H, W, Cout,
                                               vm.shape[1], vm.shape[2], _stream()), 'clv_patch_embed_blend_bwd')
-            dmt = dmt.reshape(mtshape)
+            dmt = None if sink else dmt.reshape(mtshape)
         if gf is not None:
             nblk = L.clv_layernorm_bwd_blocks(M, Cout)
             partial = torch.empty(2 * nblk * Cout, device=xc.device, dtype=torch.float32)
             dz = torch.empty_like(z)
-            dg = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
-            db = torch.zeros_like(dg)
+            if sink:
+                dg, db = gamma._clv_grad.view(-1), beta._clv_grad.view(-1)
+            else:
+                dg = torch.zeros(Cout, device=xc.device, dtype=torch.float32)
+                db = torch.zeros_like(dg)
             check(L.clv_layernorm_bwd(_ptr(dyb), _ptr(z), _ptr(None), _ptr(gf), _ptr(mean), _ptr(rstd), _ptr(None), _ptr(dz),
                                       _ptr(dg), _ptr(db), _ptr(partial), M, Cout, 0, None, _stream()),
                   'clv_layernorm_bwd')
+            if sink:
+                dg = db = None
         else:
             dz, dg, db = dyb, None, None
         patches = torch.empty(M, 96, device=xc.device, dtype=BF16)
         check(L.clv_im2col_patches(_ptr(xc), _ptr(patches), B, T, H, W, _stream()), 'clv_im2col_patches')
+        if sink:
+            linear_wgrad(dz, patches, True, weight._clv_grad.view(Cout, 96), bias._clv_grad.view(-1))
+            for q in ps:
+                q._clv_ready()
+            return None, None, None, None, None, None, None, None, None, None
         dw, dbias = linear_wgrad(dz, patches, True)
         dw = dw.reshape(wshape)
         return None, dw, dbias, dg, db, dmt, None, None, None, None
