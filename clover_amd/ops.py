@@ -231,13 +231,11 @@ class defer_folds:
         return False
 
 
-def flush_wgrads(pending):
-    """The deferred weight gradients as grouped launches (clv_linear_wgrad_batch, <= 40 problems each); returns the
-    fold entries of their partials."""
-    folds = []
+def wgrad_chunks(pending):
+    """Split the deferred weight gradients (dy, x, dW, db, M, N, K, ...) into launches of <= WGRAD_GROUP_MAX problems.
+    In-place problems (few rows / very large outputs: clv_linear_wgrad_in_place) add into dW without atomics, so two of
+    them with the SAME dW (a Linear applied twice in the segment) never share a launch."""
     L = _lib.lib()
-    # in-place problems (few rows / very large outputs) add into dW without atomics: two of them with the SAME dW (a
-    # Linear applied twice in the segment) must not share a launch
     chunks, cur, seen = [], [], set()
     for item in pending:
         key = item[2].data_ptr() if L.clv_linear_wgrad_in_place(item[4], item[5], item[6]) else None
@@ -249,7 +247,15 @@ def flush_wgrads(pending):
             seen.add(key)
     if cur:
         chunks.append(cur)
-    for chunk in chunks:
+    return chunks
+
+
+def flush_wgrads(pending):
+    """The deferred weight gradients as grouped launches (clv_linear_wgrad_batch, <= 40 problems each); returns the
+    fold entries of their partials."""
+    folds = []
+    L = _lib.lib()
+    for chunk in wgrad_chunks(pending):
         arr = (_lib.ClvWgradEntry * len(chunk))()
         for e, (dy2, x2, dw, db, M, N, K, *_) in zip(arr, chunk):
             e.dy, e.x, e.M, e.N, e.K = dy2.data_ptr(), x2.data_ptr(), M, N, K

@@ -433,3 +433,25 @@ def test_tools_cli_host_side():
             assert b['imgs'].shape[0] == b['index'].numel() == b['token_ids'].shape[0]
             seen += b['index'].tolist()
     assert sorted(seen) == list(range(10))
+
+
+def test_grouped_weight_gradient_chunking():
+    """ops.wgrad_chunks: <= 40 problems per launch, and two in-place problems (few rows, or a large 256-divisible output)
+    with the same dW never in one launch — the in-place kernels add without atomics."""
+    import torch
+    from clover_amd import ops, _lib
+    L = _lib.lib()
+    assert L.clv_linear_wgrad_in_place(512, 768, 3072) == 1 and L.clv_linear_wgrad_in_place(3648, 768, 3072) == 1
+    assert L.clv_linear_wgrad_in_place(12544, 384, 1536) == 0 and L.clv_linear_wgrad_in_place(3136, 768, 768) == 0
+    assert L.clv_linear_wgrad_class(12544, 384, 384) == 0 and L.clv_linear_wgrad_class(3136, 768, 768) == 1
+    assert L.clv_linear_wgrad_class(512, 768, 768) == 0                       # few-row problems stay on 128 x 128 tiles
+    shared = torch.zeros(768, 768)
+    other = [torch.zeros(768, 768) for _ in range(3)]
+    item = lambda dw, M: (None, None, dw, None, M, 768, 768)
+    # partial-mode uses of a shared dW may sit together (their folds run after the launch) ...
+    assert [len(c) for c in ops.wgrad_chunks([item(shared, 12544), item(shared, 12544), item(other[0], 512)])] == [3]
+    # ... two in-place uses may not; an in-place + a partial-mode use may
+    assert [len(c) for c in ops.wgrad_chunks([item(shared, 512), item(other[0], 512), item(shared, 640),
+                                              item(shared, 12544), item(other[1], 512)])] == [2, 3]
+    many = [item(torch.zeros(8, 8), 12544) for _ in range(95)]
+    assert [len(c) for c in ops.wgrad_chunks(many)] == [40, 40, 15]
