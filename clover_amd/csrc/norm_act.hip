@@ -767,19 +767,21 @@ struct LnReduceTable {
     ClvLnReduceEntry e[CLV_LN_REDUCE_MAX];
     int n;
 };
-// block = 64 channels x 16 row-lanes of one entry (see ln_bwd_reduce_kernel); 4 block rows per (entry, channel group)
+// block = 64 channels x 16 row-lanes of one entry (see ln_bwd_reduce_kernel); LNR_YS block rows per (entry, channel
+// group): 16 instead of the first version's 4 — 8 instead of 32 dependent iterations per thread
+constexpr int LNR_YS = 16;
 __global__ void __launch_bounds__(1024) ln_reduce_batch_kernel(LnReduceTable tab) {
     __shared__ float sa[16][64], sb[16][64];
     int idx = 0;
     for (int i = 1; i < tab.n; ++i)
         if ((int)blockIdx.x >= tab.e[i].block_begin) idx = i;
     const ClvLnReduceEntry& en = tab.e[idx];
-    const int lb = blockIdx.x - en.block_begin, cb = lb >> 2, ys = lb & 3;
+    const int lb = blockIdx.x - en.block_begin, cb = lb / LNR_YS, ys = lb % LNR_YS;
     const int cl = threadIdx.x & 63, sp = threadIdx.x >> 6;
     const int c = cb * 64 + cl, C = en.C, nblk = en.nblk;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        for (int i = ys * 16 + sp; i < nblk; i += 64) {
+        for (int i = ys * 16 + sp; i < nblk; i += 16 * LNR_YS) {
             a += en.partial[(int64_t)i * C + c];
             b += en.partial[((int64_t)nblk + i) * C + c];
         }
@@ -808,7 +810,7 @@ extern "C" int clv_ln_reduce_batch(const ClvLnReduceEntry* entries, int32_t n, v
         ClvLnReduceEntry en = entries[i];
         if (!en.partial || !en.dgamma || !en.dbeta || en.nblk <= 0 || en.C <= 0) return CLV_ERR_ARG;
         en.block_begin = blocks;
-        blocks += 4 * ((en.C + 63) / 64);
+        blocks += LNR_YS * ((en.C + 63) / 64);
         tab.e[i] = en;
     }
     tab.n = n;
