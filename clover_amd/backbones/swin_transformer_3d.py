@@ -278,6 +278,8 @@ class PatchMerging(nn.Module):
         """Downsample the stream s + sc * m (the last block's pending residual) without materialising it: gather,
         residual add and DropPath factor all ride in the LayerNorm kernel (ops.merge_layer_norm)."""
         B, D, H, W, C = s.shape
+        if ops.parity.enabled():
+            return self.forward(ops.parity.rnd('stream', s + DropPath.apply_scale(m, sc)))
         if not s.is_cuda or H % 2 or W % 2 or C % 8 or not isinstance(self.norm, LayerNorm):
             return self.forward(s + DropPath.apply_scale(m, sc))
         y = ops.merge_layer_norm(m, self.norm.weight, self.norm.bias, self.norm.eps, residual=s, x_scale=sc)

@@ -771,6 +771,91 @@ __global__ void __launch_bounds__(256) dbias_gather_tab_kernel(const float* __re
     if (lane == 0) dtable[w] += a;
 }
 
+// ------------------------------------------------------------------------- fp32 parity kernel
+// The "parity mode" forward (clv_attn_f32_fwd): q / k / v / o in fp32 storage, every product and the softmax in fp32
+// on the VALU — through the SAME index logic as the bf16 MFMA kernels above (tok_row: roll / partition / reverse;
+// win_lin + tcst: the relative-position table row; region-id compare for the shift mask; additive key mask).  It exists
+// so that the step can be evaluated with fp32 arithmetic end to end and compared with the reference's CPU fp32 path at
+// 1e-3 on the losses (tests/test_parity_gpu.py); it is not on the training path.  One workgroup = one (group, head)
+// and a slice of its queries; one wave = one query row at a time: lane l holds the scores of keys l, l + 64, ...
+constexpr int F32_MAXT = 16;            // <= 1024 keys
+__global__ void __launch_bounds__(256) attn_f32_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ o,
+                                                           const float* __restrict__ table, const int* __restrict__ rid,
+                                                           const float* __restrict__ kmask, Geom G, int round_p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = G.g.N, hd = G.g.hd;
+    int* row_s = reinterpret_cast<int*>(smem);                  // token -> tensor row
+    int* lin_s = row_s + N;                                     // lin(n) of the table's window
+    int* rid_s = lin_s + N;                                     // region id
+    float* kadd_s = reinterpret_cast<float*>(rid_s + N);        // additive key mask
+    float* p_s = kadd_s + N;                                    // [4 waves][N] probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gh = blockIdx.x, grp = gh / G.g.nH, h = gh - grp * G.g.nH;
+    const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    for (int n = tid; n < N; n += 256) {
+        row_s[n] = (int)tok_row(G, grp, n);
+        lin_s[n] = (G.g.mode == 1 && table) ? win_lin(G, n) : 0;
+        rid_s[n] = (G.g.mode == 1 && rid) ? rid[wloc * N + n] : 0;
+        kadd_s[n] = (G.g.mode == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f;
+    }
+    __syncthreads();
+    float* pw = p_s + wave * N;
+    for (int qi = blockIdx.y * 4 + wave; qi < N; qi += 4 * gridDim.y) {
+        const float* qp = q + (int64_t)row_s[qi] * G.g.ldq + h * hd;
+        const int linq = lin_s[qi] + G.tcst + G.tb0, rq = rid_s[qi];
+        float s[F32_MAXT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < F32_MAXT; ++t) {
+            const int j = t * 64 + lane;
+            s[t] = -INFINITY;
+            if (j < N) {
+                const float* kp = k + (int64_t)row_s[j] * G.g.ldk + h * hd;
+                float dot = 0.f;
+                for (int d = 0; d < hd; d += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(qp + d);
+                    const float4 b = *reinterpret_cast<const float4*>(kp + d);
+                    dot = fmaf(a.x, b.x, dot); dot = fmaf(a.y, b.y, dot);
+                    dot = fmaf(a.z, b.z, dot); dot = fmaf(a.w, b.w, dot);
+                }
+                float sc = dot * G.g.scale;
+                if (G.g.mode == 1 && table) sc += table[(int64_t)(linq - lin_s[j]) * G.g.nH + h];
+                if (G.g.mode == 1 && rid && rid_s[j] != rq) sc += -100.0f;
+                sc += kadd_s[j];
+                s[t] = sc;
+                m = fmaxf(m, sc);
+            }
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < F32_MAXT; ++t) {
+            const int j = t * 64 + lane;
+            if (j < N) {
+                float e = expf(s[t] - m);
+                if (round_p) e = bf2f(f2bf(e));       // emulate the bf16 P operand of the MFMA kernels
+                s[t] = e;
+                sum += e;
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < F32_MAXT; ++t) {
+            const int j = t * 64 + lane;
+            if (j < N) pw[j] = s[t];
+        }
+        __builtin_amdgcn_wave_barrier();                  // a wave's own LDS operations execute in order
+        if (lane < hd) {
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc = fmaf(pw[j], v[(int64_t)row_s[j] * G.g.ldv + h * hd + lane], acc);
+            o[(int64_t)row_s[qi] * G.g.ldo + h * hd + lane] = acc * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------- host side
 bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (!g) return false;
@@ -1014,3 +1099,20 @@ extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const v
     DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st)
 }
 
+
+extern "C" int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias,
+                                const int32_t* rid, const float* kmask, const ClvAttnGeom* geom, int32_t round_p,
+                                void* stream) {
+    Geom G;
+    if (!q || !k || !v || !o || !make_geom(geom, G)) return CLV_ERR_ARG;
+    if (bias && (G.g.mode != 1 || G.tlen == 0)) return CLV_ERR_ARG;
+    if (rid && G.g.mode != 1) return CLV_ERR_ARG;
+    if (G.g.N > F32_MAXT * 64 || G.drop_thresh) return CLV_ERR_UNSUPPORTED;      // forward-only, eval-mode kernel
+    const size_t lds = (size_t)G.g.N * (4 * 4 + 4 * 4);
+    const int pairs = G.g.groups * G.g.nH;
+    int ysplit = 1;
+    while (pairs * ysplit < 2048 && ysplit * 8 <= G.g.N) ysplit *= 2;
+    hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(pairs, ysplit), dim3(256), lds, (hipStream_t)stream, q, k, v, o, bias, rid,
+                       kmask, G, round_p);
+    return clv_check_launch();
+}

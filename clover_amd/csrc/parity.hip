@@ -1,0 +1,101 @@
+// fp32 GEMM of the parity mode (gfx950): C = A . B^T + bias on the exact-f32 matrix instruction
+// (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, MI355X_MICROARCH.md "Matrix cores").
+//
+// The parity mode evaluates the Clover step with fp32 storage and fp32 arithmetic through the same host graph and
+// the same index logic as the bf16 path, so that its losses can be compared with the reference's CPU fp32 path at the
+// north-star tolerance (1e-3) — see clover_amd/parity.py and tests/test_parity_gpu.py.  This kernel stands in for every
+// Linear of the path there (torch.nn.Linear at swin_transformer_3d.py:257-259,361-366,527, transformers' BertSelfAttention /
+// BertIntermediate / BertOutput, mlm_itm_head.py:33-41).  It is a plain LDS-tiled kernel (64 x 64 x 16 tiles, 4 waves,
+// 32 x 32 per wave): throughput is not its job.
+#include "common.hpp"
+#include "../../include/clover_hip.h"
+
+namespace {
+
+constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16, SG_LD = SG_BK + 1;
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) sgemm_tiled_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          const float* __restrict__ bias, float* __restrict__ C, int M,
+                                                          int N, int K, int64_t lda, int64_t ldb, int64_t ldc) {
+    __shared__ float As[SG_BM * SG_LD], Bs[SG_BN * SG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lg = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int srow = tid >> 2, sk = (tid & 3) * 4;            // staging: one float4 of A and of B per thread
+    for (int k0 = 0; k0 < K; k0 += SG_BK) {
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
+        const int am = m0 + srow, bn = n0 + srow;
+        if (VEC) {
+            if (am < M) av = *reinterpret_cast<const float4*>(A + am * lda + k0 + sk);
+            if (bn < N) bv = *reinterpret_cast<const float4*>(B + bn * ldb + k0 + sk);
+        } else {
+            float* a4 = reinterpret_cast<float*>(&av);
+            float* b4 = reinterpret_cast<float*>(&bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = k0 + sk + e;
+                if (am < M && kk < K) a4[e] = A[am * lda + kk];
+                if (bn < N && kk < K) b4[e] = B[bn * ldb + kk];
+            }
+        }
+        __syncthreads();                                      // the previous step's fragment reads are done
+        float* as = As + srow * SG_LD + sk;
+        float* bs = Bs + srow * SG_LD + sk;
+        as[0] = av.x; as[1] = av.y; as[2] = av.z; as[3] = av.w;
+        bs[0] = bv.x; bs[1] = bv.y; bs[2] = bv.z; bs[3] = bv.w;
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < SG_BK; k4 += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[(wr + i * 16 + lr) * SG_LD + k4 + lg];
+                b[i] = Bs[(wc + i * 16 + lr) * SG_LD + k4 + lg];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // acc[i][j][r] = C[m0 + wr + i*16 + lg*4 + r][n0 + wc + j*16 + lr]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cn = n0 + wc + j * 16 + lr;
+            if (cn >= N) continue;
+            const float bb = bias ? bias[cn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cm = m0 + wr + i * 16 + lg * 4 + r;
+                if (cm < M) C[cm * ldc + cn] = acc[i][j][r] + bb;
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
+                            int32_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream) {
+    if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || lda < K || ldb < K || ldc < N) return CLV_ERR_ARG;
+    if (M == 0) return CLV_OK;
+    if (M > 0x7fffffff) return CLV_ERR_UNSUPPORTED;
+    const dim3 grid((N + SG_BN - 1) / SG_BN, (unsigned)((M + SG_BM - 1) / SG_BM));
+    const bool vec = (K % SG_BK == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(sgemm_tiled_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K,
+                           lda, ldb, ldc);
+    else
+        hipLaunchKernelGGL(sgemm_tiled_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K,
+                           lda, ldb, ldc);
+    return clv_check_launch();
+}

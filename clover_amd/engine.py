@@ -181,6 +181,9 @@ class CloverEngine:
         self._captures = {}                    # batch-shape signature -> the captured graphs + their static tensors
         self._active_sig = None
         device = next(model.parameters()).device
+        if device.type != 'cuda':
+            raise RuntimeError('CloverEngine drives the HIP kernels: move the model to an MI355X first (there is no '
+                               f'CPU path; got parameters on {device})')
         pw = paramwise_cfg or dict(norm_decay_mult=0.0, bias_decay_mult=0.0,
                                    custom_keys={'absolute_pos_embed': dict(decay_mult=0.),
                                                 'relative_position_bias_table': dict(decay_mult=0.)})
@@ -222,7 +225,7 @@ class CloverEngine:
         self.segments = [_Segment(members, wd, device, lr_mult=lm)
                          for (wd, lm), members in sorted(classes.items(), key=lambda kv: (-kv[0][0], kv[0][1]))]
         self.sumsq = torch.zeros(1, device=device, dtype=torch.float32)
-        self.optim_state = ops.optim_state_new(device) if device.type == 'cuda' else None
+        self.optim_state = ops.optim_state_new(device)
         self.num_params = sum(p.numel() for _, p in used)
 
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
@@ -342,9 +345,11 @@ class CloverEngine:
             if collectives_active():
                 packed = packed / self.world
                 dist.all_reduce(packed)
+            else:
+                packed = packed.clone()        # the graph's static output: the next replay overwrites it
             from .recognizers.base import LazyLogVars
             log_vars = LazyLogVars(names, packed)
-            loss = loss.detach()
+            loss = loss.detach().clone()
         else:
             emb = self._static_emb.detach().requires_grad_()
             mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
@@ -562,6 +567,10 @@ class CloverEngine:
         assert len(self.segments) == len(state['segments']), 'optimizer state belongs to a different parameter layout'
         for sg, st in zip(self.segments, state['segments']):
             assert list(sg.names) == list(st['names']), 'optimizer state belongs to a different parameter layout'
+            for key in ('weight_decay', 'lr_mult'):          # the slab's options are baked into its AdamW launch
+                if key in st and abs(float(st[key]) - float(getattr(sg, key))) > 1e-12:
+                    raise ValueError(f'optimizer state was saved with {key}={st[key]} for the slab of {sg.names[0]} ... '
+                                     f'but the current paramwise_cfg gives {getattr(sg, key)}')
             sg.exp_avg.copy_(st['exp_avg'])
             sg.exp_avg_sq.copy_(st['exp_avg_sq'])
         self.refresh_shadow()

@@ -16,6 +16,9 @@ BF16 = torch.bfloat16
 
 
 def to_bf16(t):
+    """Activation storage type of the path: bf16 (fp32 in parity mode, clover_amd/parity.py)."""
+    if ops.parity.enabled():
+        return ops.parity.f32(t)
     return t if t.dtype == BF16 else t.to(BF16)
 
 

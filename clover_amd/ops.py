@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, parity
 from ._lib import ClvAttnGeom, check
 
 BF16 = torch.bfloat16
@@ -285,9 +285,26 @@ def flush_wgrads(pending):
     return folds
 
 
+def fold_chunks(pending):
+    """Split the deferred folds (partial, dW, db, ...) into launches of <= FOLD_MAX entries in which no dW (and no db)
+    appears twice: fold_batch_kernel adds with a plain load / add / store, every entry from its own blocks, so two
+    entries with one target in ONE launch would race (a Linear applied twice inside a backward segment on the partial
+    path — ADVICE r2).  Successive launches on the stream are ordered."""
+    chunks, cur, seen = [], [], set()
+    for item in pending:
+        keys = {item[1].data_ptr()} | ({item[2].data_ptr()} if item[2] is not None else set())
+        if len(cur) == _lib.FOLD_MAX or (keys & seen):
+            chunks.append(cur)
+            cur, seen = [], set()
+        cur.append(item)
+        seen |= keys
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
 def flush_folds(pending):
-    for i in range(0, len(pending), _lib.FOLD_MAX):
-        chunk = pending[i:i + _lib.FOLD_MAX]
+    for chunk in fold_chunks(pending):
         arr = (_lib.ClvFoldEntry * len(chunk))()
         for e, (work, dw, db, N, K, slices, *ow) in zip(arr, chunk):
             e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
@@ -644,11 +661,13 @@ def fused_mlp(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps=1e-5):
 
 def fused_block_supported(C_, hidden):
     """Widths for which the fused LN+projection / MLP kernels are used (stage-0 Swin-T/B: 96, 128)."""
-    return (C_ <= 128 and rowgemm_supported(3 * C_, C_, True) and rowgemm_supported(hidden, C_, True)
+    return (not parity.enabled() and C_ <= 128 and rowgemm_supported(3 * C_, C_, True) and rowgemm_supported(hidden, C_, True)
             and hidden % 32 == 0)
 
 
 def linear(x, weight, bias=None):
+    if parity.enabled():
+        return parity.linear(x, weight, bias)
     return _Linear.apply(x, weight, bias)
 
 
@@ -717,7 +736,7 @@ class _MlpGelu(torch.autograd.Function):
 def mlp_gelu_ok(x, hidden):
     """The fused-activation MLP is used where its fc1 GEMM (contraction C, 4C outputs) is one of clv_gemm_nt's shapes."""
     x2 = x.reshape(-1, x.shape[-1])
-    return x.is_cuda and x.dtype == BF16 and own_gemm_ok(x2, hidden, x.shape[-1])
+    return not parity.enabled() and x.is_cuda and x.dtype == BF16 and own_gemm_ok(x2, hidden, x.shape[-1])
 
 
 def mlp_gelu(x, w1, b1, w2, b2):
@@ -926,6 +945,14 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_sca
     f: optional dropout(p = x_dropout_p) then per-sample factor x_scale [B] on x (fused, see _LayerNorm).
     return_sum=True -> (y, f(x) + residual);  fork=True -> y is returned twice (y, y2 share storage; use one
     for each consumer and their gradients meet inside the LayerNorm backward kernel)."""
+    if parity.enabled():                      # fp32 storage: the same kernels in their fp32 instantiation, forward only
+        with torch.no_grad():
+            y, s, _ = _LayerNorm.apply(x.float(), residual.float() if residual is not None else None, weight, bias, eps,
+                                       bool(return_sum), x_scale, float(x_dropout_p), False)
+        y = parity.rnd('act', y)
+        s = parity.rnd('stream', s) if return_sum else None
+        out = (y,) + ((s,) if return_sum else ()) + ((y,) if fork else ())
+        return out if len(out) > 1 else y
     y, s, y2 = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum), x_scale, float(x_dropout_p), bool(fork))
     out = (y,) + ((s,) if return_sum else ()) + ((y2,) if fork else ())
     return out if len(out) > 1 else y
@@ -996,6 +1023,7 @@ class _MergeLayerNorm(torch.autograd.Function):
 def merge_layer_norm(x, weight, bias, eps=1e-5, residual=None, x_scale=None):
     """LayerNorm(PatchMerging-gather(x_scale[b] * x + residual)): x, residual bf16 [B, D, H, W, C] (H, W even, C % 8 == 0)
     -> bf16 [B, D, H/2, W/2, 4C] in the reference's concat order."""
+    assert not parity.enabled(), 'parity mode takes the unfused PatchMerging route'
     return _MergeLayerNorm.apply(x, residual, weight, bias, eps, x_scale)
 
 
@@ -1027,6 +1055,9 @@ class _Gelu(torch.autograd.Function):
 
 def gelu(x):
     """erf GELU (nn.GELU / HF 'gelu'), bf16 or fp32 storage."""
+    if parity.enabled():
+        with torch.no_grad():
+            return parity.rnd('act', _Gelu.apply(x.float()))
     return _Gelu.apply(x)
 
 
@@ -1153,6 +1184,8 @@ def window_attention(qkv, table, rid, window, shift, num_heads, table_window=Non
     kw = dict(mode=1, groups=B * nW, N=N, nH=num_heads, hd=hd, D=D, H=H, W=W, wd=window[0], wh=window[1],
               ww=window[2], sd=shift[0], sh=shift[1], sw=shift[2], bwd=tw[0], bwh=tw[1], bww=tw[2],
               scale=float(hd) ** -0.5)
+    if parity.enabled():
+        return parity.attention(qkv, table, rid, None, kw)
     return _Attention.apply(qkv, table, rid, None, kw, None)
 
 
@@ -1270,6 +1303,9 @@ def seq_attention(qkv, kmask, num_heads, dropout_p=0.0):
     Up to 448 tokens: the fused LDS-resident kernels; longer sequences: the unfused GEMM + row-softmax path."""
     B, S, C3 = qkv.shape
     hd = C3 // 3 // num_heads
+    if parity.enabled():
+        return parity.attention(qkv, None, None, kmask, dict(mode=0, groups=B, N=S, nH=num_heads, hd=hd,
+                                                            scale=float(hd) ** -0.5, dropout_p=float(dropout_p)))
     if S > SEQ_FUSED_MAX_KEYS:
         seed = next_dropout_seed(qkv.device) if dropout_p > 0 else None
         return _LongSeqAttention.apply(qkv, kmask, num_heads, float(dropout_p), seed)
@@ -1389,6 +1425,8 @@ class _PatchEmbed(torch.autograd.Function):
 def patch_embed(x, weight, bias, gamma, beta, mask_token=None, vmask=None, want_clean=True, eps=1e-5):
     """PatchEmbed3D + LN + mask-token blend. x fp32 [B,3,T,H,W] (already padded).
     Returns (clean, masked) bf16 [B,T/2,H/4,W/4,C] channels-last (masked None without vmask)."""
+    if parity.enabled():
+        return parity.patch_embed(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps)
     clean, masked = _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps)
     return (clean if want_clean else None), (masked if vmask is not None else None)
 
@@ -1396,6 +1434,8 @@ def patch_embed(x, weight, bias, gamma, beta, mask_token=None, vmask=None, want_
 def patch_embed_stacked(x, weight, bias, gamma, beta, mask_token, vmask, eps=1e-5):
     """As patch_embed, but the clean and the masked tokens are written as the two halves of one bf16
     [2B,T/2,H/4,W/4,C] tensor (clean first) — the layout the doubled Swin pass consumes, without a cat."""
+    if parity.enabled():
+        return parity.patch_embed(x, weight, bias, gamma, beta, mask_token, vmask, True, eps, stacked=True)
     return _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, True, eps, True)[0]
 
 

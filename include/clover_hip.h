@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 4
+#define CLV_ABI_VERSION 5
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -380,6 +380,23 @@ int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float ma
                    void* stream);
 int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow, const void* state, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* ------------------------------------------------------------------ parity mode (fp32 storage + fp32 arithmetic)
+ * The reference's CPU path is fp32 (north_star: "match the reference mmaction CPU path ... losses within 1e-3").  The
+ * training path above computes on bf16 MFMA operands; these two entry points let the SAME host graph (registered modules,
+ * window geometry, token maps, bias-table indexing, masks, heads, losses) run with fp32 storage and fp32 arithmetic so the
+ * step losses can be asserted at 1e-3 against the reference goldens.  Forward only.
+ *
+ * clv_sgemm_nt: C[M][N] (ldc) = A[M][K] (lda) . B[N][K]^T (ldb) + bias[N] — every nn.Linear of the path
+ *   (swin_transformer_3d.py:257-259,361-366,527; transformers BertSelfAttention / BertIntermediate / BertOutput as called
+ *   from bert_from_hugface.py:30, cross_transformer.py:109-110; mlm_itm_head.py:33-41) on the exact-f32 MFMA 16x16x4.
+ * clv_attn_f32_fwd: clv_attn_fwd's arithmetic (both modes, same ClvAttnGeom, strides in floats) on fp32 q / k / v / o;
+ *   round_p != 0 rounds the un-normalised probabilities to bf16 before P.V (emulates the MFMA kernels' P operand — used
+ *   by the error-isolation runs recorded in DESIGN.md). */
+int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
+                 int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias, const int32_t* rid,
+                     const float* kmask, const ClvAttnGeom* geom, int32_t round_p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -402,3 +402,71 @@ def test_checkpoint_roundtrip_through_engine(tmp_path):
     # e1 has moved on by two steps since the save; the text encoder moved by at most 2 * lr per weight
     k = 'text_backbone.bert.encoder.layer.1.attention.self.query.weight'
     assert (p1[k] - pf[k]).abs().max().item() <= 2.5 * 2e-4
+
+
+# ----------------------------------------------------------------------------- runner + CLI on the GPU
+def test_runner_two_loader_epoch_on_the_engine(tmp_path):
+    """CloverRunner.run() (clover_runner.py:76-93 interleave) driving CloverEngine in hipGraph mode over a video
+    loader and an image loader, 2 batch indices each: hook order, the reference's log_vars keys, one LR per batch
+    index shared by both loaders' steps, four optimizer steps, one graph set per batch geometry, a checkpoint in
+    the reference's layout that resumes."""
+    from clover_amd.engine import CloverEngine, cosine_lr
+    from clover_amd.runner import CheckpointHook, CloverRunner, Hook, LogHook, LrUpdaterHook
+    vid = [batch(2, f'run_v{i}') for i in range(2)]
+    img = [{k: v.to(DEV) for k, v in cf.cf_batch(2, frames=1, tag=f'run_i{i}').items()} for i in range(2)]
+    m = make_model()
+    eng = CloverEngine(m, vid[0], lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+    eng.dry_step(vid[0])
+    assert eng.capture(vid[0])
+    events = []
+
+    class Rec(Hook):
+        def before_run(self, r): events.append('before_run')
+        def before_train_epoch(self, r): events.append('before_epoch')
+        def before_train_iter(self, r): events.append(('before_iter', r.iter, r.inner_iter))
+        def after_train_iter(self, r): events.append(('after_iter', r.iter, sorted(dict(r.outputs['log_vars']))))
+        def after_train_epoch(self, r): events.append('after_epoch')
+        def after_run(self, r): events.append('after_run')
+
+    r = CloverRunner(eng, model=m, work_dir=str(tmp_path), max_epochs=1)
+    lrh = LrUpdaterHook(1e-3, min_lr_ratio=1e-3, warmup='linear', warmup_iters=1, warmup_ratio=0.001, warmup_by_epoch=True)
+    log = LogHook(interval=1)
+    for h in (lrh, Rec(), log, CheckpointHook(str(tmp_path), 1)):
+        r.register_hook(h)
+    r.run([vid, img], [('train', 1)], 1)
+    torch.cuda.synchronize()
+    assert events[0] == 'before_run' and events[1] == 'before_epoch' and events[-2:] == ['after_epoch', 'after_run']
+    iters = [e for e in events if isinstance(e, tuple)]
+    assert [e[0] for e in iters] == ['before_iter', 'after_iter'] * 4
+    assert [e[1] for e in iters if e[0] == 'before_iter'] == [0, 0, 1, 1]          # runner.iter counts batch indices
+    keys = ['loss', 'mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'rank_v_vm_loss', 'v_nce_loss']
+    assert all(e[2] == keys for e in iters if e[0] == 'after_iter')
+    want = [cosine_lr(1e-3, it, 2, 1e-3, 2, 0.001) for it in (0, 0, 1, 1)]          # warm-up: 1 epoch x 2 indices
+    assert lrh.history == pytest.approx(want) and eng.last_lr == pytest.approx(want[-1])
+    assert eng.adam_steps() == 4 and len(eng._captures) == 2
+    assert len(log.records) == 4 and all(torch.isfinite(torch.tensor(rec['loss'])) for rec in log.records)
+    ck = torch.load(str(tmp_path / 'epoch_1.pth'), map_location='cpu')
+    assert set(ck) == {'meta', 'state_dict', 'optimizer'} and ck['meta']['epoch'] == 1 and ck['meta']['iter'] == 2
+    m2 = make_model()
+    eng2 = CloverEngine(m2, vid[0], lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+    r2 = CloverRunner(eng2, model=m2, max_epochs=2)
+    r2.resume(str(tmp_path / 'epoch_1.pth'))
+    assert r2.epoch == 1 and r2.iter == 2 and eng2.adam_steps() == 4
+
+
+def test_tools_train_cli_two_loaders(tmp_path):
+    """tools/train.py (tools/train.py:26-88,259-340 of the reference) end to end in a child process: config file with
+    `_base_`, --cfg-options overrides, linear LR scaling, hipGraph capture per geometry, log lines and the checkpoint."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    syn = "data.synthetic=[{'length':2,'frames':8,'tokens':32},{'length':2,'frames':1,'tokens':32}]"
+    cmd = [sys.executable, os.path.join(root, 'tools', 'train.py'), os.path.join(root, 'configs', 'pretrain_synthetic.py'),
+           '--launcher', 'none', '--work_dir', str(tmp_path), '--seed', '3',
+           '--cfg-options', 'total_epochs=1', 'videos_per_gpu=2', 'log_config.interval=1', syn]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [ln for ln in out.stdout.splitlines() if "'mlm_loss'" in ln]
+    assert len(recs) == 4, out.stdout[-2000:]
+    assert os.path.exists(os.path.join(str(tmp_path), 'epoch_1.pth'))

@@ -448,10 +448,17 @@ def test_grouped_weight_gradient_chunking():
     shared = torch.zeros(768, 768)
     other = [torch.zeros(768, 768) for _ in range(3)]
     item = lambda dw, M: (None, None, dw, None, M, 768, 768)
-    # partial-mode uses of a shared dW may sit together (their folds run after the launch) ...
+    # partial-mode uses of a shared dW may sit together in the GEMM launch (each writes its own partial buffer; their
+    # folds are separated below) ...
     assert [len(c) for c in ops.wgrad_chunks([item(shared, 12544), item(shared, 12544), item(other[0], 512)])] == [3]
     # ... two in-place uses may not; an in-place + a partial-mode use may
     assert [len(c) for c in ops.wgrad_chunks([item(shared, 512), item(other[0], 512), item(shared, 640),
                                               item(shared, 12544), item(other[1], 512)])] == [2, 3]
     many = [item(torch.zeros(8, 8), 12544) for _ in range(95)]
     assert [len(c) for c in ops.wgrad_chunks(many)] == [40, 40, 15]
+    # the folds of two partial-mode uses of ONE dW (or db) never share a launch: the fold kernel adds without atomics
+    w = [torch.zeros(4) for _ in range(4)]
+    fold = lambda dw, db=None: (torch.zeros(1), dw, db, 2, 2, 4)
+    assert [len(c) for c in ops.fold_chunks([fold(shared), fold(other[0]), fold(shared), fold(other[1])])] == [2, 2]
+    assert [len(c) for c in ops.fold_chunks([fold(other[0], w[0]), fold(other[1], w[0]), fold(other[2], w[1])])] == [1, 2]
+    assert [len(c) for c in ops.fold_chunks([fold(torch.zeros(2, 2)) for _ in range(130)])] == [64, 64, 2]

@@ -534,6 +534,26 @@ def test_grouped_weight_gradients_shared_sink():
     assert rel(dw, ref_w) < 2e-5 and rel(db, ref_b) < 2e-5
 
 
+@pytest.mark.parametrize('group', ['1', '0'])           # grouped launch / per-layer partial kernels with deferred folds
+def test_two_partial_mode_uses_of_one_weight(group, monkeypatch):
+    """a many-row Linear applied TWICE inside one backward segment — both uses write fp32 partials and both
+    folds target the same dW / db.  The batched fold adds without atomics, so the two folds must go out as separate
+    launches (ops.fold_chunks); repeated to give a race the chance to show."""
+    monkeypatch.setenv('CLOVER_GROUP_WGRAD', group)
+    N, K = 384, 384
+    for trial in range(4):
+        dw0, db0 = rnd(N, K, seed=700 + trial), rnd(N, seed=710 + trial)
+        dw, db = dw0.clone().to(DEV), db0.clone().to(DEV)
+        ref_w, ref_b = dw0.clone().double(), db0.clone().double()
+        with ops().defer_folds():
+            for i, M in enumerate((3136, 3136, 12544, 12544)):
+                dy, x = rnd(M, N, seed=720 + 4 * trial + i).to(BF), rnd(M, K, seed=740 + 4 * trial + i).to(BF)
+                assert ops().linear_wgrad(dy.to(DEV), x.to(DEV), True, dw, db) == (None, None)
+                ref_w += dy.double().t() @ x.double()
+                ref_b += dy.double().sum(0)
+        assert rel(dw, ref_w) < 2e-5 and rel(db, ref_b) < 2e-5, (trial, rel(dw, ref_w), rel(db, ref_b))
+
+
 def test_transpose_batch():
     shapes = [(384, 1536), (96, 288), (100, 72), (64, 64), (30522 // 6, 768), (7, 5)]
     src = torch.zeros(sum(r * c for r, c in shapes) + 64, dtype=BF)

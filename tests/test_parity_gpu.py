@@ -1,0 +1,175 @@
+"""Parity mode (clover_amd/parity.py): the step with fp32 storage + fp32 arithmetic on the HIP kernels, asserted at
+the north-star tolerance — all six step losses within 1e-3 of the REFERENCE's own numbers (goldens, config 1) and of the
+oracle at BASELINE config 2's and config 4's shapes — plus the fp32 kernels against fp64 torch restatements built from
+the oracle's index helpers.  `-m gpu` only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+import gutil
+
+pytestmark = pytest.mark.gpu
+
+from oracle import indexing as ix          # noqa: E402
+from oracle import model as om             # noqa: E402
+
+DEV = 'cuda'
+LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']
+PARITY_TOL = 1e-3                      # north_star: "losses/logits within 1e-3"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('M,N,K', [(777, 288, 96), (64, 64, 16), (1000, 30522, 768), (50, 100, 52), (3, 5, 7),
+                                   (6272, 1152, 384), (1, 768, 3072)])
+@pytest.mark.parametrize('bias', [True, False])
+def test_sgemm_nt(M, N, K, bias):
+    from clover_amd import parity
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bb = rnd(N, seed=3) if bias else None
+    ref = a.double() @ b.double().t() + (bb.double() if bias else 0)
+    with parity.mode():
+        c = parity.sgemm(a.to(DEV), b.to(DEV), bb.to(DEV) if bias else None)
+    assert c.dtype == torch.float32 and rel(c, ref) < 2e-6, rel(c, ref)
+
+
+def test_sgemm_nt_strided_rows():
+    from clover_amd import parity
+    a = rnd(100, 200, seed=4).to(DEV)[:, :96]               # lda = 200
+    b = rnd(60, 96, seed=5).to(DEV)
+    with parity.mode():
+        c = parity.sgemm(a, b)
+    assert rel(c, a.double() @ b.double().t()) < 2e-6
+
+
+WIN_CASES = [
+    (2, 4, 14, 14, 96, 3, False), (2, 4, 14, 14, 96, 3, True), (1, 2, 14, 14, 48, 3, True), (2, 4, 7, 7, 64, 2, True),
+    (1, 16, 14, 14, 64, 2, True), (1, 4, 14, 14, 128, 2, True),
+]
+
+
+@pytest.mark.parametrize('case', WIN_CASES)
+def test_window_attention_f32(case):
+    """clv_attn_f32_fwd (mode 1) == roll + partition + WindowAttention3D + reverse + un-roll (swin_transformer_3d.py:375-397,
+    459-476) in fp64, over the oracle's index helpers: token map, relative_position_index[:N,:N], compute_mask."""
+    from test_kernels_gpu import ref_window_attention
+    from clover_amd import ops, parity
+    from clover_amd.backbones.swin_transformer_3d import window_geometry
+    B, D, H, W, C, nH, shifted = case
+    cfg_ws, cfg_ss = (8, 7, 7), ((4, 3, 3) if shifted else (0, 0, 0))
+    qkv = rnd(B, D, H, W, 3 * C, seed=11)
+    table = rnd((2 * 8 - 1) * 13 * 13, nH, scale=0.5, seed=12)
+    o_ref = ref_window_attention(qkv.double(), table.double(), ix.relative_position_index(cfg_ws), cfg_ws, cfg_ss, nH)
+    ws, ss, rid = window_geometry((D, H, W), cfg_ws, cfg_ss, DEV)
+    with parity.mode():
+        o = ops.window_attention(qkv.to(DEV), table.to(DEV), rid, ws, ss, nH, table_window=cfg_ws)
+    assert o.dtype == torch.float32 and rel(o, o_ref) < 1e-5, rel(o, o_ref)
+
+
+@pytest.mark.parametrize('B,S,nH,hd', [(3, 16, 2, 64), (2, 228, 12, 64), (2, 40, 4, 32), (2, 816, 12, 64), (1, 1000, 2, 16)])
+def test_seq_attention_f32(B, S, nH, hd):
+    from clover_amd import ops, parity
+    Hd = nH * hd
+    qkv = rnd(B, S, 3 * Hd, seed=21)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[0, S - 5:] = 0
+    ext = om.extended_mask(mask)
+    q, k, v = qkv.double().view(B, S, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    p = (q @ k.transpose(-1, -2) / hd ** 0.5 + ext.double()).softmax(-1)
+    o_ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, Hd)
+    with parity.mode():
+        o = ops.seq_attention(qkv.to(DEV), ext.reshape(B, S).to(DEV).contiguous(), nH)
+    assert o.dtype == torch.float32 and rel(o, o_ref) < 1e-5, rel(o, o_ref)
+
+
+# ----------------------------------------------------------------------------- the step, config 1: reference goldens
+@pytest.fixture(scope='module')
+def model():
+    import clover_amd
+    m = clover_amd.build_model(cf.tiny_model_cfg())
+    m.load_state_dict(cf.cf_state(gutil.manifest()), strict=False)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_parity_step_losses_vs_reference(model, B):
+    """BASELINE config 1, closed-form weights: the six losses of train_step in parity mode against the numbers the
+    REFERENCE itself produced (tests/golden/g_step.npz), at 1e-3."""
+    from clover_amd import parity
+    g = gutil.load('g_step.npz')
+    batch = {k: v.to(DEV) for k, v in cf.cf_batch(B, tag=f'step{B}').items()}
+    with parity.mode(), torch.no_grad():
+        lv = model.train_step(batch, None)['log_vars']
+    errs = {k: abs(lv[k] - float(g[f'B{B}.{k}'])) for k in LOSS_KEYS}
+    print('parity loss errors (config 1)', B, errs)
+    for k in LOSS_KEYS:
+        assert errs[k] <= PARITY_TOL, (k, lv[k], float(g[f'B{B}.{k}']))
+
+
+def test_parity_modules_vs_reference(model):
+    """Feature maps of the three encoders in parity mode against the reference goldens: 1e-4 of max (the bf16 path
+    asserts 2-3e-2 on the same fixtures)."""
+    from clover_amd import parity
+    g = gutil.load('g_swin.npz')
+    b = cf.cf_batch(2, tag='swin')
+    x, vm = b['imgs'][:, 0].to(DEV), b['v_token_mask'].to(DEV)
+    with parity.mode(), torch.no_grad():
+        y = model.backbone(x)
+        ym, w = model.backbone(x.clone(), vm)
+    assert rel(y, torch.from_numpy(g['clean.out'])) < 1e-4
+    assert rel(ym, torch.from_numpy(g['masked.out'])) < 1e-4
+    assert np.array_equal(w.float().cpu().numpy().astype(np.int8), g['masked.w'])
+    g = gutil.load('g_bert_fuse.npz')
+    b = cf.cf_batch(3, tag='bf')
+    ids, mask = b['token_ids'][:, 0].to(DEV), b['input_mask'][:, 0].to(DEV)
+    with parity.mode(), torch.no_grad():
+        t = model.text_backbone(ids, mask)['last_hidden_state']
+        vt = cf.cf_float('bf.vt', (3, 2, 196, 96), 1.0).to(DEV)
+        tt = torch.from_numpy(g['bert.last_hidden_state']).to(DEV)
+        f = model.multimodal_backbone(visual_token=vt, text_input_mask=mask, text_input_embeds=tt)
+    assert rel(t, torch.from_numpy(g['bert.last_hidden_state'])) < 1e-4
+    assert rel(f['t_last_hidden_state'], torch.from_numpy(g['fuse.t_last_hidden_state'])) < 1e-4
+
+
+# ----------------------------------------------------------------------------- full-size shapes: oracle
+def _full_size(variant, frames, B, seed):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    torch.manual_seed(seed)
+    cfg = bench.model_cfg(variant, frames)
+    m = clover_amd.build_model(cfg).eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items() if 'relative_position_index' not in k}
+    batch = bench.synthetic_batch(B, frames, 32, seed=seed + 1)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        _, lv_ref = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
+    return m.to(DEV), {k: v.to(DEV) for k, v in batch.items()}, lv_ref
+
+
+@pytest.mark.parametrize('variant,frames,B', [('T', 8, 2), ('B', 16, 2), ('T', 32, 2)])
+def test_parity_full_size_losses_vs_oracle(variant, frames, B):
+    """BASELINE config 2's (Swin-T, 8 frames), config 4's (Swin-B, 16 frames: 392-token windows, fc_in 1024 -> 768,
+    the depth-18 stage) and config 5's clip length (32 frames: temporal shift, 816-token fusion sequences) shapes,
+    seeded init: the six losses in parity mode against the fp32 oracle at 1e-3."""
+    from clover_amd import parity
+    m, batch, lv_ref = _full_size(variant, frames, B, 4321 + frames)
+    with parity.mode(), torch.no_grad():
+        lv = m.train_step(batch, None)['log_vars']
+    errs = {k: abs(lv[k] - lv_ref[k]) for k in LOSS_KEYS}
+    print(f'parity loss errors Swin-{variant} {frames}f B={B}', errs, {k: lv_ref[k] for k in LOSS_KEYS})
+    for k in LOSS_KEYS:
+        assert errs[k] <= PARITY_TOL, (k, lv[k], lv_ref[k])

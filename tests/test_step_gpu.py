@@ -226,11 +226,27 @@ def test_finetune_other_tasks_refuse():
             clover_amd.build_model(cfg)
 
 
-# ----------------------------------------------------------------------------- BASELINE config 2 at full size
-def test_full_size_step_matches_oracle():
-    """VideoSwin-T + BERT-base + 3-layer fusion at the benchmark's shapes (8 frames x 224^2, 32 tokens, B = 2,
-    seeded random init, eval mode so no dropout / DropPath): the five losses of the HIP step against the fp32 oracle
-    on the host cores, and a few gradients that cross every encoder.  Same tolerances as the config-1 goldens."""
+# ----------------------------------------------------------------------------- BASELINE configs 2 and 4 at full size
+FULL_GRAD_KEYS = {
+    'T': ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.3.attn.relative_position_bias_table',
+          'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
+          'text_backbone.bert.encoder.layer.6.attention.self.query.weight',
+          'multimodal_backbone.bert_encoder.layer.2.output.dense.weight', 'mlm_head.predictions.decoder.weight'],
+    # Swin-B: the fc_in projection (1024 -> 768, cross_transformer.py:69-70) exists only here; stage 2 is 18 blocks deep
+    'B': ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.11.attn.relative_position_bias_table',
+          'backbone.layers.2.blocks.14.mlp.fc1.weight', 'backbone.layers.2.blocks.17.attn.qkv.weight',
+          'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
+          'multimodal_backbone.fc_in.weight', 'multimodal_backbone.bert_encoder.layer.2.output.dense.weight',
+          'text_backbone.bert.encoder.layer.6.attention.self.query.weight', 'mlm_head.predictions.decoder.weight'],
+}
+
+
+@pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16)])
+def test_full_size_step_matches_oracle(variant, frames):
+    """BASELINE config 2 (VideoSwin-T, 8 frames) and config 4 (VideoSwin-B: embed_dim 128, heads [4,8,16,32], the
+    depth-18 stage, fc_in 1024 -> 768; 16 frames -> 392-token windows) + BERT-base + 3-layer fusion at the benchmark's
+    shapes (224^2, 32 tokens, B = 2, seeded random init, eval mode so no dropout / DropPath): the five losses of the
+    HIP step against the fp32 oracle on the host cores, and gradients that cross every encoder."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -238,11 +254,11 @@ def test_full_size_step_matches_oracle():
     import clover_amd
     from oracle import model as om
     torch.manual_seed(4321)
-    cfg = bench.model_cfg('T', 8)
+    cfg = bench.model_cfg(variant, frames)
     m = clover_amd.build_model(cfg).eval()
     P = {k: v.detach().float().clone().requires_grad_(v.is_floating_point())
          for k, v in m.state_dict().items() if 'relative_position_index' not in k}
-    batch = bench.synthetic_batch(2, 8, 32, seed=77)
+    batch = bench.synthetic_batch(2, frames, 32, seed=77)
     torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
     losses = om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False)
     loss_ref, lv_ref = om.parse_losses(losses)
@@ -252,19 +268,41 @@ def test_full_size_step_matches_oracle():
     out = m.train_step({k: v.to(DEV) for k, v in batch.items()}, None)
     lv = out['log_vars']
     errs = {k: abs(lv[k] - lv_ref[k]) for k in LOSS_KEYS}
-    print('full-size loss errors', errs, {k: lv_ref[k] for k in LOSS_KEYS})
+    print(f'full-size Swin-{variant} {frames}f loss errors', errs, {k: lv_ref[k] for k in LOSS_KEYS})
     for k in LOSS_KEYS:
         assert errs[k] <= LOSS_TOL[k], (k, lv[k], lv_ref[k])
     out['loss'].backward()
     named = dict(m.named_parameters())
-    keys = ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.3.attn.relative_position_bias_table',
-            'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
-            'text_backbone.bert.encoder.layer.6.attention.self.query.weight',
-            'multimodal_backbone.bert_encoder.layer.2.output.dense.weight', 'mlm_head.predictions.decoder.weight']
-    worst = {k: rel(named[k].grad, P[k].grad.numpy()) for k in keys}
-    print('full-size grad rel errors', worst)
+    worst = {k: rel(named[k].grad, P[k].grad.numpy()) for k in FULL_GRAD_KEYS[variant]}
+    print(f'full-size Swin-{variant} {frames}f grad rel errors', worst)
     for k, e in worst.items():
         assert e < 6e-2, (k, e)
+
+
+def test_train_mode_step_is_finite_and_learns():
+    """BASELINE config 2 shapes with model.train(): hidden dropout 0.1, attention-probability dropout 0.1 and DropPath
+    0.1 all active inside the HIP kernels.  Twelve optimizer steps on one fixed batch: every loss finite, and the total
+    falls (mean of the last three below the mean of the first three)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    from clover_amd.engine import CloverEngine
+    torch.manual_seed(11)
+    m = clover_amd.build_model(bench.model_cfg('T', 8)).to(DEV)
+    m.train()
+    batch = {k: v.to(DEV) for k, v in bench.synthetic_batch(4, 8, 32, seed=5).items()}
+    eng = CloverEngine(m, batch, lr=2e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 6)
+    hist = []
+    for _ in range(12):
+        lv = eng.step(batch)['log_vars']
+        vals = {k: float(v) for k, v in lv.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        hist.append(vals['loss'])
+    print('train-mode loss trajectory', [round(h, 3) for h in hist])
+    assert np.mean(hist[-3:]) < np.mean(hist[:3]), hist
+    m.eval()
 
 
 @pytest.mark.parametrize('frames', [16, 32])
