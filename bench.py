@@ -124,10 +124,13 @@ def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
     times = []
     t_start = time.time()
     warm = None
+    ref_losses = None
     for it in range(4):
         t0 = time.time()
         losses = om.forward_train(P, batch, ocfg, gather=False)
-        loss, _ = om.parse_losses(losses)
+        loss, lv = om.parse_losses(losses)
+        if ref_losses is None:
+            ref_losses = {k: float(v) for k, v in lv.items()}
         loss.backward()
         dt = time.time() - t0
         if it > 0:
@@ -142,7 +145,7 @@ def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
     if not times:                       # slow host: the warm-up iteration is all the budget allows
         times, note = [warm], 'iter (the warm-up itself; budget exhausted)'
     per = sum(times) / len(times)
-    return dict(value=round(B / per, 4), unit='pairs/s', cores=ncores, kind='port',
+    return dict(value=round(B / per, 4), unit='pairs/s', cores=ncores, kind='port', losses=ref_losses,
                 sample=f'oracle forward_train+backward, fp32, B={B}, {frames}f x 224^2, L={L}, '
                        f'{len(times)} {note} ({per:.2f} s/iter)')
 
@@ -221,6 +224,22 @@ def main():
     model = clover_amd.build_model(cfg).to(dev)
     model.train()                                        # dropout / DropPath active, as in training
 
+    # Loss parity of THIS model (the weights the CPU leg rebuilds from the same seed) before any training step: the
+    # B = 2 batch the oracle is timed on, eval mode (no dropout / DropPath, as the oracle), on the bf16 training path and
+    # in parity mode (fp32 storage + arithmetic on the HIP kernels); compared with the oracle's losses below.
+    own_losses = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from clover_amd import parity
+        cb = {k: v.to(dev) for k, v in synthetic_batch(2, args.frames, args.tokens, seed=999).items()}
+        model.eval()
+        with torch.no_grad():
+            fast = {k: float(v) for k, v in model.train_step(cb, None)['log_vars'].items()}
+            with parity.mode():
+                par = {k: float(v) for k, v in model.train_step(cb, None)['log_vars'].items()}
+        own_losses = dict(bf16=fast, parity=par)
+        model.train()
+        del cb
+
     batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.frames, args.tokens, 1000 + rank).items()}
     engine = CloverEngine(model, batch, lr=5e-5 / 1024 * args.batch * world, weight_decay=0.005, grad_clip=15.0,
                           max_iters=100000)
@@ -250,6 +269,18 @@ def main():
     dt = time.perf_counter() - t0
     prof, ops.PROF = ops.PROF, None
     prof_steps = args.steps
+    with_copy_ms = None
+    if graphed:
+        # the same steps fed from tensors OUTSIDE the graphs' static input buffers (what a loader that does not write
+        # into engine.input_buffers() pays: one device-to-device staging copy of the batch per step) — ADVICE r2
+        fresh = {k: v.clone() for k, v in batch.items()}
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = engine.step(fresh)
+        sync()
+        with_copy_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        del fresh
     if graphed and not args.no_kernel_timing:
         # per-kernel durations: HIP events cannot bracket launches inside a replayed graph, so the same
         # kernels (same shapes, same data) are timed on 3 eager steps right after the timed region
@@ -310,6 +341,15 @@ def main():
                 res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
+            ref = res['cpu_baseline'].pop('losses', None)
+            if ref and own_losses:
+                # |loss - oracle| on identical weights / inputs (B = 2, eval): north-star bound 1e-3 for the parity mode
+                res['loss_abs_err_vs_oracle'] = {
+                    mode: {k: round(abs(v - ref[k]), 7) for k, v in lv.items() if k in ref}
+                    for mode, lv in own_losses.items()}
+                res['loss_abs_err_vs_oracle']['sample'] = 'B=2 synthetic batch (seed 999), eval mode, seed-1234 init'
+        if with_copy_ms is not None:
+            res['ms_per_step_with_input_copy'] = round(with_copy_ms, 3)
     if args.tune_gemms and rank == 0:
         from clover_amd.utils.gemm_tuning import save_results
         save_results(args.tune_gemms)

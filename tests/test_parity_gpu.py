@@ -43,7 +43,7 @@ def test_sgemm_nt(M, N, K, bias):
     ref = a.double() @ b.double().t() + (bb.double() if bias else 0)
     with parity.mode():
         c = parity.sgemm(a.to(DEV), b.to(DEV), bb.to(DEV) if bias else None)
-    assert c.dtype == torch.float32 and rel(c, ref) < 2e-6, rel(c, ref)
+    assert c.dtype == torch.float32 and rel(c, ref) < 1e-5, rel(c, ref)      # an fp32 fmaf chain over K <= 3072
 
 
 def test_sgemm_nt_strided_rows():

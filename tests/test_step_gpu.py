@@ -3,11 +3,14 @@
 weights/inputs.  BASELINE config 1 (tiny 2-stage Swin + BERT-tiny).  `-m gpu` only.
 
 Tolerances (DESIGN.md "Parity"): indexing/masking bit-exact.  The fp32 kernels (focal CE, exclusive
-InfoNCE + rank) are checked at 1e-4 .. 1e-3.  Everything downstream of a bf16 MFMA operand carries
-~2^-9 relative rounding per operand stage, so whole-step losses are asserted at LOSS_TOL below
-(mlm 5e-3; the contrastive/rank losses 3e-2 because the cosine logits are divided by the
-temperature 0.05, a x20 amplification) — the north-star 1e-3 is met by mlm_loss only in the mean,
-not as a bound; feature maps / gradients are relative to their max magnitude as written below."""
+InfoNCE + rank) are checked at 1e-4 .. 1e-3.  The north-star bound on the step losses (1e-3) is asserted in
+tests/test_parity_gpu.py on the fp32 parity mode of the same path (measured 1e-6 .. 8e-6).  THIS file runs the bf16
+training path: every activation is stored in bf16 and every GEMM operand is bf16, and the isolation runs of
+tools/parity_isolate.py (profiles/r03_parity_isolate.json) show that either of those two roundings alone already moves
+the contrastive / rank losses by 2e-3 .. 1e-2 (cosine logits are divided by the temperature 0.05).  LOSS_TOL below is
+what the bf16 path is measured to hold with ~2x margin (round 3: mlm <= 3.3e-3, nce <= 9.6e-3, rank <= 9.6e-3, total
+<= 1.5e-2 over config 1 B = 1, 2, 4 and the config-2 / config-4 shapes); feature maps / gradients are relative to their
+max magnitude as written below."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +21,7 @@ import gutil
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']
-LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=3e-2, rank_t_tm_loss=3e-2, v_nce_loss=3e-2, rank_v_vm_loss=3e-2, loss=6e-2)
+LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=2e-2, rank_t_tm_loss=2e-2, v_nce_loss=2e-2, rank_v_vm_loss=2e-2, loss=3e-2)
 
 
 def grad_tol(name):
@@ -281,8 +284,8 @@ def test_full_size_step_matches_oracle(variant, frames):
 
 def test_train_mode_step_is_finite_and_learns():
     """BASELINE config 2 shapes with model.train(): hidden dropout 0.1, attention-probability dropout 0.1 and DropPath
-    0.1 all active inside the HIP kernels.  Twelve optimizer steps on one fixed batch: every loss finite, and the total
-    falls (mean of the last three below the mean of the first three)."""
+    0.1 all active inside the HIP kernels.  Twenty optimizer steps on one fixed batch: every loss finite, and the total
+    falls."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -293,15 +296,15 @@ def test_train_mode_step_is_finite_and_learns():
     m = clover_amd.build_model(bench.model_cfg('T', 8)).to(DEV)
     m.train()
     batch = {k: v.to(DEV) for k, v in bench.synthetic_batch(4, 8, 32, seed=5).items()}
-    eng = CloverEngine(m, batch, lr=2e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 6)
+    eng = CloverEngine(m, batch, lr=1e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 6)
     hist = []
-    for _ in range(12):
+    for _ in range(20):
         lv = eng.step(batch)['log_vars']
         vals = {k: float(v) for k, v in lv.items()}
         assert all(np.isfinite(v) for v in vals.values()), vals
         hist.append(vals['loss'])
     print('train-mode loss trajectory', [round(h, 3) for h in hist])
-    assert np.mean(hist[-3:]) < np.mean(hist[:3]), hist
+    assert min(hist[-5:]) < hist[0] - 1.0, hist              # dropout-noisy, 4 samples: the tail dips below the start
     m.eval()
 
 
