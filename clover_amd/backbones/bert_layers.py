@@ -209,6 +209,12 @@ class BertLayer(nn.Module):
     def forward(self, x, kmask, x_res=None, fork_out=False):
         """x_res: the alias of x a forked producer handed out for the residual input (see BertSelfOutput)."""
         a, a_res = self.attention(x, kmask, x_res, fork=True)
+        fc1, out = self.intermediate.dense, self.output
+        if ops.mlp_gelu_ok(a, fc1.out_features):
+            # FFN with the activation inside the GEMMs (clv_gemm_nt epilogues: bias + GELU keeping GELU' forward, one
+            # multiply in the input gradient of the second GEMM) — no standalone GELU pass over the [tokens, 3072] tensor
+            h = ops.mlp_gelu(a, fc1.weight, fc1.bias, out.dense.weight, out.dense.bias)
+            return out.LayerNorm(h, residual=a_res, x_dropout_p=out.dropout.p if self.training else 0.0, fork=fork_out)
         return self.output(self.intermediate(a), a_res, fork=fork_out)
 
 

@@ -126,13 +126,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     const int my_mblks = (nmblk - xcd + 7) >> 3;
     const int my_tiles = my_mblks * tilesN;
     if (slot >= my_tiles) return;
-    if (HAS_BIAS) {                                           // whole bias row -> LDS (bf16, as the GEMM's bf16 bias operand
-        for (int i = tid * 4; i < N; i += GN_THREADS * 4) {   // was), before any DMA is in flight
-            const float4 bv = *reinterpret_cast<const float4*>(bias + i);
-            *reinterpret_cast<uint2*>(bias_s + i) = make_uint2(pack2bf(bv.x, bv.y), pack2bf(bv.z, bv.w));
-        }
-        __syncthreads();
-    }
     const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
     const unsigned ring_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0]);
@@ -163,6 +156,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     };
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) issue_next();
+    if (HAS_BIAS) {
+        // whole bias row -> LDS (bf16, as the GEMM's bf16 bias operand was) UNDER the first stages' DMA round trip (it
+        // used to run, with a barrier, before the first DMA went out: ~1 us of serial latency per launch).  The first
+        // stage's barrier below publishes it: its LDS writes are waited for here.
+        for (int i = tid * 4; i < N; i += GN_THREADS * 4) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + i);
+            *reinterpret_cast<uint2*>(bias_s + i) = make_uint2(pack2bf(bv.x, bv.y), pack2bf(bv.z, bv.w));
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+    }
     int cslot = 0;                                            // ring slot of the stage being multiplied
     int post_epi = 0;                                         // stage tops whose wait must also leave S stores in flight
 
@@ -610,6 +613,9 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
                                   (bf16_t*)c, (bf16_t*)c2, M, N, K, lda, ldb, ldc, tilesN, nmblk);
     }
     int BM = 128, BN = 128, W = 4;
+    // few tiles and a long contraction (Swin stage 3, fusion encoder, text tower: <= 512 tiles of 128 x 128 for 512
+    // workgroup slots): 64 x 128 tiles double the workgroups that share the DMA latency (tools/probes/gemm_tiles.py)
+    if (!force && K >= 512 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) BM = 64;
     if (force) {
         BM = atoi(force);
         const char* x = strchr(force, 'x');
@@ -620,7 +626,7 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     const int tilesN = (N + BN - 1) / BN;
     const int nmblk = (int)((M + BM - 1) / BM);
     // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's tiles
-    const int per_cu = (BM == 128 && W == 4) ? 2 : 1;
+    const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : 1;
     const int max_tiles_xcd = ((nmblk + 7) / 8) * tilesN;
     const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 32 * per_cu ? max_tiles_xcd : 32 * per_cu));
     hipStream_t st = (hipStream_t)stream;
@@ -629,6 +635,8 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
     if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4
+    if (BM == 64 && BN == 128 && W == 4) return gn_launch<64, 128, 2, 2, 3>(GN_ARGS);     // 24 KiB stages x 3, two WGs per CU
+    if (BM == 64 && BN == 64 && W == 2) return gn_launch<64, 64, 1, 2, 3>(GN_ARGS);       // 16 KiB stages x 3, three WGs per CU
 #undef GN_ARGS
     return CLV_ERR_UNSUPPORTED;
 }

@@ -125,19 +125,29 @@ class _Segment:
             p._clv_grad = p.grad                                                   # sink for ops.linear
             p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
         self.shadow.copy_(self.flat_p)
-        # bf16 W^T copies for the Linear weights whose input-gradient GEMM is the K-contiguous HIP kernel
-        # (ops.linear_dgrad): one batched transpose per optimizer step refreshes them all
-        want = [(p, off) for p, off in zip(self.params, self.offsets) if getattr(p, '_clv_want_t', False) and p.dim() == 2]
         self.shadow_t, self._t_table = None, None
-        if want and self.flat_p.is_cuda:
-            self.shadow_t = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _ in want), device=device, dtype=torch.bfloat16)
-            entries, toff = [], 0
-            for p, off in want:
-                entries.append((off, toff, p.shape[0], p.shape[1]))
-                p._clv_shadow_t = self.shadow_t[toff:toff + p.numel()].view(p.shape[1], p.shape[0])
-                toff += (p.numel() + 7) // 8 * 8
-            self._t_table = ops.transpose_table(entries, device)
-            self.refresh_transposed()
+        self._fused = []                     # fused views handed out (fused_view), for build_transposed()
+
+    def build_transposed(self):
+        """bf16 W^T copies for the Linear weights whose input-gradient GEMM is a K-contiguous HIP kernel
+        (ops.linear_dgrad): one batched transpose per optimizer step refreshes them all.  A fused view (BERT Q|K|V,
+        applied as ONE [3H, H] GEMM) gets the transpose of the fused matrix, [H, 3H]; its members then need none of
+        their own.  Called once, after the engine has made the fused views."""
+        fused_members = {id(m) for f in self._fused if getattr(f, '_clv_want_t', False) for m in f._clv_members}
+        want = [(p, off, tuple(p.shape)) for p, off in zip(self.params, self.offsets)
+                if getattr(p, '_clv_want_t', False) and p.dim() == 2 and id(p) not in fused_members]
+        want += [(f, f._clv_off, tuple(f.shape)) for f in self._fused if getattr(f, '_clv_want_t', False) and f.dim() == 2]
+        if not want or not self.flat_p.is_cuda:
+            return
+        device = self.flat_p.device
+        self.shadow_t = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _, _ in want), device=device, dtype=torch.bfloat16)
+        entries, toff = [], 0
+        for p, off, shape in want:
+            entries.append((off, toff, shape[0], shape[1]))
+            p._clv_shadow_t = self.shadow_t[toff:toff + p.numel()].view(shape[1], shape[0])
+            toff += (p.numel() + 7) // 8 * 8
+        self._t_table = ops.transpose_table(entries, device)
+        self.refresh_transposed()
 
     def refresh_transposed(self):
         if self._t_table is not None:
@@ -158,6 +168,9 @@ class _Segment:
         f._clv_shadow = self.shadow[off:off + n].view(shape)
         f._clv_members = list(members)
         f._clv_ready = lambda ms=f._clv_members: [m._clv_ready() for m in ms] and None
+        f._clv_off = off
+        f._clv_want_t = all(getattr(m, '_clv_want_t', False) for m in members)
+        self._fused.append(f)
         return f
 
 
@@ -250,6 +263,8 @@ class CloverEngine:
             per_mod.setdefault(id(mod), (mod, []))[1].append(seg.fused_view(grp))
         for mod, views in per_mod.values():
             mod._clv_fused = views                       # same order as clv_fuse_groups()
+        for seg in self.segments:
+            seg.build_transposed()
 
     # ------------------------------------------------------------------ one step
     def current_lr(self):

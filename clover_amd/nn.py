@@ -23,6 +23,11 @@ def to_bf16(t):
 
 
 class Linear(nn.Linear):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # the engine keeps a bf16 W^T where the input gradient's kernel takes one (ops.linear_dgrad)
+        self.weight._clv_want_t = ops.wants_transposed(self.out_features, self.in_features)
+
     def forward(self, x):
         return ops.linear(x, self.weight, self.bias)
 

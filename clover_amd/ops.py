@@ -327,20 +327,34 @@ def _rowgemm_fwd_ok(x, N, K):
     return x.is_cuda and K <= 128 and x.stride(-1) == 1 and rowgemm_supported(N, K)
 
 
+def own_gemm_all():
+    """CLOVER_OWN_GEMM_ALL=1 (default): every forward / input-gradient GEMM of a Linear whose shape clv_gemm_nt takes
+    runs on it — Swin stages 1-3, PatchMerging, the text tower, the fusion encoder, fc_in, the MLM transform (round 3;
+    the MLM decoder, N = 30522, stays a library GEMM).  0: only where it beat the tuned library GEMM in round 2."""
+    return os.environ.get('CLOVER_OWN_GEMM_ALL', '1') == '1'
+
+
 def own_gemm_ok(a, N, K):
-    """Shapes on which clv_gemm_nt beats the tuned library GEMM (device-side durations, tools/probes/gemm_bench.py under
-    rocprofv3 --kernel-trace): token-parallel layers with a short contraction — Swin stages 1-2 (M = 12 544 .. 50 176,
-    K <= 576); long contractions with few tiles (stage 3, fusion, BERT) stay with the library."""
+    """Shapes that run on clv_gemm_nt (forward: a = x [M, K], N outputs; input gradient: a = dy, contraction = the layer's
+    output width).  Device-side durations against the tuned library GEMM: tools/probes/gemm_bench.py (round 2: token-
+    parallel layers with a short contraction win) and tools/probes/gemm_tiles.py (round 3: the 64 x 128 tile class for
+    long contractions with few tiles)."""
     M = a.shape[0]
-    return (os.environ.get('CLOVER_OWN_GEMM', '1') == '1' and a.is_cuda and a.dtype == BF16 and M >= 8192
-            and 64 <= K <= 576 and K % 64 == 0 and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1
-            and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
+    if not (os.environ.get('CLOVER_OWN_GEMM', '1') == '1' and a.is_cuda and a.dtype == BF16 and K % 64 == 0 and K >= 64
+            and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0):
+        return False
+    if own_gemm_all():
+        return M >= 64
+    return M >= 8192 and K <= 576
 
 
 def wants_transposed(out_features, in_features):
     """Does the input gradient of a Linear(in, out) run on a kernel that takes W^T as a K-contiguous operand
-    (linear_dgrad: the row-streaming GEMM of the stage-0 widths, clv_gemm_nt for contractions <= 576)?  Modules flag
-    such weights (``_clv_want_t``) and the engine keeps their bf16 transposes fresh."""
+    (linear_dgrad: the row-streaming GEMM of the stage-0 widths, clv_gemm_nt otherwise)?  Modules flag such weights
+    (``_clv_want_t``) and the engine keeps their bf16 transposes fresh."""
+    if own_gemm_all():
+        return (out_features % 64 == 0 and 64 <= in_features <= 3072 and in_features % 8 == 0) or \
+               (in_features <= 128 and out_features <= 384)
     return out_features <= 576 or (in_features <= 128 and out_features <= 384)
 
 

@@ -96,8 +96,12 @@ def test_transposed_weight_shadows_follow_the_optimizer():
     from clover_amd.engine import CloverEngine
     b = batch(tag='wt')
     eng = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.005, grad_clip=15.0, max_iters=100)
-    flagged = [p for sg in eng.segments for p in sg.params if getattr(p, '_clv_want_t', False)]
-    assert flagged and all(hasattr(p, '_clv_shadow_t') for p in flagged)
+    # members of a fused view (BERT Q|K|V, one [3H, H] GEMM) are served by the transpose of the FUSED matrix
+    fused = [f for sg in eng.segments for f in sg._fused if getattr(f, '_clv_want_t', False)]
+    in_fused = {id(m) for f in fused for m in f._clv_members}
+    flagged = [p for sg in eng.segments for p in sg.params if getattr(p, '_clv_want_t', False) and id(p) not in in_fused]
+    flagged += fused
+    assert flagged and fused and all(hasattr(p, '_clv_shadow_t') for p in flagged)
 
     def check():
         for p in flagged:
