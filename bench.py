@@ -178,6 +178,8 @@ def main():
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--tokens', type=int, default=32)
     ap.add_argument('--variant', default='T', choices=['T', 'B'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
+                    help='fp8: forward GEMMs on e4m3 operands (BASELINE config 5); gradients stay bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of as one hipGraph')
@@ -213,6 +215,8 @@ def main():
     import clover_amd
     from clover_amd import ops
     from clover_amd.engine import CloverEngine
+    if args.dtype == 'fp8':
+        ops.FP8 = True
 
     tuned = 0
     if not args.no_gemm_tuning:
@@ -316,7 +320,7 @@ def main():
             'metric': f'video-text pairs/sec ({args.frames}f x 224^2, {args.tokens}-tok), full pre-training step',
             'value': round(pairs_s, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'hip_graph': graphed, 'tuned_gemm_shapes': tuned,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'hip_graph': graphed, 'tuned_gemm_shapes': tuned,
             'config': {'workload': f'VideoSwin-{args.variant} + BERT-base + 3-layer fusion, MLM + tri-modal '
                                    f'exclusive InfoNCE + rank losses, {args.frames}f x 224^2, {args.tokens}-tok',
                        'per_gpu_batch': args.batch, 'global_batch': gb, 'parallelism': f'dp{world}',

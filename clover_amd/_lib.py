@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -102,6 +102,9 @@ SIGNATURES = {
     'clv_wgrad_fold_batch': (C.c_int, [_p, _i32, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),
     'clv_adamw_step_dev': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
+    'clv_quant_fp8_rows': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i64, _p]),
+    'clv_gemm_nt_fp8_supported': (C.c_int, [_i64, _i32, _i32]),
+    'clv_gemm_nt_fp8': (C.c_int, [_p] * 7 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p]),
     'clv_sgemm_nt': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _p]),
     'clv_attn_f32_fwd': (C.c_int, [_p] * 7 + [C.POINTER(ClvAttnGeom), _i32, _p]),
 }

@@ -104,12 +104,29 @@ __device__ __forceinline__ float gn_hi(uint32_t u) { return __uint_as_float(u & 
 // flight across it).  The epilogue runs straight on the accumulators; its stores are younger than the stages already in
 // flight, which the wait counts of the next R-1 stages account for (gfx9 returns loads and stores in issue order on
 // vmcnt), so the stores drain under the next tile's first stages instead of stalling the pipeline.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int R, int EPI>
+//
+// FP8 = true (clv_gemm_nt_fp8): the operands are OCP e4m3 bytes.  The staging side is unchanged — a stage row is still 128
+// bytes, now 128 k-elements — so a, b, K, lda, ldb arrive in 2-byte units (K / 2 ...); a stage is ONE k-step of the
+// K = 128 matrix instruction (v_mfma_f32_16x16x128_f8f6f4, twice the bf16 rate): a lane's operand is the 32 bytes at
+// chunks 2 lg, 2 lg + 1 of its row (the same assignment for A and B, so the order of k inside a stage is immaterial).
+// The epilogue applies the per-row scales of the two quantised operands: acc * sa[m] * sb[n] (+ bias ...).
+typedef int gn_i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t gn_mfma_fp8(const Frag8 (&x)[2], const Frag8 (&y)[2], f32x4_t acc) {
+    const gn_i32x8_t xv = {(int)x[0].u[0], (int)x[0].u[1], (int)x[0].u[2], (int)x[0].u[3],
+                           (int)x[1].u[0], (int)x[1].u[1], (int)x[1].u[2], (int)x[1].u[3]};
+    const gn_i32x8_t yv = {(int)y[0].u[0], (int)y[0].u[1], (int)y[0].u[2], (int)y[0].u[3],
+                           (int)y[1].u[0], (int)y[1].u[1], (int)y[1].u[2], (int)y[1].u[3]};
+    // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 127) — the tensors carry per-row fp32 scales instead
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xv, yv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int R, int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                                 const float* __restrict__ bias, const bf16_t* __restrict__ aux,
                                                                 bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N,
                                                                 int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN,
-                                                                int nmblk) {
+                                                                int nmblk, const float* __restrict__ sa = nullptr,
+                                                                const float* __restrict__ sb = nullptr) {
     constexpr int WAVES = WAVES_M * WAVES_N, GN_THREADS = 64 * WAVES;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
@@ -192,6 +209,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
             const unsigned char* As = ring + cslot * STAGE;
             const unsigned char* Bs = As + A_BYTES;
             cslot = cslot == R - 1 ? 0 : cslot + 1;
+            if constexpr (FP8) {
+                Frag8 fa[TM][2], fb[TN][2];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    fb[j][0] = gn_frag(Bs, wn + j * 16 + lr, 2 * lg);
+                    fb[j][1] = gn_frag(Bs, wn + j * 16 + lr, 2 * lg + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    fa[i][0] = gn_frag(As, wm + i * 16 + lr, 2 * lg);
+                    fa[i][1] = gn_frag(As, wm + i * 16 + lr, 2 * lg + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = gn_mfma_fp8(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+            } else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 Frag8 fa[TM], fb[TN];
@@ -237,6 +271,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
             float bn[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bn[e] = 0.f;
+            float sn[8];
+            if constexpr (FP8) {
+                const float4 s0 = *reinterpret_cast<const float4*>(sb + nh), s1 = *reinterpret_cast<const float4*>(sb + nh + 4);
+                sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+            }
             if (HAS_BIAS) {
                 const uint4 bv = *reinterpret_cast<const uint4*>(bias_s + nh);
                 const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -249,8 +288,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                 if (m >= M) continue;
                 const int64_t g = m * ldc + nh;
                 float v[8];
+                if constexpr (FP8) {
+                    const float sm = sa[m];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bn[e];
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[i][2 * h + (e >> 2)][e & 3] * sm, sn[e], bn[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bn[e];
+                }
                 if (EPI == GN_EPI_GELU) {
                     *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                                                    pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
@@ -581,7 +626,54 @@ int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf1
     return clv_check_launch();
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int R>
+int gn_launch_fp8(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, bf16_t* c,
+                  bf16_t* c2, int64_t M, int N, int K2, int64_t lda2, int64_t ldb2, int64_t ldc, int tilesN, int nmblk,
+                  const float* sa, const float* sb) {
+#define GN_GO(E)                                                                                                         \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, R, E, true>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, \
+                       st, a, b, bias, (const bf16_t*)nullptr, c, c2, M, N, K2, lda2, ldb2, ldc, tilesN, nmblk, sa, sb)
+    switch (epi) {
+        case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
+        case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
+        case GN_EPI_GELUD: GN_GO(GN_EPI_GELUD); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef GN_GO
+    return clv_check_launch();
+}
+
 }  // namespace
+
+extern "C" int clv_gemm_nt_fp8_supported(int64_t M, int32_t N, int32_t K) {
+    return M >= 1 && N >= 64 && N % 8 == 0 && N <= GN_MAX_BIAS && K >= 128 && K % 128 == 0;
+}
+
+extern "C" int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, const float* sb, const float* bias, void* c,
+                               void* c2, int64_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                               int32_t epilogue, void* stream) {
+    if (!a8 || !b8 || !sa || !sb || !c || M <= 0 || N <= 0 || K <= 0) return CLV_ERR_ARG;
+    if (!clv_gemm_nt_fp8_supported(M, N, K)) return CLV_ERR_UNSUPPORTED;
+    if ((lda & 15) || (ldb & 15) || (ldc & 7) || lda < K || ldb < K || ldc < N) return CLV_ERR_ARG;
+    if ((((uintptr_t)a8) | ((uintptr_t)b8) | ((uintptr_t)c) | ((uintptr_t)c2) | ((uintptr_t)bias) | ((uintptr_t)sb)) & 15)
+        return CLV_ERR_ARG;
+    if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELUD) && !bias) return CLV_ERR_ARG;
+    if (epilogue == GN_EPI_GELUD && !c2) return CLV_ERR_ARG;
+    int BM = 128;
+    if (K >= 1024 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) BM = 64;      // same rule as clv_gemm_nt (K in bytes here)
+    const int BN = 128;
+    const int tilesN = (N + BN - 1) / BN;
+    const int nmblk = (int)((M + BM - 1) / BM);
+    const int max_tiles_xcd = ((nmblk + 7) / 8) * tilesN;
+    const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 64 ? max_tiles_xcd : 64));
+    hipStream_t st = (hipStream_t)stream;
+    // the staging code moves bytes: hand it the operands in 2-byte units
+#define GN_ARGS8 epilogue, st, grid, (const bf16_t*)a8, (const bf16_t*)b8, bias, (bf16_t*)c, (bf16_t*)c2, M, N, K / 2, lda / 2, \
+                 ldb / 2, ldc, tilesN, nmblk, sa, sb
+    if (BM == 128) return gn_launch_fp8<128, 128, 2, 2, 2>(GN_ARGS8);
+    return gn_launch_fp8<64, 128, 2, 2, 3>(GN_ARGS8);
+#undef GN_ARGS8
+}
 
 extern "C" int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K) {
     return M >= 1 && N >= 64 && N % 8 == 0 && N <= GN_MAX_BIAS && K >= 64 && K % GN_BK == 0;

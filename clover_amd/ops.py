@@ -358,6 +358,53 @@ def wants_transposed(out_features, in_features):
     return out_features <= 576 or (in_features <= 128 and out_features <= 384)
 
 
+# --------------------------------------------------------------------------- fp8 forward GEMMs (BASELINE config 5)
+FP8 = os.environ.get('CLOVER_FP8', '0') == '1'
+
+
+def fp8_ok(a, N, K):
+    """CLOVER_FP8=1: forward GEMMs whose contraction is a multiple of 128 run on e4m3 operands (clv_gemm_nt_fp8) — QKV,
+    attention-output / FFN / PatchMerging projections of Swin stages 1-3 (stage 0 and the patch projection contract over
+    96-128 inputs: their row-streaming / fused kernels are bound by the activation traffic, not the matrix pipe), the text
+    tower and the fusion encoder.  Gradients stay bf16."""
+    return (FP8 and a.is_cuda and a.dtype == BF16 and a.shape[0] >= 64 and K % 128 == 0 and 256 <= K <= 4096
+            and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
+
+
+def quant_fp8_rows(x2):
+    """(q uint8 [M,K] e4m3 bytes, scale fp32 [M]) with q = x / scale, scale = rowmax|x| / 448."""
+    _need_gpu(x2)
+    assert x2.dtype == BF16 and x2.dim() == 2 and x2.stride(1) == 1
+    M, K = x2.shape
+    q = torch.empty(M, K, device=x2.device, dtype=torch.uint8)
+    sc = torch.empty(M, device=x2.device, dtype=torch.float32)
+    check(_lib.lib().clv_quant_fp8_rows(_ptr(x2), _ptr(q), _ptr(sc), M, K, x2.stride(0), K, _stream()), 'clv_quant_fp8_rows')
+    return q, sc
+
+
+def gemm_nt_fp8(a, b, bias=None, epilogue=None):
+    """c bf16 [M,N] = a [M,K] . b [N,K]^T (+ bias, GELU) with both bf16 operands quantised row-wise to e4m3 on the way
+    (raw launcher, no autograd).  Returns c, or (c, GELU'(pre)) for GEMM_EPI_BIAS_GELU_D."""
+    if epilogue is None:
+        epilogue = GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE
+    aq, asc = quant_fp8_rows(a)
+    bq, bsc = quant_fp8_rows(b)
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty(M, N, device=a.device, dtype=BF16)
+    c2 = torch.empty_like(c) if epilogue == GEMM_EPI_BIAS_GELU_D else None
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    args = (_ptr(aq), _ptr(bq), _ptr(asc), _ptr(bsc), _ptr(bias), _ptr(c), _ptr(c2), M, N, K, K, K, N, int(epilogue), _stream())
+    if PROF is None:
+        check(_lib.lib().clv_gemm_nt_fp8(*args), 'clv_gemm_nt_fp8')
+    else:
+        nout = 2 if c2 is not None else 1
+        with _Timed(f'gemm_nt_kernel<fp8, {int(epilogue)}>', 2 * M * N * K, M * K + N * K + nout * M * N * 2):
+            check(_lib.lib().clv_gemm_nt_fp8(*args), 'clv_gemm_nt_fp8')
+    return (c, c2) if c2 is not None else c
+
+
 def _wt(weight, wb):
     """bf16 W^T [K,N]: the engine's transposed shadow (refreshed once per step) or a transpose on the spot."""
     wt = getattr(weight, '_clv_shadow_t', None) if weight is not None else None
@@ -419,6 +466,8 @@ class _Linear(torch.autograd.Function):
         if _rowgemm_fwd_ok(xb, N, K):
             bf = bias if bias is not None and bias.dtype == torch.float32 else (bias.float() if bias is not None else None)
             y = rowgemm(x2, wb, bf)['y'].view(xb.shape[:-1] + (N,))
+        elif fp8_ok(x2, N, K):
+            y = gemm_nt_fp8(x2, wb, bias.detach() if bias is not None else None).view(xb.shape[:-1] + (N,))
         elif own_gemm_ok(x2, N, K):
             y = gemm_nt(x2, wb, bias.detach() if bias is not None else None,
                         epilogue=GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE).view(xb.shape[:-1] + (N,))
@@ -717,9 +766,14 @@ class _MlpGelu(torch.autograd.Function):
         Hd, C_ = w1b.shape[0], w2b.shape[0]
         ctx.dgelu_saved = (os.environ.get('CLOVER_GELU_SAVE_GRAD', '1') == '1' and own_gemm_ok(x2, Hd, C_)
                            and os.environ.get('CLOVER_DGELU_FUSE', '1') == '1')
-        act, pre = gemm_nt(x2, w1b, b1.detach(),
-                           epilogue=GEMM_EPI_BIAS_GELU_D if ctx.dgelu_saved else GEMM_EPI_BIAS_GELU)
-        if own_gemm_ok(act, C_, Hd):
+        if ctx.dgelu_saved and fp8_ok(x2, Hd, C_):
+            act, pre = gemm_nt_fp8(x2, w1b, b1.detach(), epilogue=GEMM_EPI_BIAS_GELU_D)
+        else:
+            act, pre = gemm_nt(x2, w1b, b1.detach(),
+                               epilogue=GEMM_EPI_BIAS_GELU_D if ctx.dgelu_saved else GEMM_EPI_BIAS_GELU)
+        if fp8_ok(act, C_, Hd):
+            out = gemm_nt_fp8(act, w2b, b2.detach() if b2 is not None else None)
+        elif own_gemm_ok(act, C_, Hd):
             out = gemm_nt(act, w2b, b2.detach() if b2 is not None else None,
                           epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
         else:

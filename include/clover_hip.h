@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 5
+#define CLV_ABI_VERSION 6
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -397,6 +397,25 @@ int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, in
                  int64_t lda, int64_t ldb, int64_t ldc, void* stream);
 int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias, const int32_t* rid,
                      const float* kmask, const ClvAttnGeom* geom, int32_t round_p, void* stream);
+
+/* ------------------------------------------------------------------ fp8 forward GEMMs (BASELINE config 5)
+ * "fp8 MFMA QKV / patch-proj path": the forward GEMM of a Linear on OCP e4m3 operands with one fp32 scale per row of
+ * each operand (per token for the activation, per output channel for the weight), fp32 accumulation on the K = 128 matrix
+ * instruction (v_mfma_f32_16x16x128_f8f6f4, twice the bf16 MFMA rate), bf16 output; gradients stay bf16 (the backward
+ * takes the bf16 activation and weight).  Replaces, under CLOVER_FP8=1, the same torch.nn.Linear sites as clv_gemm_nt
+ * (swin_transformer_3d.py:257-268,361-366,527; the transformers BERT layers called from bert_from_hugface.py:30 and
+ * cross_transformer.py:109-110); precision policy site: mmaction/core/hooks/fp16_utils.py:215-259.
+ *
+ * clv_quant_fp8_rows: q[r][k] = e4m3(x[r][k] / scale[r]), scale[r] = max_k |x[r][k]| / 448; x bf16 [rows][K] (ldx),
+ *   q bytes [rows][K] (ldq); K % 8 == 0, K <= 4096.
+ * clv_gemm_nt_fp8: c[M][N] bf16 = (a8[M][K] . b8[N][K]^T) * sa[m] * sb[n] (+ bias; CLV_GEMM_EPI_NONE / _BIAS / _BIAS_GELU_D
+ *   with c2 = GELU'(pre) as clv_gemm_nt); K % 128 == 0, lda / ldb in bytes and % 16 == 0. */
+int clv_quant_fp8_rows(const void* x, void* q, float* scale, int64_t rows, int32_t K, int64_t ldx, int64_t ldq,
+                       void* stream);
+int clv_gemm_nt_fp8_supported(int64_t M, int32_t N, int32_t K);
+int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, const float* sb, const float* bias, void* c, void* c2,
+                    int64_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue,
+                    void* stream);
 
 #ifdef __cplusplus
 }
