@@ -367,8 +367,10 @@ def fp8_ok(a, N, K):
     attention-output / FFN / PatchMerging projections of Swin stages 1-3 (stage 0 and the patch projection contract over
     96-128 inputs: their row-streaming / fused kernels are bound by the activation traffic, not the matrix pipe), the text
     tower and the fusion encoder.  Gradients stay bf16."""
+    # wide outputs only (CLOVER_FP8_MIN_N, default 1024): the row-wise quantisation of the activation is an extra pass
+    # over [M, K]; it pays where the GEMM does >= ~1000 MACs per activation element (measured, DESIGN.md §fp8)
     return (FP8 and a.is_cuda and a.dtype == BF16 and a.shape[0] >= 64 and K % 128 == 0 and 256 <= K <= 4096
-            and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
+            and int(os.environ.get('CLOVER_FP8_MIN_N', '1024')) <= N <= 3072 and N >= 64 and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0)
 
 
 def quant_fp8_rows(x2):
