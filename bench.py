@@ -266,11 +266,14 @@ def main():
     sync()
     if not args.no_kernel_timing and not graphed:
         ops.PROF = {}
+    if engine.reducer.active:
+        engine.reducer.start_timing()                    # stall of the compute stream on the gradient all-reduces
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = engine.step(batch)
     sync()
     dt = time.perf_counter() - t0
+    exposed_comm_ms = engine.reducer.exposed_ms() if engine.reducer.active else None
     prof, ops.PROF = ops.PROF, None
     prof_steps = args.steps
     with_copy_ms = None
@@ -328,6 +331,10 @@ def main():
             'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
             'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
             'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
+            # data-parallel runs: mean per-step stall of the compute stream on the gradient all-reduces (rank 0), and what
+            # travels: bf16 gradients in per-class buckets (null at N = 1: no collective is issued)
+            'exposed_comm_ms': round(exposed_comm_ms, 3) if exposed_comm_ms is not None else None,
+            'grad_allreduce_dtype': ('bf16' if engine.wire is not None else 'fp32') if engine.reducer.active else None,
         }
         if prof:
             res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, prof_steps)

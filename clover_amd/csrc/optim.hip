@@ -6,17 +6,30 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
+// Gradient element type of the optimizer kernels: fp32 (the slabs the backward accumulates into) or bf16 (the wire copy
+// a data-parallel job all-reduces over xGMI — half the bytes; the update itself stays fp32: clv_pack_bf16,
+// clv_sumsq_bf16, clv_adamw_step_dev_bf16g).
+__device__ __forceinline__ float4 load_g4(const float* g, int64_t i) { return reinterpret_cast<const float4*>(g)[i]; }
+__device__ __forceinline__ float4 load_g4(const bf16_t* g, int64_t i) {
+    const uint2 u = reinterpret_cast<const uint2*>(g)[i];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float load_g1(const float* g, int64_t i) { return g[i]; }
+__device__ __forceinline__ float load_g1(const bf16_t* g, int64_t i) { return bf2f(g[i]); }
+
+template <typename GT>
+__global__ void __launch_bounds__(256) sumsq_kernel(const GT* __restrict__ g, float* __restrict__ acc, int64_t n) {
     __shared__ float sh[4];
     const int64_t n4 = n / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        const float4 v = load_g4(g, i);
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
-        const float v = g[n4 * 4 + threadIdx.x];
+        const float v = load_g1(g, n4 * 4 + threadIdx.x);
         s += v * v;
     }
     s = wave_sum(s);
@@ -120,7 +133,8 @@ __global__ void optim_prep_kernel(float* __restrict__ acc, OptimState* __restric
     *st = o;
 }
 
-__global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <typename GT>
+__global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, const GT* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         bf16_t* __restrict__ shadow, const OptimState* __restrict__ st,
                                                         int64_t n, AdamArgs a) {
@@ -132,7 +146,7 @@ __global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, c
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        const float4 gv = load_g4(g, i);
         float4 mv = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         adam_one(pv.x, gv.x, mv.x, vv.x, a, coef);
@@ -152,10 +166,21 @@ __global__ void __launch_bounds__(256) adamw_dev_kernel(float* __restrict__ p, c
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
         const int64_t i = n4 * 4 + threadIdx.x;
         float pv = p[i], mv = m[i], vv = v[i];
-        adam_one(pv, g[i], mv, vv, a, coef);
+        adam_one(pv, load_g1(g, i), mv, vv, a, coef);
         p[i] = pv; m[i] = mv; v[i] = vv;
         if (shadow) shadow[i] = f2bf(pv);
     }
+}
+
+// fp32 gradient slab slice -> its bf16 wire copy (one 16-byte load, one 8-byte store per thread)
+__global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t n4 = n / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x]);
 }
 
 // Streaming kernels: ONE float4 per thread for the optimizer update (160 M parameters: 785 us = 6.1 TB/s of its 30 B per
@@ -177,7 +202,24 @@ extern "C" int clv_sumsq(const float* g, float* acc, int64_t n, void* stream) {
     if (n == 0) return CLV_OK;
     if (((uintptr_t)g) & 15) return CLV_ERR_ARG;
     static const int sumsq_cap = getenv("CLV_SUMSQ_GRID") ? atoi(getenv("CLV_SUMSQ_GRID")) : 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4, sumsq_cap)), dim3(256), 0, (hipStream_t)stream, g, acc, n);
+    hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid_for(n / 4, sumsq_cap)), dim3(256), 0, (hipStream_t)stream, g, acc, n);
+    return clv_check_launch();
+}
+
+extern "C" int clv_sumsq_bf16(const void* g, float* acc, int64_t n, void* stream) {
+    if (!g || !acc || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if (((uintptr_t)g) & 7) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(grid_for(n / 4, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)g, acc, n);
+    return clv_check_launch();
+}
+
+extern "C" int clv_pack_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7)) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     return clv_check_launch();
 }
 
@@ -211,7 +253,20 @@ extern "C" int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, 
     if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CLV_ERR_ARG;
     if (shadow && (((uintptr_t)shadow) & 7)) return CLV_ERR_ARG;
     AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, 0.f, 1.f};
-    hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+    hipLaunchKernelGGL(adamw_dev_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (bf16_t*)shadow, (const OptimState*)state, n, a);
+    return clv_check_launch();
+}
+
+extern "C" int clv_adamw_step_dev_bf16g(float* p, const void* g, float* m, float* v, void* shadow, const void* state,
+                                        int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        void* stream) {
+    if (!p || !g || !m || !v || !state || n < 0) return CLV_ERR_ARG;
+    if (n == 0) return CLV_OK;
+    if ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return CLV_ERR_ARG;
+    if ((((uintptr_t)g) & 7) || (shadow && (((uintptr_t)shadow) & 7))) return CLV_ERR_ARG;
+    AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, 0.f, 1.f};
+    hipLaunchKernelGGL(adamw_dev_kernel<bf16_t>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                       (const bf16_t*)g, m, v, (bf16_t*)shadow, (const OptimState*)state, n, a);
     return clv_check_launch();
 }

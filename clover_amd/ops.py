@@ -1674,8 +1674,19 @@ def norm_softmax_loss(video=None, text=None, sim_mat=None, temperature=0.07, eps
 
 # --------------------------------------------------------------------------- optimizer primitives
 def sumsq_accumulate(flat_grad, acc):
+    """acc += sum(g^2); g fp32, or the bf16 wire copy of a data-parallel job."""
     _need_gpu(flat_grad, acc)
-    check(_lib.lib().clv_sumsq(_ptr(flat_grad), _ptr(acc), flat_grad.numel(), _stream()), 'clv_sumsq')
+    if flat_grad.dtype == BF16:
+        check(_lib.lib().clv_sumsq_bf16(_ptr(flat_grad), _ptr(acc), flat_grad.numel(), _stream()), 'clv_sumsq_bf16')
+    else:
+        check(_lib.lib().clv_sumsq(_ptr(flat_grad), _ptr(acc), flat_grad.numel(), _stream()), 'clv_sumsq')
+
+
+def pack_bf16(src, dst):
+    """dst (bf16) = src (fp32), the wire copy of a gradient-slab slice (clv_pack_bf16)."""
+    _need_gpu(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == BF16 and src.numel() == dst.numel()
+    check(_lib.lib().clv_pack_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), 'clv_pack_bf16')
 
 
 def adamw_step(p, g, m, v, shadow, sumsq, lr, beta1, beta2, eps, weight_decay, step, max_norm, grad_scale=1.0):
@@ -1713,7 +1724,8 @@ def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0):
 def adamw_step_dev(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay):
     _need_gpu(p, g, m, v, state)
     # algorithmic traffic: p, g, m, v read + p, m, v written (fp32) + the bf16 compute copy
-    with _Timed('adamw_dev_kernel', 12 * p.numel(), (28 + (2 if shadow is not None else 0)) * p.numel()):
-        check(_lib.lib().clv_adamw_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(state), p.numel(),
-                                            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                            _stream()), 'clv_adamw_step_dev')
+    fn = _lib.lib().clv_adamw_step_dev_bf16g if g.dtype == BF16 else _lib.lib().clv_adamw_step_dev
+    gbytes = 2 if g.dtype == BF16 else 4
+    with _Timed('adamw_dev_kernel', 12 * p.numel(), (24 + gbytes + (2 if shadow is not None else 0)) * p.numel()):
+        check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(state), p.numel(),
+                 float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), _stream()), 'clv_adamw_step_dev')

@@ -12,11 +12,17 @@ from .dist import collectives_active
 
 
 class BucketedGradReducer:
-    def __init__(self, slabs, bucket_bytes=64 << 20, split_key=None):
+    def __init__(self, slabs, bucket_bytes=64 << 20, split_key=None, wire=None):
         """slabs: list of (flat_grad, params, offsets) with params[i].grad a view of
         flat_grad[offsets[i]:offsets[i+1]] (in the order backward is expected to fill them).
         split_key(param): buckets never span a change of key (the engine's graph mode launches buckets per
         gradient class — heads / text encoder / late / early video stages — as each class completes)."""
+        # wire: optional list of bf16 tensors parallel to the slabs' flat gradients.  With it a bucket travels as bf16 —
+        # its fp32 slice is packed into the wire slab on the comm stream right before its all-reduce, and the optimizer
+        # reads the reduced bf16 copy (fp32 update) — half the bytes over xGMI; the reference all-reduces fp16 gradients
+        # (mmcv_Fp16OptimizerHook.py:119-122).
+        self.wire = wire
+        self.launch_log = []        # (bucket, split key, bytes on the wire, 'hook' | 'where' | 'finish') of the last step
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.enabled = True         # False: hooks are inert (hipGraph capture) and finish() sends everything
         self.buckets = []           # [flat_grad, start, end, n_params]
@@ -39,7 +45,8 @@ class BucketedGradReducer:
                     q._clv_ready = (lambda: None)
             return
         cap = max(1, bucket_bytes // 4)
-        for flat, params, offsets in slabs:
+        self._bucket_key, self._bucket_slab = [], []
+        for si, (flat, params, offsets) in enumerate(slabs):
             start, count = 0, 0
             for i, p in enumerate(params):
                 count += 1
@@ -47,6 +54,8 @@ class BucketedGradReducer:
                 boundary = split_key is not None and i + 1 < len(params) and split_key(params[i + 1]) != split_key(p)
                 if end - start >= cap or i == len(params) - 1 or boundary:
                     self.buckets.append([flat, start, end, count])
+                    self._bucket_slab.append(si)
+                    self._bucket_key.append(split_key(p) if split_key is not None else None)
                     self._bucket_params.append(list(params[i + 1 - count:i + 1]))
                     b = len(self.buckets) - 1
                     for q in params[i + 1 - count:i + 1]:
@@ -58,14 +67,32 @@ class BucketedGradReducer:
                 self.comm_stream = torch.cuda.Stream(device=flat.device)
         self.reset()
 
+    def begin_step(self):
+        """Forget the previous step's launch log (the engine calls this when a step starts)."""
+        self.launch_log = []
+
     def reset(self):
         self.pending = [b[3] for b in self.buckets]
         self.handles = []
         self.seen = {}
         self._producers = [[] for _ in self.buckets]
 
-    def _launch(self, b):
+    def _payload(self, b):
+        """The tensor bucket b puts on the wire: the fp32 slab slice, or its freshly packed bf16 copy."""
         flat, s, e, _ = self.buckets[b]
+        if self.wire is None:
+            return flat[s:e]
+        w = self.wire[self._bucket_slab[b]][s:e]
+        if flat.is_cuda:
+            from .. import ops
+            ops.pack_bf16(flat[s:e], w)
+        else:
+            w.copy_(flat[s:e])
+        return w
+
+    def _launch(self, b, phase='hook'):
+        flat, s, e, _ = self.buckets[b]
+        self.launch_log.append((b, self._bucket_key[b], (e - s) * (2 if self.wire is not None else 4), phase))
         if self.comm_stream is not None:
             # The hook countdown is HOST-ordered: the bucket's other gradients may have been produced on another
             # stream than the last hook's (the text tower runs on a side stream) — wait for every producer stream.
@@ -73,9 +100,9 @@ class BucketedGradReducer:
             for st in self._producers[b]:
                 self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(dist.all_reduce(flat[s:e], async_op=True))
+                self.handles.append(dist.all_reduce(self._payload(b), async_op=True))
         else:
-            self.handles.append(dist.all_reduce(flat[s:e], async_op=True))
+            self.handles.append(dist.all_reduce(self._payload(b), async_op=True))
 
     def _make_hook(self, b):
         def hook(param):
@@ -104,7 +131,7 @@ class BucketedGradReducer:
             raise RuntimeError('launch_where needs the bucket -> parameter map')
         for b, ps in enumerate(self._bucket_params):
             if self.pending[b] > 0 and all(ready(q) for q in ps):
-                self._launch(b)
+                self._launch(b, 'where')
                 self.pending[b] = 0
 
     def finish(self):
@@ -117,9 +144,30 @@ class BucketedGradReducer:
             self.calibrated = True
         for b, left in enumerate(self.pending):
             if left > 0:
-                self._launch(b)
+                self._launch(b, 'finish')
         for h in self.handles:
             h.wait()
         if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            if self.time_exposed:
+                # GPU-side stall of the compute stream on the comm stream = the exposed (not overlapped) part of the
+                # gradient exchange: two events around the cross-stream wait, read by exposed_ms() after a sync
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.comm_stream)
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self.comm_stream)
         self.reset()
+
+    time_exposed = False
+    _exposed = ()
+
+    def start_timing(self):
+        self.time_exposed, self._exposed = True, []
+
+    def exposed_ms(self):
+        """Mean per-step stall of the compute stream waiting for the gradient all-reduces (call after a device sync)."""
+        ev, self._exposed, self.time_exposed = self._exposed, [], False
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None

@@ -417,6 +417,15 @@ int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, const float
                     int64_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue,
                     void* stream);
 
+/* Data-parallel gradient exchange in bf16 (the reference all-reduces the fp16 model gradients:
+ * mmaction/core/hooks/mmcv_Fp16OptimizerHook.py:119-122): clv_pack_bf16 writes the bf16 wire copy of an fp32 gradient-slab
+ * slice (RCCL all-reduces THAT over xGMI: half the bytes), clv_sumsq_bf16 / clv_adamw_step_dev_bf16g are clv_sumsq /
+ * clv_adamw_step_dev reading the reduced bf16 gradient — the update itself (moments, master weights) stays fp32. */
+int clv_pack_bf16(const float* src, void* dst, int64_t n, void* stream);
+int clv_sumsq_bf16(const void* g, float* acc, int64_t n, void* stream);
+int clv_adamw_step_dev_bf16g(float* p, const void* g, float* m, float* v, void* shadow, const void* state, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,57 @@ def test_bucketed_allreduce_and_log_vars_world2():
         assert all(r[1:]), r
 
 
+def _w_reducer_wire(rank, world, port, q):
+    """bf16 wire slabs + per-class buckets + launch_where: what the engine's graph mode does between backward replays."""
+    _init(rank, world, port)
+    from clover_amd.utils.grad_reducer import BucketedGradReducer
+    torch.manual_seed(0)
+    mods = dict(h=torch.nn.Linear(8, 8), t=torch.nn.Linear(8, 8), v1=torch.nn.Linear(8, 8), v0=torch.nn.Linear(8, 4))
+    cls_of, params = {}, []
+    for c in ('h', 't', 'v1', 'v0'):                       # slab order = the order backward completes the classes
+        for p in mods[c].parameters():
+            cls_of[id(p)] = c
+            params.append(p)
+    offs = [0]
+    for p in params:
+        offs.append(offs[-1] + (p.numel() + 3) // 4 * 4)
+    flat = torch.zeros(offs[-1])
+    wire = [torch.zeros(offs[-1], dtype=torch.bfloat16)]
+    for p, o in zip(params, offs):
+        p.grad = flat[o:o + p.numel()].view_as(p)
+    red = BucketedGradReducer([(flat, params, offs)], bucket_bytes=1 << 20, split_key=lambda p_: cls_of[id(p_)], wire=wire)
+    red.enabled = False                                     # graph mode: the engine launches the buckets itself
+    red.reset()
+    g = torch.Generator().manual_seed(7 + rank)
+    for p in params:
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    mine = flat.clone()
+    red.begin_step()
+    ready = lambda *cs: (lambda p_: cls_of[id(p_)] in cs)
+    red.launch_where(ready('h'))
+    red.launch_where(ready('h', 't'))
+    red.launch_where(ready('h', 'v1'))
+    red.finish()
+    log = list(red.launch_log)
+    ok_cls = [k for _, k, _, _ in log] == ['h', 't', 'v1', 'v0'] and [ph for *_, ph in log] == ['where'] * 3 + ['finish']
+    ok_bytes = sum(b for _, _, b, _ in log) == 2 * offs[-1]            # bf16 on the wire: 2 bytes per gradient element
+    # reduced values: sum over ranks of the bf16-rounded gradients, in the wire slab; the fp32 slab keeps the local ones
+    tot = torch.zeros_like(flat)
+    for r in range(world):
+        gr = torch.Generator().manual_seed(7 + r)
+        for p, o in zip(params, offs):
+            tot[o:o + p.numel()] += torch.randn(p.shape, generator=gr).reshape(-1).to(torch.bfloat16).float()
+    ok_val = torch.allclose(wire[0].float(), tot, rtol=2 ** -7, atol=1e-6) and torch.equal(flat, mine)
+    q.put((rank, ok_cls, ok_bytes, ok_val))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_buckets_leave_per_gradient_class_world2():
+    for r in _run(_w_reducer_wire, 2, 29716):
+        assert all(r[1:]), r
+
+
 # ----------------------------------------------------------------------------- oracle vs the reference's 2-rank run
 def _w_oracle(rank, world, port, q):
     _init(rank, world, port)

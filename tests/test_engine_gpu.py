@@ -348,6 +348,17 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
         classes = {eng._pclass.get(id(q), 'h') for ps in eng.reducer._bucket_params for q in ps}
         assert classes == {'h', 't', 'v1', 'v0'}
         assert all(len({eng._pclass.get(id(q), 'h') for q in ps}) == 1 for ps in eng.reducer._bucket_params)
+        # bucket launch order of the last step: heads / fusion first (right after graph 1), text-encoder and late-video
+        # buckets from between the replays, and only the early video stages (+ patch embedding) are left to finish();
+        # the gradients travel as bf16 (2 bytes per element on the wire)
+        log = list(eng.reducer.launch_log)
+        assert eng.wire is not None and len(log) == len(eng.reducer.buckets)
+        order = [k for _, k, _, _ in log]
+        nh = order.count('h')
+        assert nh > 0 and order[:nh] == ['h'] * nh and order[-1] == 'v0'
+        assert {k for _, k, _, ph in log if ph == 'finish'} == {'v0'} and {ph for _, k, _, ph in log if k != 'v0'} == {'where'}
+        total, left = sum(b for _, _, b, _ in log), sum(b for _, _, b, ph in log if ph == 'finish')
+        assert total == 2 * sum(seg.flat_g.numel() for seg in eng.segments) and left <= 0.05 * total, (left, total)
         g_got, g_ref = grads(eng), grads(eng, graph=False)
     finally:
         dist.destroy_process_group()
