@@ -20,7 +20,7 @@ class ClvAttnGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('mode', 'groups', 'N', 'nH', 'hd', 'D', 'H', 'W', 'wd', 'wh', 'ww', 'sd', 'sh', 'sw',
                  'ldq', 'ldk', 'ldv', 'ldo', 'bwd', 'bwh', 'bww')] + [('scale', C.c_float), ('dropout_p', C.c_float),
-                                                                      ('dbias_index', C.c_void_p)]
+                                                                      ('dbias_index', C.c_void_p), ('work', C.c_void_p)]
 
 
 _p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -51,13 +51,16 @@ class ClvLnReduceEntry(C.Structure):
 class ClvLnExtra(C.Structure):
     """Mirror of ``struct ClvLnExtra`` (include/clover_hip.h)."""
     _fields_ = [('xscale', _p), ('rows_per_sample', _i32), ('drop_p', _f), ('seed', _p), ('dy2', _p), ('dres', _p),
-                ('x_is_sum', _i32), ('gather_c', _i32), ('gather_h2', _i32), ('gather_w2', _i32), ('no_reduce', _i32)]
+                ('x_is_sum', _i32), ('gather_c', _i32), ('gather_h2', _i32), ('gather_w2', _i32), ('no_reduce', _i32),
+                ('q8', _p), ('qscale', _p)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
+    'clv_attn_seq_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_seq_max_keys': (C.c_int, []),
     'clv_attn_bwd_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index_count': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p]),

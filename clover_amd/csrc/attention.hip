@@ -39,6 +39,13 @@ struct Geom {
     // few (group, head) pairs (the fusion encoder: 16 x 12 = 192 on 256 CUs): tsplit workgroups per pair, each staging
     // the pair's K / V (or Q / dO) and taking every tsplit-th set of 4 query (key) tiles
     int tsplit;
+    // long sequences (mode 0, 448 < N <= 896 keys): the tokens STAGED in LDS — keys in the forward / dQ kernels, queries in
+    // the dK / dV kernel — are split into nparts contiguous parts of pt16 tokens, one workgroup set per part; each set
+    // writes its partial result (o + lse per key part, dq per key part, dk / dv per query part) to the caller's scratch
+    // and a combine kernel merges them (seq_combine_*).  nparts = 1: everything below degenerates to the plain kernels.
+    int nparts, pt16;
+    int lddq, lddk, lddv;                // row strides of the dq / dk / dv OUTPUTS (= ldq / ldk / ldv unless partial)
+    int64_t o_ps, lse_ps, dq_ps, dk_ps, dv_ps;   // element strides between the parts' partial outputs (0: one part)
 };
 
 __device__ __forceinline__ int win_lin(const Geom& G, int n) {
@@ -132,9 +139,14 @@ __device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int 
 // The token -> tensor-row map of this window (roll / partition folded in, ~60 integer VALU ops with five
 // divisions) is evaluated ONCE per workgroup into LDS; staging and the per-tile operand loads index it.
 template <int NK>
-__device__ __forceinline__ void token_rows(const Geom& G, int grp, int* row_s, int tid, int nthr = THREADS) {
-    for (int n = tid; n < NK; n += nthr) row_s[n] = (n < G.g.N) ? (int)tok_row(G, grp, n) : 0;
+__device__ __forceinline__ void token_rows(const Geom& G, int grp, int* row_s, int tid, int nthr = THREADS, int s0 = 0) {
+    for (int n = tid; n < NK; n += nthr) row_s[n] = (s0 + n < G.g.N) ? (int)tok_row(G, grp, s0 + n) : 0;
     __syncthreads();
+}
+// tensor row of a LOOPED token (query in fwd / dQ, key in dK / dV): the LDS map covers the staged part only once a
+// sequence is split, and a sequence's map is one multiply-add anyway
+__device__ __forceinline__ int64_t loop_row(const Geom& G, const int* row_s, int grp, int n) {
+    return G.nparts > 1 ? (int64_t)grp * G.g.N + n : (int64_t)row_s[n];
 }
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -171,16 +183,18 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int part = bid % G.tsplit;                          // tsplit workgroups share one (group, head): tile subsets
+    const int sp = (bid / G.tsplit) % G.nparts, gh = bid / (G.tsplit * G.nparts);     // sp: which part of the keys is staged
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
+    const int s0 = sp * G.pt16, Ns = min(N - s0, G.pt16);     // staged keys [s0, s0 + Ns); one part: all N
 
     int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
     int* linb_s = row_s + NK;                                // mode 1 + bias: 4 * lin(n)
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);    //                the head's bias table
     int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);     // "window straddles shift regions"
     if (tid == 0) *flag_s = 0;
-    token_rows<NK>(G, grp, row_s, tid);
+    token_rows<NK>(G, grp, row_s, tid, THREADS, s0);
     // Q fragments of ALL this wave's query tiles go out before the K / V staging loads: their round trip (~2 us under
     // load) then overlaps the staging instead of stalling every tile of the loop below.  (Long windows keep the
     // per-tile load: their score registers leave no room.)
@@ -193,14 +207,14 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             const int qt = wave + WAVES * part + ti * WAVES * G.tsplit;
             const int nq = qt * 16 + (lane & 15);
             const bool qv = qt < nqt && nq < N;
-            load_frags<HD>(qpre[ti], q + (int64_t)row_s[qv ? nq : 0] * G.g.ldq + h * HD, qv, lane);
+            load_frags<HD>(qpre[ti], q + loop_row(G, row_s, grp, qv ? nq : 0) * G.g.ldq + h * HD, qv, lane);
         }
     }
     // K is staged as K * scale * log2(e) and every additive term (bias table, key mask, region mask) is kept in log2
     // units: the MFMA, started from the additive terms as its accumulator, delivers the exp2-ready score — one VALU
     // operation per score less than scale-and-add after the MFMA.
-    stage<HD, NK, true>(row_s, k, G.g.ldk, h, N, Ks, tid, THREADS, G.g.scale * LOG2E);
-    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid);
+    stage<HD, NK, true>(row_s, k, G.g.ldk, h, Ns, Ks, tid, THREADS, G.g.scale * LOG2E);
+    stage<HD, NK>(row_s, v, G.g.ldv, h, Ns, Vs, tid);
     if (MODE == 1 && bias) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, THREADS, LOG2E);
     int* rid_s = reinterpret_cast<int*>(aux);
     // kadd[n]: additive key term — the key mask (mode 0) for real keys, -inf for the pad keys of the last tile.
@@ -213,7 +227,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
         }
-        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f) : -INFINITY;
+        kadd[n] = (n < Ns) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + s0 + n] * LOG2E : 0.f) : -INFINITY;
     }
     // a shifted block's windows that lie inside ONE region (all but the last row / column of windows: 49 of 64 at
     // 56 x 56) need no mask: 12 VALU operations per key tile and query less
@@ -231,7 +245,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
         if (qt >= nqt) break;
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
-        const int64_t qrow = row_s[qv ? nq : 0];
+        const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
         Frag8 qf[KS];
         if (PRE > 1) {
 #pragma unroll
@@ -257,7 +271,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             const float4 bv = bnext;
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
             f32x4_t acc = {bv.x, bv.y, bv.z, bv.w};                   // additive terms first, the MFMA adds q.k on top
-            if (MODE == 0 || (t + 1) * 16 > N) {                      // key mask (mode 0) / -inf on the pad keys of the last tiles
+            if (MODE == 0 || (t + 1) * 16 > Ns) {                     // key mask (mode 0) / -inf on the pad keys of the last tiles
                 const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
                 acc[0] += ka.x; acc[1] += ka.y; acc[2] += ka.z; acc[3] += ka.w;
             }
@@ -294,7 +308,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             for (int t = 0; t < NKT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    p[t][r] *= keep_scale(sd, rowid, (unsigned)(t * 16 + lg * 4 + r), G.drop_thresh, G.inv_keep);
+                    p[t][r] *= keep_scale(sd, rowid, (unsigned)(s0 + t * 16 + lg * 4 + r), G.drop_thresh, G.inv_keep);
         }
 
         f32x4_t oacc[NC];
@@ -322,10 +336,12 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             if (!DROP) sacc = mfma16(onesf, pf, sacc);
         }
         if (!DROP) sum = sacc[0];
-        if (qv && lg == 0) lse[((int64_t)grp * G.g.nH + h) * N + nq] = (m + __log2f(sum)) * (1.0f / LOG2E);
+        // one part: the final o / lse.  Several: this key part's normalised o and its lse into the caller's scratch (part
+        // stride o_ps / lse_ps), merged by seq_combine_fwd_kernel
+        if (qv && lg == 0) lse[sp * G.lse_ps + ((int64_t)grp * G.g.nH + h) * N + nq] = (m + __log2f(sum)) * (1.0f / LOG2E);
         const float inv = 1.0f / sum;
         if (qv) {
-            bf16_t* orow = o + qrow * G.g.ldo + h * HD + lg * 4;
+            bf16_t* orow = o + sp * G.o_ps + qrow * G.g.ldo + h * HD + lg * 4;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 uint2 w;
@@ -360,14 +376,16 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int part = bid % G.tsplit;                          // tsplit workgroups share one (group, head): tile subsets
+    const int sp = (bid / G.tsplit) % G.nparts, gh = bid / (G.tsplit * G.nparts);     // see attn_fwd_kernel
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
+    const int s0 = sp * G.pt16, Ns = min(N - s0, G.pt16);     // staged keys [s0, s0 + Ns)
     const bool tb = MODE == 1 && bias != nullptr;
     int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);
     if (tid == 0) *flag_s = 0;
 
-    token_rows<NK>(G, grp, row_s, tid, nthr);
+    token_rows<NK>(G, grp, row_s, tid, nthr, s0);
     // q / dO / o fragments of all this wave's query tiles go out before the K / V staging loads (see attn_fwd_kernel)
     constexpr int NWAVES = DKV_THREADS(NKT) / 64;
     constexpr int PRE = (NKT + NWAVES - 1) / NWAVES;
@@ -378,15 +396,15 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
         const int qt = wave + nwaves * part + ti * nwaves * G.tsplit;
         const int nq = qt * 16 + (lane & 15);
         const bool qv = qt < nqt && nq < N;
-        const int64_t qrow = row_s[qv ? nq : 0];
+        const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
         load_frags<HD>(qpre[ti], q + qrow * G.g.ldq + h * HD, qv, lane);
         load_frags<HD>(dopre[ti], dout + qrow * G.g.ldo + h * HD, qv, lane);
         load_frags<HD>(opre[ti], o + qrow * G.g.ldo + h * HD, qv, lane);
     }
     // K staged as K * scale * log2(e), additive terms in log2 units, MFMA started from them (see attn_fwd_kernel);
     // dQ = dS . K * scale then is (dS . K') / log2(e)
-    stage<HD, NK, true>(row_s, k, G.g.ldk, h, N, Ks, tid, nthr, G.g.scale * LOG2E);
-    stage<HD, NK>(row_s, v, G.g.ldv, h, N, Vs, tid, nthr);
+    stage<HD, NK, true>(row_s, k, G.g.ldk, h, Ns, Ks, tid, nthr, G.g.scale * LOG2E);
+    stage<HD, NK>(row_s, v, G.g.ldv, h, Ns, Vs, tid, nthr);
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr, LOG2E);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     int differs = 0;
@@ -396,7 +414,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
         }
-        kadd[n] = (n < N) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f) : -INFINITY;
+        kadd[n] = (n < Ns) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + s0 + n] * LOG2E : 0.f) : -INFINITY;
     }
     if (differs) *flag_s = 1;
     __syncthreads();
@@ -410,7 +428,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
         if (qt >= nqt) break;
         const int nq = qt * 16 + lr;
         const bool qv = nq < N;
-        const int64_t qrow = row_s[qv ? nq : 0];
+        const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
         Frag8 qf[KS], dof[KS], of[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { qf[s] = qpre[ti][s]; dof[s] = dopre[ti][s]; of[s] = opre[ti][s]; }
@@ -442,7 +460,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
             f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
             const int key0 = t * 16 + lg * 4;
-            if (MODE == 0 || (t + 1) * 16 > N) {
+            if (MODE == 0 || (t + 1) * 16 > Ns) {
                 const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
                 sacc[0] += ka.x; sacc[1] += ka.y; sacc[2] += ka.z; sacc[3] += ka.w;
             }
@@ -466,7 +484,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
             for (int r = 0; r < 4; ++r) {
                 const float pr = __builtin_amdgcn_exp2f(sacc[r] + nL2);           // pad keys: exp2(-inf) = 0
                 float dp = pacc[r];
-                if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(key0 + r), G.drop_thresh, G.inv_keep);
+                if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(s0 + key0 + r), G.drop_thresh, G.inv_keep);
                 ds[r] = pr * (dp - dsm);
             }
             dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
@@ -489,7 +507,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
                 qacc[c] = mfma16(kf, dsf[s2], qacc[c]);
             }
         if (qv) {
-            bf16_t* drow = dq + qrow * G.g.ldq + h * HD + lg * 4;
+            bf16_t* drow = dq + sp * G.dq_ps + qrow * G.lddq + h * HD + lg * 4;    // several key parts: partial dq each
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 uint2 w;
@@ -518,9 +536,11 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int part = bid % G.tsplit, gh = bid / G.tsplit;     // tsplit workgroups share one (group, head): tile subsets
+    const int part = bid % G.tsplit;                          // tsplit workgroups share one (group, head): tile subsets
+    const int sp = (bid / G.tsplit) % G.nparts, gh = bid / (G.tsplit * G.nparts);     // sp: which part of the QUERIES is staged
     const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
     const int N = G.g.N;
+    const int s0 = sp * G.pt16, Ns = min(N - s0, G.pt16);     // staged queries [s0, s0 + Ns)
 
     int* row_s = reinterpret_cast<int*>(aux + NK);
     int* linb_s = row_s + NK;
@@ -528,7 +548,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     const bool tb = MODE == 1 && bias != nullptr;
     int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);
     if (tid == 0) *flag_s = 0;
-    token_rows<NK>(G, grp, row_s, tid, nthr);
+    token_rows<NK>(G, grp, row_s, tid, nthr, s0);
     // k / v fragments of all this wave's key tiles go out before the Q / dO staging loads (see attn_fwd_kernel)
     constexpr int NWAVES = DKV_THREADS(NKT) / 64;
     constexpr int PRE = (NKT + NWAVES - 1) / NWAVES;
@@ -539,27 +559,27 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
         const int kt = wave + nwaves * part + ti * nwaves * G.tsplit;
         const int nk = kt * 16 + (lane & 15);
         const bool kv = kt < nkt && nk < N;
-        const int64_t krow = row_s[kv ? nk : 0];
+        const int64_t krow = loop_row(G, row_s, grp, kv ? nk : 0);
         load_frags<HD>(kpre[ti], k + krow * G.g.ldk + h * HD, kv, lane);
         load_frags<HD>(vpre[ti], v + krow * G.g.ldv + h * HD, kv, lane);
     }
     // Q staged as Q * scale * log2(e), additive terms in log2 units, MFMA started from them (see attn_fwd_kernel);
     // dK = dS^T . Q * scale then is (dS^T . Q') / log2(e)
-    stage<HD, NK, true>(row_s, q, G.g.ldq, h, N, Qs, tid, nthr, G.g.scale * LOG2E);
-    stage<HD, NK>(row_s, dout, G.g.ldo, h, N, dOs, tid, nthr);
+    stage<HD, NK, true>(row_s, q, G.g.ldq, h, Ns, Qs, tid, nthr, G.g.scale * LOG2E);
+    stage<HD, NK>(row_s, dout, G.g.ldo, h, Ns, dOs, tid, nthr);
     if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, nthr, LOG2E);
     int* rid_s = reinterpret_cast<int*>(aux);
     const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
     int differs = 0;
     for (int n = tid; n < NK; n += nthr) {
-        const int64_t li = ((int64_t)grp * G.g.nH + h) * N + n;
-        L_s[n] = (n < N) ? -lse[li] * LOG2E : -INFINITY;    // -L * log2e (exp_sub's form); pad queries: P = exp2(-inf) = 0
-        D_s[n] = (n < N) ? dsum[li] : 0.f;
+        const int64_t li = ((int64_t)grp * G.g.nH + h) * N + s0 + n;
+        L_s[n] = (n < Ns) ? -lse[li] * LOG2E : -INFINITY;   // -L * log2e (exp_sub's form); pad queries: P = exp2(-inf) = 0
+        D_s[n] = (n < Ns) ? dsum[li] : 0.f;
         if (MODE == 1 && rid) {
             const int rv = (n < N) ? rid[wloc * N + n] : 0;
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
-        } else if (MODE == 0 && kmask) aux[n] = (n < N) ? kmask[(int64_t)grp * N + n] * LOG2E : 0.f;
+        }
     }
     if (differs) *flag_s = 1;
     __syncthreads();
@@ -573,12 +593,12 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
         if (kt >= nkt) break;
         const int nk = kt * 16 + lr;
         const bool kv = nk < N;
-        const int64_t krow = row_s[kv ? nk : 0];
+        const int64_t krow = loop_row(G, row_s, grp, kv ? nk : 0);
         Frag8 kf[KS], vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { kf[s] = kpre[ti][s]; vf[s] = vpre[ti][s]; }
         const int rk = (MODE == 1 && rid && kv) ? rid_s[nk] : 0;
-        const float kmv = (MODE == 0 && kmask && kv) ? aux[nk] : 0.f;
+        const float kmv = (MODE == 0 && kmask && kv) ? kmask[(int64_t)grp * N + nk] * LOG2E : 0.f;   // this lane's key
         const int ko = tb ? linb_s[kv ? nk : 0] - 4 * G.tcst : 0;     // slot(q, key) = lin(q) - (lin(key) - tcst)
 
         f32x4_t dvacc[NC], dkacc[NC];
@@ -632,7 +652,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
                     const float pr = __builtin_amdgcn_exp2f(sacc[r] + Lr[r]);
                     float ks = 1.f;
                     if (DROP)
-                        ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + qn0 + r), (unsigned)nk, G.drop_thresh,
+                        ks = keep_scale(sd, (unsigned)((grp * G.g.nH + h) * N + s0 + qn0 + r), (unsigned)nk, G.drop_thresh,
                                         G.inv_keep);
                     pv[r] = pr * ks;
                     dsv[r] = pr * (pacc[r] * ks - Dr[r]);
@@ -655,8 +675,8 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
             }
         }
         if (kv) {
-            bf16_t* dvrow = dv + krow * G.g.ldv + h * HD + lg * 4;
-            bf16_t* dkrow = dk + krow * G.g.ldk + h * HD + lg * 4;
+            bf16_t* dvrow = dv + sp * G.dv_ps + krow * G.lddv + h * HD + lg * 4;    // several query parts: partial dk / dv each
+            bf16_t* dkrow = dk + sp * G.dk_ps + krow * G.lddk + h * HD + lg * 4;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 uint2 w;
@@ -856,7 +876,69 @@ __global__ void __launch_bounds__(256) attn_f32_fwd_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------- long sequences: merging the parts
+// Forward: key part p delivered o_p = softmax over ITS keys . V_p and lse_p; over all keys
+//   lse = log sum_p exp(lse_p),   o = sum_p exp(lse_p - lse) o_p.
+// One thread = 8 consecutive channels of one (token, head).
+__global__ void __launch_bounds__(256) seq_combine_fwd_kernel(const bf16_t* __restrict__ o_part, const float* __restrict__ lse_part,
+                                                              bf16_t* __restrict__ o, float* __restrict__ lse, Geom G) {
+    const int HD = G.g.hd, C = G.g.nH * HD, cpr = C / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tokens = (int64_t)G.g.groups * G.g.N;
+    if (idx >= tokens * cpr) return;
+    const int64_t row = idx / cpr;
+    const int c = (int)(idx - row * cpr) * 8, h = c / HD;
+    const int64_t grp = row / G.g.N, n = row - grp * G.g.N;
+    const int64_t li = (grp * G.g.nH + h) * G.g.N + n;
+    float lp[4], m = -INFINITY;
+    for (int p = 0; p < G.nparts; ++p) {
+        lp[p] = lse_part[p * G.lse_ps + li];
+        m = fmaxf(m, lp[p]);
+    }
+    float tot = 0.f;
+    for (int p = 0; p < G.nparts; ++p) tot += __expf(lp[p] - m);
+    const float L = m + __logf(tot);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int p = 0; p < G.nparts; ++p) {
+        const float w = __expf(lp[p] - L);
+        Frag8 f;
+        f.u4 = *reinterpret_cast<const uint4*>(o_part + p * G.o_ps + row * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, bf2f(f.h[e]), acc[e]);
+    }
+    *reinterpret_cast<uint4*>(o + row * G.g.ldo + c) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+    if ((c % HD) == 0) lse[li] = L;
+}
+
+// Backward: dq is the sum of the key parts' partial dq, dk / dv the sum of the query parts' partial dk / dv.
+__global__ void __launch_bounds__(256) seq_combine_bwd_kernel(const bf16_t* __restrict__ part, bf16_t* __restrict__ dq,
+                                                              bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, Geom G) {
+    const int C = G.g.nH * G.g.hd, cpr = C / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tokens = (int64_t)G.g.groups * G.g.N;
+    if (idx >= 3 * tokens * cpr) return;
+    const int which = (int)(idx / (tokens * cpr));
+    const int64_t rem = idx - which * tokens * cpr, row = rem / cpr;
+    const int c = (int)(rem - row * cpr) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int p = 0; p < G.nparts; ++p) {
+        Frag8 f;      // scratch layout [part][dq | dk | dv][tokens][C]
+        f.u4 = *reinterpret_cast<const uint4*>(part + ((int64_t)p * 3 + which) * tokens * C + row * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(f.h[e]);
+    }
+    bf16_t* out = which == 0 ? dq + row * G.g.ldq : which == 1 ? dk + row * G.g.ldk : dv + row * G.g.ldv;
+    *reinterpret_cast<uint4*>(out + c) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+}
+
 // ------------------------------------------------------------------------- host side
+constexpr int SEQ_ONE_PART_TILES = 28;       // 448 keys: the largest instantiation (LDS)
 bool make_geom(const ClvAttnGeom* g, Geom& G) {
     if (!g) return false;
     G.g = *g;
@@ -876,6 +958,21 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
         const int pairs = g->groups * g->nH, tiles = (g->N + 15) / 16;
         G.tsplit = 1;
         while (G.tsplit < 4 && pairs * G.tsplit < 384 && tiles >= 8 * G.tsplit) G.tsplit *= 2;
+        G.nparts = 1;
+        G.pt16 = tiles * 16;
+        G.lddq = g->ldq; G.lddk = g->ldk; G.lddv = g->ldv;
+        G.o_ps = G.lse_ps = G.dq_ps = G.dk_ps = G.dv_ps = 0;
+        if (g->mode == 0 && tiles > SEQ_ONE_PART_TILES) {   // K / V (Q / dO) of one (sample, head) exceed the LDS: two parts
+            if (tiles > 2 * SEQ_ONE_PART_TILES) return false;
+            G.nparts = 2;
+            G.pt16 = (tiles + 1) / 2 * 16;
+            G.tsplit = 2;                                   // looped tiles per workgroup set: <= 64 (see launch checks)
+            const int64_t tokens = (int64_t)g->groups * g->N, C = (int64_t)g->nH * g->hd;
+            G.o_ps = tokens * C;
+            G.lse_ps = (int64_t)g->groups * g->nH * g->N;
+            G.lddq = G.lddk = G.lddv = (int)C;
+            G.dq_ps = G.dk_ps = G.dv_ps = 3 * tokens * C;   // scratch [part][dq | dk | dv][tokens][C]
+        }
     }
     if (g->mode == 1) {
         if (g->wd <= 0 || g->wh <= 0 || g->ww <= 0) return false;
@@ -961,9 +1058,25 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     if (lds > MAX_LDS || dq_lds<HD, NKT>(bl) > MAX_LDS || dkv_lds<HD, NKT>(bl) > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
-    const int nblk = G.g.groups * G.g.nH * G.tsplit;
+    const int nblk = G.g.groups * G.g.nH * G.tsplit * G.nparts;
+    if (G.nparts == 1) {
+        CLV_PICK(attn_fwd_kernel, <<<dim3(nblk), dim3(THREADS), lds, st>>>((const bf16_t*)q, (const bf16_t*)k,
+                 (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G));
+        return clv_check_launch();
+    }
+    // two key parts: partial o (dense [tokens][C]) + lse per part into the scratch, then the merge
+    if (!G.g.work || (NKT + WAVES - 1) / WAVES * WAVES * G.tsplit < (G.g.N + 15) / 16) return CLV_ERR_UNSUPPORTED;
+    Geom P = G;
+    P.g.ldo = G.g.nH * G.g.hd;
+    bf16_t* o_part = reinterpret_cast<bf16_t*>(G.g.work);
+    float* lse_part = reinterpret_cast<float*>(o_part + G.nparts * G.o_ps);
     CLV_PICK(attn_fwd_kernel, <<<dim3(nblk), dim3(THREADS), lds, st>>>((const bf16_t*)q, (const bf16_t*)k,
-             (const bf16_t*)v, (bf16_t*)o, lse, bias, rid, kmask, seed, G));
+             (const bf16_t*)v, o_part, lse_part, bias, rid, kmask, seed, P));
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    const int64_t items = (int64_t)G.g.groups * G.g.N * (G.g.nH * G.g.hd / 8);
+    hipLaunchKernelGGL(seq_combine_fwd_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, o_part, lse_part,
+                       (bf16_t*)o, lse, G);
     return clv_check_launch();
 }
 
@@ -980,11 +1093,24 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     if (lds_a > MAX_LDS || lds_b > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
-    const int nblk = G.g.groups * G.g.nH * G.tsplit;
+    const int nblk = G.g.groups * G.g.nH * G.tsplit * G.nparts;
     int rc = CLV_OK;
+    bf16_t* dq_out = (bf16_t*)dq;
+    bf16_t* dk_out = (bf16_t*)dk;
+    bf16_t* dv_out = (bf16_t*)dv;
+    if (G.nparts > 1) {                                      // partial dq / dk / dv: scratch [part][dq | dk | dv][tokens][C]
+        const int looped = (G.g.N + 15) / 16;
+        if (!G.g.work || (NKT + DKV_THREADS(NKT) / 64 - 1) / (DKV_THREADS(NKT) / 64) * (DKV_THREADS(NKT) / 64) * G.tsplit < looped ||
+            (NKE + DKV_THREADS(NKE) / 64 - 1) / (DKV_THREADS(NKE) / 64) * (DKV_THREADS(NKE) / 64) * G.tsplit < looped)
+            return CLV_ERR_UNSUPPORTED;
+        const int64_t tc = (int64_t)G.g.groups * G.g.N * G.g.nH * G.g.hd;
+        dq_out = reinterpret_cast<bf16_t*>(G.g.work);
+        dk_out = dq_out + tc;
+        dv_out = dq_out + 2 * tc;
+    }
     if (stages & 1) {
         CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(DKV_THREADS(NKT)), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
-                 (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, (bf16_t*)dq,
+                 (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, dq_out,
                  (bf16_t*)(bias ? work : nullptr), dsum, seed, G));
         rc = clv_check_launch();
         if (rc) return rc;
@@ -1012,8 +1138,15 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     }
     if (stages & 4) {
         CLV_PICK_N(attn_bwd_dkv_kernel, NKE, <<<dim3(nblk), dim3(DKV_THREADS(NKE)), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
-                 (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, (bf16_t*)dk, (bf16_t*)dv, seed, G));
+                 (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, dk_out, dv_out, seed, G));
         rc = clv_check_launch();
+        if (rc) return rc;
+        if (G.nparts > 1) {
+            const int64_t items = 3 * (int64_t)G.g.groups * G.g.N * (G.g.nH * G.g.hd / 8);
+            hipLaunchKernelGGL(seq_combine_bwd_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const bf16_t*>(G.g.work), (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, G);
+            rc = clv_check_launch();
+        }
     }
     return rc;
 }
@@ -1051,7 +1184,7 @@ extern "C" int clv_attn_fwd(const void* q, const void* k, const void* v, void* o
     const unsigned long long* sp = (const unsigned long long*)seed;
     if (bias && (G.g.mode != 1 || G.tlen == 0)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
-    const int nkt = pick_nkt(G.g.N);
+    const int nkt = pick_nkt(G.nparts > 1 ? G.pt16 : G.g.N);
     hipStream_t st = (hipStream_t)stream;
     if (G.g.hd == 16) { DISPATCH_NKT(16, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st) }
     if (G.g.hd == 32) { DISPATCH_NKT(32, launch_fwd, q, k, v, o, lse, bias, rid, kmask, sp, G, st) }
@@ -1065,6 +1198,17 @@ extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
     if (nkt < 0) return 0;
     return ds_scratch_bytes(G, nkt) + (int64_t)(DBIAS_SPLITS + 1) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;   // + fp32 partials, dense
 }
+
+extern "C" int64_t clv_attn_seq_work_bytes(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G) || G.nparts == 1) return 0;
+    // forward: partial o + lse per part; backward: partial dq / dk / dv per part (the larger of the two)
+    const int64_t tc = (int64_t)G.g.groups * G.g.N * G.g.nH * G.g.hd;
+    const int64_t fwd = G.nparts * (tc * 2 + G.lse_ps * 4), bwd = G.nparts * 3 * tc * 2;
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int clv_attn_seq_max_keys(void) { return 2 * SEQ_ONE_PART_TILES * 16; }
 
 extern "C" int64_t clv_attn_dbias_index_count(const ClvAttnGeom* geom) {
     Geom G;
@@ -1092,7 +1236,7 @@ extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const v
     if (bias && (G.g.mode != 1 || G.tlen == 0 || !dbias || !work)) return CLV_ERR_ARG;
     if (rid && G.g.mode != 1) return CLV_ERR_ARG;
     if (G.drop_thresh && !seed) return CLV_ERR_ARG;
-    const int nkt = pick_nkt(G.g.N);
+    const int nkt = pick_nkt(G.nparts > 1 ? G.pt16 : G.g.N);
     hipStream_t st = (hipStream_t)stream;
     if (G.g.hd == 16) { DISPATCH_NKT(16, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st) }
     if (G.g.hd == 32) { DISPATCH_NKT(32, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st) }

@@ -274,6 +274,10 @@ struct LnX {
     // gC-wide source rows (2h+hp, 2w+wp) with channel block q = 2*wp + hp; x / res / dx / dres are then the
     // UN-gathered [.., 2*gH2, 2*gW2, gC] tensors and the kernels address them through src_off().  gC = 0: off.
     int gC, gH2, gW2;
+    // fp8 path (clv_gemm_nt_fp8's activation operand produced HERE instead of by a clv_quant_fp8_rows pass over y):
+    // q8 [rows][C] e4m3 bytes = y / qscale[row], qscale[row] = max |y[row]| / 448.  null: off.
+    unsigned char* q8;
+    float* qscale;
 };
 
 // element offset in the un-gathered tensor of column c (a multiple of 8; gC % 8 == 0) of gathered row `row`
@@ -321,6 +325,13 @@ template <> struct IO8<float> {
     }
 };
 __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) { IO8<float>::ld(p, v); }
+
+template <int GROUP>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 template <int GROUP>
 __device__ __forceinline__ float group_sum(float v) {
@@ -420,6 +431,37 @@ __global__ void __launch_bounds__(LN_THREADS) lnv_fwd_kernel(
                 for (int e = 0; e < 8; ++e) o[e] = (t[i][e] - mu) * rs * g[e] + b[e];
                 IO8<T>::st(y + row * C + c, o);
                 if (sum_out) IO8<T>::st(sum_out + row * C + c, t[i]);
+                if (xf.q8) {                                  // keep the outputs for the quantisation pass below
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[i][e] = o[e];
+                }
+            }
+        }
+        if (xf.q8) {
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i)
+                if ((i * GROUP + gl) * 8 < C) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(t[i][e]));
+                }
+            amax = group_max<GROUP>(amax);
+            const float inv = amax > 0.f ? 448.0f / amax : 1.0f;
+            if (gl == 0) xf.qscale[row] = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int c = (i * GROUP + gl) * 8;
+                if (c < C) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(t[i][e] * inv, -448.f), 448.f);
+                    int lo = 0, hi = 0;
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+                    *reinterpret_cast<uint2*>(xf.q8 + row * C + c) = make_uint2((unsigned)lo, (unsigned)hi);
+                }
             }
         }
     }
@@ -589,8 +631,12 @@ inline int lnv_blocks(int64_t rows, int group, bool fwd = false) {
     LNV_CASE(64, 6, KERNEL, TY, XF, GRID, __VA_ARGS__)
 
 inline bool make_lnx(const ClvLnExtra* ex, LnX& xf) {
-    xf = LnX{nullptr, 1, 0u, 1.f, nullptr, 0, 0, 0, 0};
+    xf = LnX{nullptr, 1, 0u, 1.f, nullptr, 0, 0, 0, 0, nullptr, nullptr};
     if (!ex) return false;
+    if (ex->q8 && ex->qscale) {
+        xf.q8 = (unsigned char*)ex->q8;
+        xf.qscale = ex->qscale;
+    }
     if (ex->gather_c > 0) {
         xf.gC = ex->gather_c;
         xf.gH2 = ex->gather_h2;
@@ -688,7 +734,7 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
         }
         return clv_check_launch();
     }
-    if (XF) return CLV_ERR_UNSUPPORTED;              // the scalar fallback has no operand transforms
+    if (XF || xf.q8) return CLV_ERR_UNSUPPORTED;     // the scalar fallback has no operand transforms / fp8 output
     const int it = ln_iters(C);
     const int grid = ln_fwd_blocks(rows);
     if (is_f32) {

@@ -84,6 +84,8 @@ def _dbias_index(g, device):
 def _kname(kernel, g):
     """Device-kernel name as rocprofv3 prints it: template <HD, NKT, DROP, MODE> (attention.hip CLV_PICK)."""
     need = (g.N + 15) // 16
+    if g.mode == 0 and need > 28:             # a long sequence runs as two parts of staged tokens (attention.hip make_geom)
+        need = (need + 1) // 2
     nkt = next((o for o in (2, 8, 13, 14, 15, 16, 25, 28) if o >= need), need)       # > 28: the C call reports UNSUPPORTED
     drop = 'true' if (g.dropout_p > 0 and g.mode == 0) else 'false'
     if kernel == 'attn_bwd_dkv_kernel':
@@ -384,12 +386,16 @@ def quant_fp8_rows(x2):
     return q, sc
 
 
-def gemm_nt_fp8(a, b, bias=None, epilogue=None):
+def gemm_nt_fp8(a, b, bias=None, epilogue=None, aq8=None):
     """c bf16 [M,N] = a [M,K] . b [N,K]^T (+ bias, GELU) with both bf16 operands quantised row-wise to e4m3 on the way
-    (raw launcher, no autograd).  Returns c, or (c, GELU'(pre)) for GEMM_EPI_BIAS_GELU_D."""
+    (raw launcher, no autograd).  aq8 = (q uint8 [M,K], scale fp32 [M]): a's quantised form when its producer already
+    wrote it (the LayerNorm kernel).  Returns c, or (c, GELU'(pre)) for GEMM_EPI_BIAS_GELU_D."""
     if epilogue is None:
         epilogue = GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE
-    aq, asc = quant_fp8_rows(a)
+    if aq8 is not None and tuple(aq8[0].shape) == tuple(a.shape):
+        aq, asc = aq8
+    else:
+        aq, asc = quant_fp8_rows(a)
     bq, bsc = quant_fp8_rows(b)
     M, K = a.shape
     N = b.shape[0]
@@ -452,7 +458,7 @@ class _Linear(torch.autograd.Function):
     gradient all-reduce)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, xq=None):
         _need_gpu(x, weight)
         xb = x if x.dtype == BF16 else x.to(BF16)
         wb = getattr(weight, '_clv_shadow', None)
@@ -469,7 +475,7 @@ class _Linear(torch.autograd.Function):
             bf = bias if bias is not None and bias.dtype == torch.float32 else (bias.float() if bias is not None else None)
             y = rowgemm(x2, wb, bf)['y'].view(xb.shape[:-1] + (N,))
         elif fp8_ok(x2, N, K):
-            y = gemm_nt_fp8(x2, wb, bias.detach() if bias is not None else None).view(xb.shape[:-1] + (N,))
+            y = gemm_nt_fp8(x2, wb, bias.detach() if bias is not None else None, aq8=xq).view(xb.shape[:-1] + (N,))
         elif own_gemm_ok(x2, N, K):
             y = gemm_nt(x2, wb, bias.detach() if bias is not None else None,
                         epilogue=GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE).view(xb.shape[:-1] + (N,))
@@ -504,7 +510,7 @@ class _Linear(torch.autograd.Function):
                 dw, db = linear_wgrad(dy2, x2, ctx.has_bias)
                 dw = dw.to(ctx.wdtype)
                 db = db.to(ctx.wdtype) if db is not None else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 _NOAFFINE_CONST = {}
@@ -733,7 +739,7 @@ def fused_block_supported(C_, hidden):
 def linear(x, weight, bias=None):
     if parity.enabled():
         return parity.linear(x, weight, bias)
-    return _Linear.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias, getattr(x, '_clv_fp8', None) if FP8 else None)
 
 
 def _param_grads(dy2, x2, weight, bias):
@@ -756,7 +762,7 @@ class _MlpGelu(torch.autograd.Function):
     clv_gemm_nt with the GELU-backward epilogue — the two standalone GELU passes over the [M, 4C] tensor are gone."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, xq=None):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         w1b = getattr(w1, '_clv_shadow', None)
@@ -769,7 +775,7 @@ class _MlpGelu(torch.autograd.Function):
         ctx.dgelu_saved = (os.environ.get('CLOVER_GELU_SAVE_GRAD', '1') == '1' and own_gemm_ok(x2, Hd, C_)
                            and os.environ.get('CLOVER_DGELU_FUSE', '1') == '1')
         if ctx.dgelu_saved and fp8_ok(x2, Hd, C_):
-            act, pre = gemm_nt_fp8(x2, w1b, b1.detach(), epilogue=GEMM_EPI_BIAS_GELU_D)
+            act, pre = gemm_nt_fp8(x2, w1b, b1.detach(), epilogue=GEMM_EPI_BIAS_GELU_D, aq8=xq)
         else:
             act, pre = gemm_nt(x2, w1b, b1.detach(),
                                epilogue=GEMM_EPI_BIAS_GELU_D if ctx.dgelu_saved else GEMM_EPI_BIAS_GELU)
@@ -800,7 +806,7 @@ class _MlpGelu(torch.autograd.Function):
         dw2, db2 = _param_grads(do2, act, w2, b2)
         dx = linear_dgrad(dpre, w1b, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = _param_grads(dpre, x2, w1, b1)
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None
 
 
 def mlp_gelu_ok(x, hidden):
@@ -810,7 +816,7 @@ def mlp_gelu_ok(x, hidden):
 
 
 def mlp_gelu(x, w1, b1, w2, b2):
-    return _MlpGelu.apply(x, w1, b1, w2, b2)
+    return _MlpGelu.apply(x, w1, b1, w2, b2, getattr(x, '_clv_fp8', None) if FP8 else None)
 
 
 # --------------------------------------------------------------------------- LDS-tiled GEMM with fused epilogues
@@ -893,12 +899,21 @@ def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=No
 
 
 # --------------------------------------------------------------------------- LayerNorm
-def _ln_extra(xscale, rows_per_sample, drop_p, seed, dy2=None, dres=None, x_is_sum=False):
+def _ln_extra(xscale, rows_per_sample, drop_p, seed, dy2=None, dres=None, x_is_sum=False, q8=None, qscale=None):
     """ClvLnExtra for the C call, or None when nothing is requested (keeps its tensors alive via the caller)."""
-    if xscale is None and not drop_p and dy2 is None and dres is None:
+    if xscale is None and not drop_p and dy2 is None and dres is None and q8 is None:
         return None
     return _lib.ClvLnExtra(_ptr(xscale), int(rows_per_sample), float(drop_p or 0.0), _ptr(seed), _ptr(dy2),
-                           _ptr(dres), int(x_is_sum), 0, 0, 0, 0)
+                           _ptr(dres), int(x_is_sum), 0, 0, 0, 0, _ptr(q8), _ptr(qscale))
+
+
+_LN_FP8_OUT = None          # side channel: the (q8, scale) pair the last _LayerNorm.forward produced (read by layer_norm)
+
+
+def ln_emits_fp8(C_, f32):
+    """CLOVER_FP8=1: LayerNorms whose width an fp8 GEMM can contract over also write their output as e4m3 + row scales
+    (the activation operand of the QKV / FFN-in GEMM that follows: no separate quantisation pass over the activation)."""
+    return FP8 and not f32 and C_ % 128 == 0 and 256 <= C_ <= 3072 and os.environ.get('CLOVER_FP8_LN', '1') == '1'
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -938,7 +953,13 @@ class _LayerNorm(torch.autograd.Function):
             assert rps * xs.numel() == rows, 'xscale must have one entry per leading-dim sample'
         if drop_p:
             seed = next_dropout_seed(x.device)
-        ex = _ln_extra(xs, rps or 1, drop_p, seed)
+        global _LN_FP8_OUT
+        q8 = qs = None
+        if ln_emits_fp8(C_, f32):
+            q8 = torch.empty(rows, C_, device=x.device, dtype=torch.uint8)
+            qs = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _LN_FP8_OUT = (q8, qs) if q8 is not None else None
+        ex = _ln_extra(xs, rps or 1, drop_p, seed, q8=q8, qscale=qs)
         check(_lib.lib().clv_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(g), _ptr(b), _ptr(y), _ptr(ssum), _ptr(mean),
                                            _ptr(rstd), rows, C_, float(eps), int(f32),
                                            C.byref(ex) if ex is not None else None, _stream()),
@@ -1023,7 +1044,14 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_sca
         s = parity.rnd('stream', s) if return_sum else None
         out = (y,) + ((s,) if return_sum else ()) + ((y,) if fork else ())
         return out if len(out) > 1 else y
+    global _LN_FP8_OUT
+    _LN_FP8_OUT = None
     y, s, y2 = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum), x_scale, float(x_dropout_p), bool(fork))
+    if _LN_FP8_OUT is not None:               # the consumer GEMM (ops.linear / ops.mlp_gelu) picks the operand up from here
+        y._clv_fp8 = _LN_FP8_OUT
+        if y2 is not None:
+            y2._clv_fp8 = _LN_FP8_OUT
+        _LN_FP8_OUT = None
     out = (y,) + ((s,) if return_sum else ()) + ((y2,) if fork else ())
     return out if len(out) > 1 else y
 
@@ -1186,6 +1214,9 @@ class _Attention(torch.autograd.Function):
             tab = _c(table.detach().float())
         o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=BF16)
         lse = torch.empty(g.groups * g.nH * g.N, device=qkv.device, dtype=torch.float32)
+        wbytes = _lib.lib().clv_attn_seq_work_bytes(C.byref(g))        # > 0: a sequence beyond the LDS, run as two parts
+        seq_work = torch.empty(wbytes, device=qkv.device, dtype=torch.uint8) if wbytes > 0 else None
+        g.work = seq_work.data_ptr() if seq_work is not None else None
         base = qkv.data_ptr()
         with _Timed(_kname('attn_fwd_kernel', g), *_attn_work(g, False)):
             check(_lib.lib().clv_attn_fwd(C.c_void_p(base), C.c_void_p(base + 2 * Cdim),
@@ -1207,6 +1238,9 @@ class _Attention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dsum = torch.empty_like(lse)
         L = _lib.lib()
+        wbytes = L.clv_attn_seq_work_bytes(C.byref(g))
+        seq_work = torch.empty(wbytes, device=qkv.device, dtype=torch.uint8) if wbytes > 0 else None
+        g.work = seq_work.data_ptr() if seq_work is not None else None
         dtab = work = sink = None
         if tab is not None:
             sink = getattr(ctx.tref, '_clv_grad', None)
@@ -1320,7 +1354,8 @@ def next_dropout_seed(device):
     return seed
 
 
-SEQ_FUSED_MAX_KEYS = 448          # K / V of one (sample, head) must fit LDS in the fused kernels (28 key tiles)
+SEQ_FUSED_MAX_KEYS = 896          # fused kernels: up to 448 keys staged at once, longer sequences as two parts
+                                  # (clv_attn_seq_max_keys(); the 32-frame fusion sequence has 816 tokens)
 
 
 class _LongSeqAttention(torch.autograd.Function):
@@ -1370,7 +1405,8 @@ class _LongSeqAttention(torch.autograd.Function):
 def seq_attention(qkv, kmask, num_heads, dropout_p=0.0):
     """BERT self-attention. qkv bf16 [B,S,3H]; kmask fp32 [B,S] additive ((1-m)*-10000) or None;
     dropout_p: dropout on the attention probabilities (HF attention_probs_dropout_prob).
-    Up to 448 tokens: the fused LDS-resident kernels; longer sequences: the unfused GEMM + row-softmax path."""
+    Up to 896 tokens: the fused LDS-resident kernels (beyond 448 as two parts + a merge); longer sequences: the unfused
+    GEMM + row-softmax path."""
     B, S, C3 = qkv.shape
     hd = C3 // 3 // num_heads
     if parity.enabled():

@@ -65,12 +65,19 @@ typedef struct ClvAttnGeom {
     float dropout_p;        /* dropout on the attention probabilities (HF attention_probs_dropout_prob), 0 = off */
     const int32_t* dbias_index; /* backward, optional: the device table clv_attn_dbias_index() built for this window
                                    geometry (N, bwd, bwh, bww) — the table-gradient gather then does no index arithmetic */
+    void* work;                 /* mode 0 with 448 < N <= clv_attn_seq_max_keys() (the 32-frame fusion sequence, 816 tokens,
+                                   cross_transformer.py:89-110): clv_attn_seq_work_bytes() of scratch.  K / V (Q / dO) of one
+                                   (sample, head) then exceed the LDS, so the staged tokens are split in two parts, each
+                                   with its own workgroups; the parts' results (o + lse; dq; dk / dv) meet in a merge
+                                   kernel.  Not read otherwise. */
 } ClvAttnGeom;
 
 /* lse: float [groups][nH][N].  bias: the module's relative_position_bias_table, float [rows][nH], or NULL.  rid: int32 [nW][N] region
  * ids of compute_mask (:548-562) or NULL.  kmask: float [groups][N] additive or NULL.
  * seed: device uint64[1], read when dropout_p > 0; the mask is a counter-based hash of
  * (seed, group, head, query, key), so the backward regenerates it from the same seed. */
+int64_t clv_attn_seq_work_bytes(const ClvAttnGeom* geom);
+int clv_attn_seq_max_keys(void);
 int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const float* bias, const int32_t* rid, const float* kmask, const void* seed,
                  const ClvAttnGeom* geom_host, void* stream);
@@ -136,6 +143,11 @@ typedef struct ClvLnExtra {
      * partials of many LayerNorms into their dgamma / dbeta with ONE clv_ln_reduce_batch launch (needs_reduce tells
      * whether this launch wrote partials at all: up to 256 blocks add into dgamma / dbeta directly) */
     int32_t no_reduce;
+    /* forward, fp8 path (vector kernels: C % 8 == 0 and one of their widths): also emit y as OCP e4m3 with one scale per row
+     * — q8 [rows][C] bytes = y / qscale[row], qscale[row] = max |y[row]| / 448 — the activation operand of clv_gemm_nt_fp8,
+     * produced here instead of by a clv_quant_fp8_rows pass over y.  Both NULL: off. */
+    void* q8;
+    float* qscale;
 } ClvLnExtra;
 int clv_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                       void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int32_t C,

@@ -104,6 +104,33 @@ def test_fp8_linear_and_mlp_autograd(monkeypatch):
     assert rel(wl.grad, torch.ones(M, Hd).t() @ x.float()) < 2e-2         # the backward is the bf16 one
 
 
+@pytest.mark.parametrize('rows,C', [(3136, 768), (777, 384), (100, 1024), (64, 3072), (50, 256)])
+def test_layernorm_emits_fp8_operand(rows, C, monkeypatch):
+    """With the fp8 path on, the LayerNorm forward also writes its output as e4m3 + row scales (the next GEMM's operand):
+    scale = rowmax|y| / 448 and the de-quantised rows equal y to half an e4m3 ulp; the consumer takes the pair instead of
+    running clv_quant_fp8_rows (same GEMM result as with the separate pass, up to the bf16 rounding of y the pass sees)."""
+    from clover_amd import ops
+    monkeypatch.setattr(ops, 'FP8', True)
+    x = rnd(rows, C, seed=31).to(BF).to(DEV)
+    r = rnd(rows, C, seed=32).to(BF).to(DEV)
+    g, b = (1 + 0.1 * rnd(C, seed=33)).to(DEV), (0.1 * rnd(C, seed=34)).to(DEV)
+    y, ssum = ops.layer_norm(x, g, b, 1e-5, residual=r, return_sum=True)
+    assert hasattr(y, '_clv_fp8')
+    q, sc = y._clv_fp8
+    assert q.shape == (rows, C) and q.dtype == torch.uint8
+    amax = y.float().abs().amax(1)
+    assert torch.allclose(sc, amax / 448.0, rtol=2 ** -7)                       # y is the bf16 rounding of what was scaled
+    deq = q.view(F8).float() * sc[:, None]
+    assert rel(deq, y.float()) < 2 ** -4 + 2 ** -7
+    w = (rnd(1536, C, seed=35) * 0.05).to(BF).to(DEV)
+    c_fused = ops.gemm_nt_fp8(y, w, None, aq8=(q, sc))
+    c_pass = ops.gemm_nt_fp8(y, w, None)
+    assert rel(c_fused, c_pass) < 2e-2
+    monkeypatch.setattr(ops, 'FP8', False)
+    y2 = ops.layer_norm(x, g, b, 1e-5, residual=r)
+    assert not hasattr(y2, '_clv_fp8') and torch.equal(y2, y)
+
+
 FP8_LOSS_TOL = dict(mlm_loss=5e-2, nce_loss=2.5e-1, rank_t_tm_loss=2.5e-1, v_nce_loss=2.5e-1, rank_v_vm_loss=2.5e-1, loss=6e-1)
 
 

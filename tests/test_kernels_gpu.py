@@ -738,8 +738,9 @@ def test_seq_attention_dropout():
 
 @pytest.mark.parametrize('B,S,nH,hd', [(2, 816, 12, 64), (1, 450, 2, 64), (1, 1030, 2, 32), (2, 2048, 1, 64)])
 def test_long_seq_attention(B, S, nH, hd):
-    """Sequences beyond the fused kernels' LDS budget (32-frame fusion encoder: 16*49 + 32 = 816 tokens): the unfused
-    GEMM + row-softmax path against a fp32 reference; ragged lengths exercise the row tail."""
+    """Sequences beyond 448 keys (32-frame fusion encoder: 16*49 + 32 = 816 tokens): up to 896 the fused kernels run as
+    two parts of staged tokens + a merge kernel (816 and 450 here), beyond that the unfused GEMM + row-softmax path (1030,
+    2048) — both against a fp32 reference; ragged lengths exercise the row / tile tails."""
     Hd = nH * hd
     qkv = rnd(B, S, 3 * Hd, seed=121).to(BF)
     do = rnd(B, S, Hd, seed=122).to(BF)
@@ -759,6 +760,31 @@ def test_long_seq_attention(B, S, nH, hd):
     # masked keys receive exactly zero probability mass: their V gradient is zero
     dv = qg.grad.view(B, S, 3, nH, hd)[0, S - 37:, 2]
     assert dv.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('S', [816, 600, 896])
+def test_split_seq_attention_dropout_equals_unfused_path(S):
+    """The two-part fused kernels with attention-probability dropout: the mask is a hash of (seed, query row, GLOBAL key
+    index), so for one seed the fused result must equal the unfused GEMM + row-softmax path's (which materialises the same
+    mask) — forward and the q / k / v gradients, with a key mask."""
+    from clover_amd.ops import _Attention, _LongSeqAttention
+    B, nH, hd, pdrop = 2, 4, 64, 0.2
+    Hd = nH * hd
+    seed = torch.tensor([1234567], device=DEV, dtype=torch.int64)
+    qkv = rnd(B, S, 3 * Hd, seed=141).to(BF)
+    do = rnd(B, S, Hd, seed=142).to(BF).to(DEV)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, S - 50:] = 0
+    km = om.extended_mask(mask).reshape(B, S).to(DEV).contiguous()
+    q1 = qkv.to(DEV).requires_grad_()
+    o1 = _LongSeqAttention.apply(q1, km, nH, pdrop, seed)
+    o1.backward(do)
+    q2 = qkv.to(DEV).requires_grad_()
+    kw = dict(mode=0, groups=B, N=S, nH=nH, hd=hd, scale=hd ** -0.5, dropout_p=pdrop)
+    o2 = _Attention.apply(q2, None, None, km, kw, seed)
+    o2.backward(do)
+    assert rel(o2, o1) < 2e-2, rel(o2, o1)
+    assert rel(q2.grad, q1.grad) < 3e-2, rel(q2.grad, q1.grad)
 
 
 def test_long_seq_attention_dropout():
