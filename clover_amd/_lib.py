@@ -111,6 +111,7 @@ SIGNATURES = {
     'clv_pack_bf16': (C.c_int, [_p, _p, _i64, _p]),
     'clv_sumsq_bf16': (C.c_int, [_p, _p, _i64, _p]),
     'clv_adamw_step_dev_bf16g': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
+    'clv_sgemm_strided': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _p]),
     'clv_sgemm_nt': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _p]),
     'clv_attn_f32_fwd': (C.c_int, [_p] * 7 + [C.POINTER(ClvAttnGeom), _i32, _p]),
 }

@@ -962,8 +962,9 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
         G.pt16 = tiles * 16;
         G.lddq = g->ldq; G.lddk = g->ldk; G.lddv = g->ldv;
         G.o_ps = G.lse_ps = G.dq_ps = G.dk_ps = G.dv_ps = 0;
-        if (g->mode == 0 && tiles > SEQ_ONE_PART_TILES) {   // K / V (Q / dO) of one (sample, head) exceed the LDS: two parts
-            if (tiles > 2 * SEQ_ONE_PART_TILES) return false;
+        // K / V (Q / dO) of one (sample, head) exceed the LDS: two parts (beyond two parts' reach the bf16 launchers find
+        // no instantiation and report CLV_ERR_UNSUPPORTED; the fp32 parity kernel stages nothing and takes any length)
+        if (g->mode == 0 && tiles > SEQ_ONE_PART_TILES && tiles <= 2 * SEQ_ONE_PART_TILES) {
             G.nparts = 2;
             G.pt16 = (tiles + 1) / 2 * 16;
             G.tsplit = 2;                                   // looped tiles per workgroup set: <= 64 (see launch checks)

@@ -38,7 +38,9 @@ class LinearFP32(nn.Linear):
     O(B*D^2) and cost nothing (the reference forces fp32 here too, contrastive_loss.py:102)."""
 
     def forward(self, x):
-        return F.linear(x.float(), self.weight, self.bias)
+        if x.is_cuda:
+            return ops.linear_f32(x, self.weight, self.bias)         # exact-f32 MFMA kernel, gradients into the slabs
+        return F.linear(x.float(), self.weight, self.bias)           # CPU: host-side unit tests of the module graph only
 
 
 class LayerNorm(nn.LayerNorm):

@@ -436,6 +436,68 @@ def linear_dgrad(dy2, wb, weight=None, pre=None):
     return dx
 
 
+# --------------------------------------------------------------------------- fp32 Linear of the projection heads
+def _sgemm_strided(A, sa, B, sb, bias, Cout, M, N, K, accumulate):
+    check(_lib.lib().clv_sgemm_strided(_ptr(A), _ptr(B), _ptr(bias), _ptr(Cout), M, N, K, sa[0], sa[1], sb[0], sb[1],
+                                       Cout.stride(0) if Cout.dim() == 2 else 1, int(accumulate), _stream()),
+          'clv_sgemm_strided')
+
+
+class _LinearF32(torch.autograd.Function):
+    """y = x W^T + b in fp32 storage and exact-f32 MFMA arithmetic (clv_sgemm_strided) for the [batch, D]-sized projection
+    heads: the contrastive logits are cosines / 0.05, so these few-row GEMMs stay fp32 (the reference forces fp32 there too,
+    contrastive_loss.py:102).  Forward, input gradient and weight / bias gradient are the same kernel with different
+    strides; engine-managed parameters receive their gradients straight in the fp32 slab (accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight)
+        K = weight.shape[1]
+        x2 = _c(x.float().reshape(-1, K))
+        w = _c(weight.detach().float())
+        M, N = x2.shape[0], w.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        bf = _c(bias.detach().float()) if bias is not None else None
+        _sgemm_strided(x2, (K, 1), w, (K, 1), bf, y, M, N, K, False)
+        ctx.save_for_backward(x2, w)
+        ctx.refs = (weight, bias)
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        weight, bias = ctx.refs
+        N, K = w.shape
+        dy2 = _c(dy.float().reshape(-1, N))
+        M = dy2.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy2.device, dtype=torch.float32)
+            _sgemm_strided(dy2, (N, 1), w, (1, K), None, dx, M, K, N, False)          # dx[m][k] = sum_n dy[m][n] W[n][k]
+            dx = dx.view(ctx.xshape)
+        wsink = getattr(weight, '_clv_grad', None)
+        bsink = getattr(bias, '_clv_grad', None) if bias is not None else None
+        sink = wsink is not None and wsink.dtype == torch.float32 and (bias is None or bsink is not None)
+        dw = wsink if sink else torch.empty(N, K, device=dy2.device, dtype=torch.float32)
+        _sgemm_strided(dy2, (1, N), x2, (1, K), None, dw, N, K, M, sink)              # dW[n][k] (+)= sum_m dy[m][n] x[m][k]
+        db = None
+        if bias is not None:
+            db = bsink if sink else torch.empty(N, device=dy2.device, dtype=torch.float32)
+            ones = torch.ones(M, device=dy2.device, dtype=torch.float32)
+            _sgemm_strided(dy2, (1, N), ones, (0, 1), None, db.view(N, 1), N, 1, M, sink)   # db[n] (+)= sum_m dy[m][n]
+        if sink:
+            weight._clv_ready()
+            if bias is not None:
+                bias._clv_ready()
+            return dx, None, None
+        return dx, dw.to(weight.dtype), (db.to(bias.dtype) if db is not None else None)
+
+
+def linear_f32(x, weight, bias=None):
+    return _LinearF32.apply(x, weight, bias)
+
+
 def _sink_or_return(param, grad):
     """Accumulate `grad` into an engine-managed parameter's flat-slab view (returns None), or hand it
     back to autograd."""

@@ -407,6 +407,12 @@ int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shado
  *   by the error-isolation runs recorded in DESIGN.md). */
 int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
                  int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+/* fp32 GEMM with general strides — the [batch, D]-sized projection heads of the contrastive losses (ssl_head.py:24-35,
+ * 158-166,240-245; the reference forces fp32 there, contrastive_loss.py:102), on the training path too:
+ * C[i][j] (ldc) (+)= sum_k A[i*sai + k*sak] * B[j*sbj + k*sbk] (+ bias[j]);  accumulate != 0: added into C (the fp32 gradient
+ * slab).  Forward x W^T, input gradient dy W and weight gradient dy^T x are this one kernel with different strides. */
+int clv_sgemm_strided(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
+                      int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc, int32_t accumulate, void* stream);
 int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias, const int32_t* rid,
                      const float* kmask, const ClvAttnGeom* geom, int32_t round_p, void* stream);
 

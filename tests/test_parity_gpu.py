@@ -55,6 +55,39 @@ def test_sgemm_nt_strided_rows():
     assert rel(c, a.double() @ b.double().t()) < 2e-6
 
 
+@pytest.mark.parametrize('M,N,K,bias', [(16, 1536, 768, True), (8, 768, 1536, True), (3, 130, 70, False), (40, 768, 768, True)])
+def test_linear_f32_heads(M, N, K, bias):
+    """ops.linear_f32 (clv_sgemm_strided: the fp32 Linear of the contrastive projection heads, on the TRAINING path):
+    forward, input gradient, weight / bias gradient against fp64 torch — returned to autograd and accumulated into
+    engine-style fp32 sinks."""
+    from clover_amd import ops
+    x, w = rnd(M, K, seed=51), rnd(N, K, seed=52) * 0.05
+    b = rnd(N, seed=53) if bias else None
+    dy = rnd(M, N, seed=54)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.double())
+    xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bg = b.to(DEV).requires_grad_() if bias else None
+    y = ops.linear_f32(xg, wg, bg)
+    y.backward(dy.to(DEV))
+    assert y.dtype == torch.float32 and rel(y, yr) < 1e-5
+    assert rel(xg.grad, xr.grad) < 1e-5 and rel(wg.grad, wr.grad) < 1e-5
+    if bias:
+        assert rel(bg.grad, br.grad) < 1e-5
+    # sinks: the gradients are ADDED into pre-filled fp32 buffers and nothing is returned to autograd
+    w2, b2 = w.to(DEV).requires_grad_(), (b.to(DEV).requires_grad_() if bias else None)
+    w0, b0 = rnd(N, K, seed=55).to(DEV), rnd(N, seed=56).to(DEV)
+    w2._clv_grad, w2._clv_ready = w0.clone(), (lambda: None)
+    if bias:
+        b2._clv_grad, b2._clv_ready = b0.clone(), (lambda: None)
+    ops.linear_f32(x.to(DEV).requires_grad_(), w2, b2).backward(dy.to(DEV))
+    assert w2.grad is None and rel(w2._clv_grad, w0.double().cpu() + wr.grad) < 1e-5
+    if bias:
+        assert rel(b2._clv_grad, b0.double().cpu() + br.grad) < 1e-5
+
+
 WIN_CASES = [
     (2, 4, 14, 14, 96, 3, False), (2, 4, 14, 14, 96, 3, True), (1, 2, 14, 14, 48, 3, True), (2, 4, 7, 7, 64, 2, True),
     (1, 16, 14, 14, 64, 2, True), (1, 4, 14, 14, 128, 2, True),
