@@ -105,7 +105,8 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(so, name), name
     assert _lib.lib().clv_abi_version() == _lib.ABI_VERSION
-    assert ctypes.sizeof(_lib.ClvAttnGeom) == 23 * 4 + 4 + 8  # 21 int32 + scale + dropout_p, padding, dbias_index pointer
+    assert ctypes.sizeof(_lib.ClvAttnGeom) == 23 * 4 + 4 + 8 + 8  # 21 int32 + scale + dropout_p, padding, dbias_index + work pointers
+    assert ctypes.sizeof(_lib.ClvLnExtra) == 80                   # ... + q8 / qscale pointers (round 3)
 
 
 def test_no_cpu_fallback_and_no_oracle_in_product():
