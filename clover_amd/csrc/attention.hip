@@ -43,6 +43,7 @@ struct Geom {
     // the dK / dV kernel — are split into nparts contiguous parts of pt16 tokens, one workgroup set per part; each set
     // writes its partial result (o + lse per key part, dq per key part, dk / dv per query part) to the caller's scratch
     // and a combine kernel merges them (seq_combine_*).  nparts = 1: everything below degenerates to the plain kernels.
+    int grp0;                            // first group of this launch (the table-gradient path runs the dQ kernel in chunks)
     int nparts, pt16;
     int lddq, lddk, lddv;                // row strides of the dq / dk / dv OUTPUTS (= ldq / ldk / ldv unless partial)
     int64_t o_ps, lse_ps, dq_ps, dk_ps, dv_ps;   // element strides between the parts' partial outputs (0: one part)
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int part = bid % G.tsplit;                          // tsplit workgroups share one (group, head): tile subsets
     const int sp = (bid / G.tsplit) % G.nparts, gh = bid / (G.tsplit * G.nparts);     // see attn_fwd_kernel
-    const int grp = gh / G.g.nH, h = gh - grp * G.g.nH;
+    const int grp = gh / G.g.nH + G.grp0, h = gh % G.g.nH;    // grp0: this launch covers groups [grp0, grp0 + gridDim / ..)
     const int N = G.g.N;
     const int s0 = sp * G.pt16, Ns = min(N - s0, G.pt16);     // staged keys [s0, s0 + Ns)
     const bool tb = MODE == 1 && bias != nullptr;
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : 1)) attn_bwd
         // dS scratch in MFMA-fragment order [group][head][q tile][key tile][lane][4]: every store instruction of a
         // wave is one contiguous 512-B run (row-major rows would be 32-B pieces of 128-B lines)
         bf16_t* dsfrag = (tb && ds_out)
-            ? ds_out + ((((int64_t)grp * G.g.nH + h) * nqt + qt) * NKT * 64 + lane) * 4 : nullptr;
+            ? ds_out + ((((int64_t)(grp - G.grp0) * G.g.nH + h) * nqt + qt) * NKT * 64 + lane) * 4 : nullptr;
 
         Frag8 dsf[(NKT + 1) / 2];
         if (NKT & 1) dsf[NKT / 2].u[2] = dsf[NKT / 2].u[3] = 0u;   // the missing second half of an odd tile count
@@ -959,6 +960,7 @@ bool make_geom(const ClvAttnGeom* g, Geom& G) {
         G.tsplit = 1;
         while (G.tsplit < 4 && pairs * G.tsplit < 384 && tiles >= 8 * G.tsplit) G.tsplit *= 2;
         G.nparts = 1;
+        G.grp0 = 0;
         G.pt16 = tiles * 16;
         G.lddq = g->ldq; G.lddk = g->ldk; G.lddv = g->ldv;
         G.o_ps = G.lse_ps = G.dq_ps = G.dk_ps = G.dv_ps = 0;
@@ -1109,7 +1111,39 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         dk_out = dq_out + tc;
         dv_out = dq_out + 2 * tc;
     }
-    if (stages & 1) {
+    const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
+    float* partial = bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT)) : nullptr;
+    // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
+    // bf16 scratch itself once a slice covers only 4 groups
+    int splits = G.g.groups / 16;
+    splits = splits < 1 ? 1 : (splits > DBIAS_SPLITS ? DBIAS_SPLITS : splits);
+    // The dS scratch of a stage-0 block is 266 MB at 16 clips: written by the dQ kernel, read once by the streaming sum —
+    // a 0.5 GB HBM round trip per block that exists only to feed the table gradient.  Run the pair in CHUNKS of groups that
+    // reuse one scratch region small enough for the Infinity Cache (256 MB): the sum then reads what the dQ kernel just
+    // wrote from the cache, and the next chunk overwrites the same lines before they are ever written back.
+    static const int chunk_mb = getenv("CLV_DBIAS_CHUNK_MB") ? atoi(getenv("CLV_DBIAS_CHUNK_MB")) : 128;      // same-box A/B: 12.52 -> 12.46 ms per step
+    int nch = 1;
+    if (bias && stages == 7 && chunk_mb > 0 && G.nparts == 1) {
+        const int64_t per_group = E * 2;                       // scratch bytes per group
+        while (nch < 8 && (G.g.groups / nch) * per_group > (int64_t)chunk_mb << 20 && G.g.groups % (2 * nch) == 0 &&
+               splits % (2 * nch) == 0)
+            nch *= 2;
+    }
+    if (nch > 1) {
+        const int cg = G.g.groups / nch, spc = splits / nch;
+        for (int cix = 0; cix < nch; ++cix) {
+            Geom Cg = G;
+            Cg.grp0 = cix * cg;
+            const int nb = cg * G.g.nH * G.tsplit;
+            CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nb), dim3(DKV_THREADS(NKT)), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, dq_out,
+                     (bf16_t*)work, dsum, seed, Cg));
+            hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), spc), dim3(256), 0, st,
+                               (const bf16_t*)work, reinterpret_cast<float4*>(partial + (int64_t)cix * spc * E * 4), cg, E / 2);
+        }
+        rc = clv_check_launch();
+        if (rc) return rc;
+    } else if (stages & 1) {
         CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nblk), dim3(DKV_THREADS(NKT)), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
                  (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, dq_out,
                  (bf16_t*)(bias ? work : nullptr), dsum, seed, G));
@@ -1117,15 +1151,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         if (rc) return rc;
     }
     if (bias && (stages & 2)) {
-        const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
-        float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT));
-        // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
-        // bf16 scratch itself once a slice covers only 4 groups
-        int splits = G.g.groups / 16;
-        splits = splits < 1 ? 1 : (splits > DBIAS_SPLITS ? DBIAS_SPLITS : splits);
         float* dense = partial + (int64_t)splits * E * 4;
-        hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
-                           (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
+        if (nch == 1)
+            hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
+                               (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
         (void)dense;
         if (G.g.dbias_index) {
             hipLaunchKernelGGL(dbias_gather_tab_kernel, dim3((G.tbn * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias,
