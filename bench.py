@@ -338,18 +338,42 @@ def main():
         }
         if prof:
             res['roofline'], res['kernels'] = ops.roofline_from_prof(prof, prof_steps)
-            # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes (tools/pmc_traffic.sh; counters
-            # cannot be read from inside the process), null when no measurement of this kernel is committed
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
-            if os.path.exists(pmc):
-                rec = json.load(open(pmc)).get(res['roofline']['kernel'])
-                res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
-            # fraction of the dense bf16 MFMA peak the same kernel sustains, from the SQ / GRBM counter pass
-            # (tools/pmc_mfma.sh -> profiles/r02_pmc_mfma.json); null when not measured
-            mf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_mfma.json')
-            if os.path.exists(mf):
-                rec = json.load(open(mf)).get(res['roofline']['kernel'])
-                res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
+            # Counter-derived fields cannot be read from inside the process: they come from the committed rocprofv3 passes of
+            # THIS command (tools/pmc_traffic.sh, tools/pmc_mfma.sh, tools/gpu_round.sh), each file carrying the commit it
+            # was taken at; the *_source fields say which file and commit, so a reader can tell a fresh counter from a stale one.
+            prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+            kname = res['roofline']['kernel']
+
+            def committed(fname):
+                path = os.path.join(prof_dir, fname)
+                if not os.path.exists(path):
+                    return None, None
+                d = json.load(open(path))
+                return d.get(kname), f"profiles/{fname}@{(d.get('_meta') or {}).get('commit', 'unknown')}"
+            rec, src = committed('r03_pmc_traffic.json')
+            res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
+            res['roofline']['traffic_source'] = src if rec else None
+            rec, src = committed('r03_pmc_mfma.json')
+            res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
+            res['roofline']['mfma_util_source'] = src if rec else None
+            # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
+            # (device-side, no event / dispatch overhead) and the roofline fraction it gives
+            stats = os.path.join(prof_dir, 'r03_kernel_stats_bench_default_final.csv')
+            if os.path.exists(stats):
+                import csv
+                meta = os.path.join(prof_dir, 'r03_kernel_stats_bench_default_final.meta.json')
+                sha = json.load(open(meta)).get('commit', 'unknown') if os.path.exists(meta) else 'unknown'
+                for row in csv.DictReader(open(stats)):
+                    nm = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+                    if nm.startswith(kname):
+                        us = float(row['AverageNs']) / 1e3
+                        res['roofline']['avg_us_rocprof'] = round(us, 2)
+                        per = res['roofline']['algorithmic_bytes_per_launch' if res['roofline']['bound'] == 'hbm'
+                                              else 'algorithmic_flops_per_launch']
+                        peak = 8.0e12 if res['roofline']['bound'] == 'hbm' else 2.5e15
+                        res['roofline']['frac_rocprof'] = round(per / (us * 1e-6) / peak, 4)
+                        res['roofline']['rocprof_source'] = f'profiles/r03_kernel_stats_bench_default_final.csv@{sha}'
+                        break
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
             ref = res['cpu_baseline'].pop('losses', None)
