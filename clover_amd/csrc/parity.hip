@@ -85,28 +85,43 @@ __global__ void __launch_bounds__(256) sgemm_tiled_kernel(const float* __restric
 // rows): C[i][j] (ldc) (+)= sum_k A(i,k) B(j,k) (+ bias[j]),  A(i,k) = A[i*sai + k*sak],  B(j,k) = B[j*sbj + k*sbk] — one
 // wave per 16 x 16 tile on the exact-f32 MFMA, so that forward (x W^T), input gradient (dy W) and weight gradient
 // (dy^T x, accumulated into the fp32 gradient slab) of such a layer are the SAME kernel with different strides.
-__global__ void __launch_bounds__(64) sgemm_strided_kernel(const float* __restrict__ A, const float* __restrict__ B,
+constexpr int SS_WAVES = 4;
+__global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ bias, float* __restrict__ C, int M,
                                                            int N, int K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk,
                                                            int64_t ldc, int accumulate) {
-    const int lane = threadIdx.x, lg = lane >> 4, lr = lane & 15;
+    // 4 waves share one 16 x 16 output tile and split the contraction (these layers have 8-64 rows: a tile per wave left
+    // under a hundred waves walking K = 768..1536 alone: 29 us per launch); partial tiles meet in LDS
+    __shared__ float red[SS_WAVES - 1][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     const int i = blockIdx.y * 16 + lr, j = blockIdx.x * 16 + lr;
     const bool av = i < M, bv = j < N;
     const float* ap = A + (int64_t)(av ? i : 0) * sai;
     const float* bp = B + (int64_t)(bv ? j : 0) * sbj;
+    const int kchunk = ((K + SS_WAVES * 16 - 1) / (SS_WAVES * 16)) * 16;     // per wave, a multiple of 16
+    const int kb = wave * kchunk, ke = min(K, kb + kchunk);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        float a[4], b[4];
+    for (int k0 = kb; k0 < ke; k0 += 32) {                    // two 16-deep blocks per trip: 16 loads in flight
+        float a[8], b[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + e * 4 + lg;                    // k-step e of this 16-deep block: lane group lg holds k = 4e + lg
-            a[e] = (av && k < K) ? ap[k * sak] : 0.f;
-            b[e] = (bv && k < K) ? bp[k * sbk] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e * 4 + lg;                    // k-step e: lane group lg holds k = k0 + 4e + lg
+            a[e] = (av && k < ke) ? ap[k * sak] : 0.f;
+            b[e] = (bv && k < ke) ? bp[k * sbk] : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
     }
-    if (j < N) {
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && j < N) {
+#pragma unroll
+        for (int w = 0; w < SS_WAVES - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
         const float bb = bias ? bias[j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -127,7 +142,7 @@ extern "C" int clv_sgemm_strided(const float* A, const float* B, const float* bi
     if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || ldc < N) return CLV_ERR_ARG;
     if (M == 0) return CLV_OK;
     if (M > 0x7fffffff) return CLV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sgemm_strided_kernel, dim3((N + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(sgemm_strided_kernel, dim3((N + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64 * SS_WAVES), 0, (hipStream_t)stream,
                        A, B, bias, C, (int)M, N, K, sai, sak, sbj, sbk, ldc, accumulate);
     return clv_check_launch();
 }
