@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(256) sgemm_tiled_kernel(const float* __restric
 // rows): C[i][j] (ldc) (+)= sum_k A(i,k) B(j,k) (+ bias[j]),  A(i,k) = A[i*sai + k*sak],  B(j,k) = B[j*sbj + k*sbk] — one
 // wave per 16 x 16 tile on the exact-f32 MFMA, so that forward (x W^T), input gradient (dy W) and weight gradient
 // (dy^T x, accumulated into the fp32 gradient slab) of such a layer are the SAME kernel with different strides.
-constexpr int SS_WAVES = 4;
+constexpr int SS_WAVES = 8;
 __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ bias, float* __restrict__ C, int M,
                                                            int N, int K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk,
                                                            int64_t ldc, int accumulate) {
-    // 4 waves share one 16 x 16 output tile and split the contraction (these layers have 8-64 rows: a tile per wave left
+    // 8 waves share one 16 x 16 output tile and split the contraction (these layers have 8-64 rows: a tile per wave left
     // under a hundred waves walking K = 768..1536 alone: 29 us per launch); partial tiles meet in LDS
     __shared__ float red[SS_WAVES - 1][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
