@@ -75,6 +75,7 @@ SIGNATURES = {
     'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
     'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),
+    'clv_patch_embed_fwd_fp8': (C.c_int, [_p] * 13 + [_i32] * 7 + [_f, _p]),
     'clv_patch_embed_blend_bwd': (C.c_int, [_p] * 5 + [_i32] * 7 + [_p]),
     'clv_im2col_patches': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     'clv_linear_wgrad_work_floats': (C.c_int64, [_i64, _i32, _i32]),

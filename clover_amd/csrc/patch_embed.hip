@@ -52,22 +52,55 @@ __device__ __forceinline__ Frag8 patch_frag(const float* __restrict__ x, const P
     return f;
 }
 
-template <int C>
+// fp8 variant (BASELINE config 5, "fp8 MFMA ... patch-proj path"): the same 8 k-values per lane, kept in fp32 until the
+// token's 96 patch values are all in hand (its row maximum sits in the 4 lane groups x 3 channel steps of lane lr), then
+// scaled by 448 / max and converted to OCP e4m3; the product runs on v_mfma_f32_16x16x32_fp8_fp8 (same lane -> k map as
+// the bf16 instruction, 8 bytes per lane) and is rescaled by row scale x per-output-channel weight scale afterwards.
+__device__ __forceinline__ void patch_frag_f32(const float* __restrict__ x, const PEShape& S, int64_t m, bool valid, int c,
+                                               int g, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (!valid) return;
+    int b, tp, hp, wp;
+    tok_coords(S, m, b, tp, hp, wp);
+    const int t = 2 * tp + (g >> 1), y = 4 * hp + 2 * (g & 1);
+    const float* p = x + ((((int64_t)b * 3 + c) * S.T + t) * S.H + y) * S.W + 4 * wp;
+    const float4 r0 = *reinterpret_cast<const float4*>(p);
+    const float4 r1 = *reinterpret_cast<const float4*>(p + S.W);
+    v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w; v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
+}
+__device__ __forceinline__ long pack8_fp8(const float (&v)[8], float inv) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int C, bool FP8 = false>
 __global__ void __launch_bounds__(PE_THREADS) patch_embed_fwd_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask_token,
     const int64_t* __restrict__ vmask, bf16_t* __restrict__ out_clean, bf16_t* __restrict__ out_masked,
-    bf16_t* __restrict__ z_out, float* __restrict__ mean, float* __restrict__ rstd, PEShape S, float eps) {
+    bf16_t* __restrict__ z_out, float* __restrict__ mean, float* __restrict__ rstd, PEShape S, float eps,
+    const unsigned char* __restrict__ w8 = nullptr, const float* __restrict__ wscale = nullptr) {
     constexpr int NT = C / 16, LDO = C + 8;
     __shared__ __attribute__((aligned(16))) bf16_t tile[PE_WAVES][3][16 * LDO];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lg = lane >> 4, lr = lane & 15;
     // weight fragments: B[k = s*32 + lg*8 + j][n = nt*16 + lr] = W[n][k]
     Frag8 wf[3][NT];
+    long wf8[3][NT];
+    float ws[NT];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            wf[s][nt].u4 = *reinterpret_cast<const uint4*>(w + (nt * 16 + lr) * 96 + s * 32 + lg * 8);
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (FP8) wf8[s][nt] = *reinterpret_cast<const long*>(w8 + (nt * 16 + lr) * 96 + s * 32 + lg * 8);
+            else wf[s][nt].u4 = *reinterpret_cast<const uint4*>(w + (nt * 16 + lr) * 96 + s * 32 + lg * 8);
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ws[nt] = FP8 ? wscale[nt * 16 + lr] : 1.f;
     float bi[NT], ga[NT], be[NT], mt[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -84,11 +117,37 @@ __global__ void __launch_bounds__(PE_THREADS) patch_embed_fwd_kernel(
         f32x4_t acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (FP8) {
+            float pv[3][8], amax = 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const Frag8 a = patch_frag(x, S, m0 + lr, m0 + lr < S.M, s, lg);
+            for (int s = 0; s < 3; ++s) {
+                patch_frag_f32(x, S, m0 + lr, m0 + lr < S.M, s, lg, pv[s]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a, wf[s][nt], acc[nt]);
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(pv[s][e]));
+            }
+            amax = grp4_max(amax);                               // the token's 96 values: 4 lane groups x 3 steps
+            const float inv = amax > 0.f ? 448.0f / amax : 1.0f, rsc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const long a8 = pack8_fp8(pv[s], inv);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, wf8[s][nt], acc[nt], 0, 0, 0);
+            }
+            // acc[nt][r] belongs to token m0 + lg*4 + r: its row scale lives in the lanes with lr = lg*4 + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sr = __shfl(rsc, lg * 4 + r, 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][r] *= sr * ws[nt];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const Frag8 a = patch_frag(x, S, m0 + lr, m0 + lr < S.M, s, lg);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a, wf[s][nt], acc[nt]);
+            }
         }
         // acc[nt][r] = z[token m0 + lg*4 + r][n = nt*16 + lr]  (before bias)
 #pragma unroll
@@ -259,6 +318,34 @@ extern "C" int clv_patch_embed_fwd(const float* x, const void* w, const float* b
         default: return CLV_ERR_UNSUPPORTED;
     }
 #undef PE_LAUNCH
+    return clv_check_launch();
+}
+
+extern "C" int clv_patch_embed_fwd_fp8(const float* x, const void* w8, const float* wscale, const float* bias,
+                                       const float* gamma, const float* beta, const float* mask_token,
+                                       const int64_t* vmask, void* out_clean, void* out_masked, void* z_out, float* mean,
+                                       float* rstd, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t mh,
+                                       int32_t mw, float eps, void* stream) {
+    PEShape S;
+    if (!x || !w8 || !wscale || !bias || (!out_clean && !out_masked)) return CLV_ERR_ARG;
+    if ((gamma == nullptr) != (beta == nullptr)) return CLV_ERR_ARG;
+    if (out_masked && (!vmask || !mask_token)) return CLV_ERR_ARG;
+    if (!make_shape(S, B, T, H, W, out_masked ? mh : 1, out_masked ? mw : 1)) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t ntiles = (S.M + 15) / 16;
+    int grid = (int)((ntiles + PE_WAVES - 1) / PE_WAVES);
+    if (grid > 1024) grid = 1024;
+#define PE_LAUNCH8(CV)                                                                                              \
+    hipLaunchKernelGGL((patch_embed_fwd_kernel<CV, true>), dim3(grid), dim3(PE_THREADS), 0, st, x, (const bf16_t*)nullptr, \
+                       bias, gamma, beta, mask_token, vmask, (bf16_t*)out_clean, (bf16_t*)out_masked,              \
+                       (bf16_t*)z_out, mean, rstd, S, eps, (const unsigned char*)w8, wscale)
+    switch (C) {
+        case 48: PE_LAUNCH8(48); break;
+        case 96: PE_LAUNCH8(96); break;
+        case 128: PE_LAUNCH8(128); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef PE_LAUNCH8
     return clv_check_launch();
 }
 

@@ -1514,9 +1514,16 @@ class _PatchEmbed(torch.autograd.Function):
         mean = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
         rstd = torch.empty(M, device=dev, dtype=torch.float32) if need_grad else None
         mh, mw = (vm.shape[1], vm.shape[2]) if want_masked else (1, 1)
-        check(_lib.lib().clv_patch_embed_fwd(_ptr(xc), _ptr(w2), _ptr(bf), _ptr(gf), _ptr(bef), _ptr(mt), _ptr(vm),
-                                             _ptr(clean), _ptr(masked), _ptr(z), _ptr(mean), _ptr(rstd), B, T, H, W,
-                                             Cout, mh, mw, float(eps), _stream()), 'clv_patch_embed_fwd')
+        if FP8:                                  # BASELINE config 5: the patch projection on the fp8 matrix instruction
+            w8, wsc = quant_fp8_rows(w2)
+            check(_lib.lib().clv_patch_embed_fwd_fp8(_ptr(xc), _ptr(w8), _ptr(wsc), _ptr(bf), _ptr(gf), _ptr(bef), _ptr(mt),
+                                                     _ptr(vm), _ptr(clean), _ptr(masked), _ptr(z), _ptr(mean), _ptr(rstd),
+                                                     B, T, H, W, Cout, mh, mw, float(eps), _stream()),
+                  'clv_patch_embed_fwd_fp8')
+        else:
+            check(_lib.lib().clv_patch_embed_fwd(_ptr(xc), _ptr(w2), _ptr(bf), _ptr(gf), _ptr(bef), _ptr(mt), _ptr(vm),
+                                                 _ptr(clean), _ptr(masked), _ptr(z), _ptr(mean), _ptr(rstd), B, T, H, W,
+                                                 Cout, mh, mw, float(eps), _stream()), 'clv_patch_embed_fwd')
         ctx.save_for_backward(xc, z, mean, rstd, gf, vm)
         ctx.prefs = (weight, bias, gamma, beta, mask_token)
         ctx.meta = (B, T, H, W, Cout, want_clean, want_masked, weight.shape,

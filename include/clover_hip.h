@@ -428,6 +428,14 @@ int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, c
  *   q bytes [rows][K] (ldq); K % 8 == 0, K <= 4096.
  * clv_gemm_nt_fp8: c[M][N] bf16 = (a8[M][K] . b8[N][K]^T) * sa[m] * sb[n] (+ bias; CLV_GEMM_EPI_NONE / _BIAS / _BIAS_GELU_D
  *   with c2 = GELU'(pre) as clv_gemm_nt); K % 128 == 0, lda / ldb in bytes and % 16 == 0. */
+/* clv_patch_embed_fwd with the projection on the fp8 matrix instruction: w8 [C][96] e4m3 bytes + wscale [C] (the conv
+ * weight through clv_quant_fp8_rows); each token's 96 patch values are scaled by 448 / their maximum and converted to
+ * e4m3 inside the kernel.  Everything else (bias, LayerNorm, blend, outputs, saved tensors) as clv_patch_embed_fwd; the
+ * backward is the bf16 one. */
+int clv_patch_embed_fwd_fp8(const float* x, const void* w8, const float* wscale, const float* bias, const float* gamma,
+                            const float* beta, const float* mask_token, const int64_t* vmask, void* out_clean,
+                            void* out_masked, void* z_out, float* mean, float* rstd, int32_t B, int32_t T, int32_t H,
+                            int32_t W, int32_t C, int32_t mh, int32_t mw, float eps, void* stream);
 int clv_quant_fp8_rows(const void* x, void* q, float* scale, int64_t rows, int32_t K, int64_t ldx, int64_t ldq,
                        void* stream);
 int clv_gemm_nt_fp8_supported(int64_t M, int32_t N, int32_t K);
