@@ -129,8 +129,12 @@ def roofline_from_prof(prof, steps):
     roof['launches_per_step'] = round(top['launches_per_step'], 2)
     roof['algorithmic_bytes_per_launch'] = int(top['bytes'] / n)
     roof['algorithmic_flops_per_launch'] = int(top['flops'] / n)
+    def frac_of(r):       # the same roofline arithmetic for every instrumented kernel: which roof bounds it, what fraction it reaches
+        hb, mf = r['bytes'] / 8.0e12, r['flops'] / 2.5e15
+        return ('hbm', round(r['bytes'] / r['secs'] / 8.0e12, 4)) if hb >= mf else ('mfma', round(r['flops'] / r['secs'] / 2.5e15, 4))
     table = [dict(kernel=r['kernel'], launches_per_step=round(r['launches_per_step'], 2),
-                  avg_us=round(r['avg_us'], 2), ms_per_step=round(r['total_ms_per_step'], 3)) for r in rows[:12]]
+                  avg_us=round(r['avg_us'], 2), ms_per_step=round(r['total_ms_per_step'], 3),
+                  bound=frac_of(r)[0], frac=frac_of(r)[1]) for r in rows[:14]]
     return roof, table
 
 
@@ -408,7 +412,7 @@ def gemm_nt_fp8(a, b, bias=None, epilogue=None, aq8=None):
         check(_lib.lib().clv_gemm_nt_fp8(*args), 'clv_gemm_nt_fp8')
     else:
         nout = 2 if c2 is not None else 1
-        with _Timed(f'gemm_nt_kernel<fp8, {int(epilogue)}>', 2 * M * N * K, M * K + N * K + nout * M * N * 2):
+        with _Timed(_gemm_kname(M, N, K // 2, int(epilogue), True), 2 * M * N * K, M * K + N * K + nout * M * N * 2):
             check(_lib.lib().clv_gemm_nt_fp8(*args), 'clv_gemm_nt_fp8')
     return (c, c2) if c2 is not None else c
 
@@ -885,6 +889,13 @@ def mlp_gelu(x, w1, b1, w2, b2):
 GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU, GEMM_EPI_BIAS_GELU_D, GEMM_EPI_MUL = 0, 1, 2, 3, 4, 5
 
 
+def _gemm_kname(M, N, K, epi, fp8):
+    """Device-kernel name as rocprofv3 prints it (gemm_nt.hip: tile class by tile count, see clv_gemm_nt; K in 2-byte units
+    for the fp8 entry point)."""
+    small = K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) <= 512
+    return f"gemm_nt_kernel<{64 if small else 128}, 128, 2, 2, {3 if small else 2}, {epi}, {'true' if fp8 else 'false'}>"
+
+
 def gemm_nt_supported(M, N, K):
     return bool(_lib.lib().clv_gemm_nt_supported(int(M), int(N), int(K)))
 
@@ -910,7 +921,7 @@ def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
     else:
         nout = 2 if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else 1
         nin = 1 if epilogue in (GEMM_EPI_DGELU, GEMM_EPI_MUL) else 0
-        with _Timed(f'gemm_nt_kernel<128, 128, 2, 2, 2, {int(epilogue)}>', 2 * M * N * K,
+        with _Timed(_gemm_kname(M, N, K, int(epilogue), False), 2 * M * N * K,
                     (M * K + N * K + (nout + nin) * M * N) * 2):
             check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
     return (c, c2) if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else c
