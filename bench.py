@@ -331,6 +331,7 @@ def main():
             'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
             'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
             'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
+            'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             # data-parallel runs: mean per-step stall of the compute stream on the gradient all-reduces (rank 0), and what
             # travels: bf16 gradients in per-class buckets (null at N = 1: no collective is issued)
             'exposed_comm_ms': round(exposed_comm_ms, 3) if exposed_comm_ms is not None else None,
