@@ -374,6 +374,31 @@ def test_adamw_and_clip():
     assert torch.equal(before, pg)
 
 
+def test_bf16_gradient_variants_of_norm_and_adamw():
+    """clv_pack_bf16 + clv_sumsq_bf16 + clv_adamw_step_dev_bf16g (the data-parallel path: gradients travel and are read as
+    bf16, the update stays fp32) against the fp32 kernels fed the SAME bf16-rounded gradient: bit-identical update, and
+    the norm equal to the fp32 kernel's on the rounded values."""
+    n = 1_000_003
+    p0, g = rnd(n, seed=301), rnd(n, seed=302) * 0.01
+    gb = torch.empty(n, dtype=BF, device=DEV)
+    ops().pack_bf16(g.to(DEV), gb)
+    assert torch.equal(gb.cpu(), g.to(BF))
+    gr = gb.float()                                            # what the fp32 kernels see for comparison
+    out = {}
+    for tag, grad in (('f32', gr), ('bf16', gb)):
+        p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sh = torch.zeros(n, device=DEV, dtype=BF)
+        acc, st = torch.zeros(1, device=DEV), ops().optim_state_new(DEV)
+        for _ in range(2):
+            ops().sumsq_accumulate(grad, acc)
+            ops().optim_prep(acc, st, 0.9, 0.98, 15.0, 0.5)
+            ops().adamw_step_dev(p, grad, m, v, sh, st, 1e-3, 0.9, 0.98, 1e-8, 0.005)
+        out[tag] = (p.cpu(), m.cpu(), v.cpu(), sh.cpu(), ops().optim_state_read(st)['norm'])
+    for a, b in zip(out['f32'][:4], out['bf16'][:4]):
+        assert torch.equal(a, b)
+    assert abs(out['f32'][4] - out['bf16'][4]) <= 1e-6 * out['f32'][4]
+
+
 def test_adamw_device_state_two_option_groups_and_skip():
     """clv_optim_prep + clv_adamw_step_dev (the engine's path): two slabs with different (weight_decay, lr) — the
     per-parameter options of a paramwise_cfg — against torch.optim.AdamW param groups with a global-norm clip; a
