@@ -447,6 +447,19 @@ def _sgemm_strided(A, sa, B, sb, bias, Cout, M, N, K, accumulate):
           'clv_sgemm_strided')
 
 
+_ONES = {}
+
+
+def _ones_f32(n, device):
+    """A cached all-ones fp32 vector (the bias gradient of a few-row layer is a GEMM against it): no fill kernel per use."""
+    key = (int(n), str(device))
+    if key not in _ONES:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.ones(n, device=device, dtype=torch.float32)
+        _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ONES[key]
+
+
 class _LinearF32(torch.autograd.Function):
     """y = x W^T + b in fp32 storage and exact-f32 MFMA arithmetic (clv_sgemm_strided) for the [batch, D]-sized projection
     heads: the contrastive logits are cosines / 0.05, so these few-row GEMMs stay fp32 (the reference forces fp32 there too,
@@ -488,7 +501,7 @@ class _LinearF32(torch.autograd.Function):
         db = None
         if bias is not None:
             db = bsink if sink else torch.empty(N, device=dy2.device, dtype=torch.float32)
-            ones = torch.ones(M, device=dy2.device, dtype=torch.float32)
+            ones = _ones_f32(M, dy2.device)
             _sgemm_strided(dy2, (1, N), ones, (0, 1), None, db.view(N, 1), N, 1, M, sink)   # db[n] (+)= sum_m dy[m][n]
         if sink:
             weight._clv_ready()

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 45
 ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows), key=lambda e: e[0])
-adam = [i for i, e in enumerate(ev) if 'adamw_kernel' in e[2] and e[1] - e[0] > 200000]
+adam = [i for i, e in enumerate(ev) if 'adamw' in e[2] and e[1] - e[0] > 200000]
 # the timed graph-replay steps are the most regular run of AdamW-to-AdamW intervals: take the middle of the
 # longest run whose period is within 10 % of the median period
 per = [ev[adam[i + 1]][0] - ev[adam[i]][0] for i in range(len(adam) - 1)]
