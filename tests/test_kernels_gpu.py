@@ -376,7 +376,7 @@ def test_adamw_and_clip():
 
 def test_bf16_gradient_variants_of_norm_and_adamw():
     """clv_pack_bf16 + clv_sumsq_bf16 + clv_adamw_step_dev_bf16g (the data-parallel path: gradients travel and are read as
-    bf16, the update stays fp32) against the fp32 kernels fed the SAME bf16-rounded gradient: bit-identical update, and
+    bf16, the update stays fp32) against the fp32 kernels fed the SAME bf16-rounded gradient: the same update to fp32 round-off, and
     the norm equal to the fp32 kernel's on the rounded values."""
     n = 1_000_003
     p0, g = rnd(n, seed=301), rnd(n, seed=302) * 0.01
@@ -394,8 +394,11 @@ def test_bf16_gradient_variants_of_norm_and_adamw():
             ops().optim_prep(acc, st, 0.9, 0.98, 15.0, 0.5)
             ops().adamw_step_dev(p, grad, m, v, sh, st, 1e-3, 0.9, 0.98, 1e-8, 0.005)
         out[tag] = (p.cpu(), m.cpu(), v.cpu(), sh.cpu(), ops().optim_state_read(st)['norm'])
-    for a, b in zip(out['f32'][:4], out['bf16'][:4]):
-        assert torch.equal(a, b)
+    # same arithmetic on the same values; the clip coefficient comes from an atomically accumulated norm (summation order
+    # differs between launches), so equality holds to fp32 round-off, and exactly for the bf16 shadow except at ties
+    for a, b in zip(out['f32'][:3], out['bf16'][:3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9)
+    assert (out['f32'][3] != out['bf16'][3]).float().mean().item() < 1e-3
     assert abs(out['f32'][4] - out['bf16'][4]) <= 1e-6 * out['f32'][4]
 
 
