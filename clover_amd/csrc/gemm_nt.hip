@@ -47,15 +47,53 @@ __device__ __forceinline__ void gn_wait_vm() {
 // swapped-operand MFMAs leave each lane with 8 CONSECUTIVE output columns per accumulator pair and the 4 lanes of a row
 // with 64 contiguous bytes per store instruction: LDS row j*16 + x of a wave's WN-row block holds global row
 // (j >> 1) * 32 + (x >> 2) * 8 + (j & 1) * 4 + (x & 3) — the per-lane source address makes any row permutation free.
+template <int NPIECE>
+__device__ __forceinline__ void gn_dma_block(unsigned lds, const unsigned (&v)[NPIECE], const bf16_t* base);
+template <>
+__device__ __forceinline__ void gn_dma_block<4>(unsigned lds, const unsigned (&v)[4], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [b] "s"(base)
+        : "memory", "scc");
+}
+template <>
+__device__ __forceinline__ void gn_dma_block<2>(unsigned lds, const unsigned (&v)[2], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [b] "s"(base)
+        : "memory", "scc");
+}
+
+
+// The DMA pieces of a wave go out in the SGPR-base + 32-bit-VGPR-offset form, one asm block per operand and stage (M0 saved /
+// restored once): the per-lane offsets are fixed for a tile, a stage advance is ONE scalar add on the base.  The first version
+// kept a 64-bit per-lane pointer per piece (readfirstlane + two M0 moves + a 64-bit VALU add per piece): the pieces' issue
+// cost — not their latency — paced the few-tile classes (6 pieces per 16 MFMAs and wave at 64 x 128; a ring of 6 changed
+// nothing, tools/probes/gemm_tiles.py).
 template <int ROWS, int WAVES>
 struct GnOper {
     static constexpr int PIECES = ROWS / (8 * WAVES);
-    const bf16_t* src[PIECES];
+    unsigned voff[PIECES];              // bytes from `base`, per lane
+    const bf16_t* base;                 // wave-uniform: first row of the tile, current k offset
 };
 
 template <int ROWS, int WAVES, int PERM_TN>
 __device__ __forceinline__ void gn_init(GnOper<ROWS, WAVES>& o, const bf16_t* base, int64_t row0, int64_t nrows, int64_t ld, int wave,
                                         int lane) {
+    const int64_t r0 = row0 < nrows ? row0 : nrows - 1;       // a tile past the edge (never stored) reads the last row
+    o.base = base + r0 * ld;
 #pragma unroll
     for (int j = 0; j < GnOper<ROWS, WAVES>::PIECES; ++j) {
         const int r = (wave * GnOper<ROWS, WAVES>::PIECES + j) * 8 + (lane >> 3);      // LDS row
@@ -66,21 +104,19 @@ __device__ __forceinline__ void gn_init(GnOper<ROWS, WAVES>& o, const bf16_t* ba
             const int h = r / WN, p = r % WN, jj = p >> 4, x = p & 15;
             g = h * WN + (jj >> 1) * 32 + (x >> 2) * 8 + (jj & 1) * 4 + (x & 3);
         }
-        int64_t gr = row0 + g;
+        int64_t gr = r0 + g;
         gr = gr < nrows ? gr : nrows - 1;
-        o.src[j] = base + gr * ld + c * 8;
+        o.voff[j] = (unsigned)(((gr - r0) * ld + c * 8) * 2);
     }
 }
 
 template <int ROWS, int WAVES>
 __device__ __forceinline__ void gn_issue(GnOper<ROWS, WAVES>& o, unsigned lds_oper_base, int wave) {
-#pragma unroll
-    for (int j = 0; j < GnOper<ROWS, WAVES>::PIECES; ++j) {
 #ifndef GN_ABL_NODMA
-        gn_dma16(o.src[j], __builtin_amdgcn_readfirstlane(lds_oper_base + (unsigned)((wave * GnOper<ROWS, WAVES>::PIECES + j) * 1024)));
+    gn_dma_block<GnOper<ROWS, WAVES>::PIECES>(
+        __builtin_amdgcn_readfirstlane(lds_oper_base + (unsigned)(wave * GnOper<ROWS, WAVES>::PIECES * 1024)), o.voff, o.base);
 #endif
-        o.src[j] += GN_BK;
-    }
+    o.base += GN_BK;
 }
 
 __device__ __forceinline__ Frag8 gn_frag(const unsigned char* oper, int r, int kc) {
@@ -126,7 +162,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                                                                 bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N,
                                                                 int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN,
                                                                 int nmblk, const float* __restrict__ sa = nullptr,
-                                                                const float* __restrict__ sb = nullptr) {
+                                                                const float* __restrict__ sb = nullptr, int pc = 1) {
     constexpr int WAVES = WAVES_M * WAVES_N, GN_THREADS = 64 * WAVES;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
@@ -139,10 +175,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     bf16_t* bias_s = reinterpret_cast<bf16_t*>(ring + R * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    // The tile grid is split over the 8 XCDs as (8 / pc) x pc: XCD x = xr * pc + xc owns the row blocks = xr (mod 8 / pc) and
+    // the column tiles = xc (mod pc), so one L2 serves A_bytes * pc / 8 + B_bytes / pc.  pc = 1 (rows only) suits the
+    // token-parallel layers (a small weight, every XCD reads all of it); for M ~ 3 000 rows against a 3-5 MB weight the
+    // rows-only split puts the WHOLE weight + an eighth of A (> 4 MB) through every L2 and the DMA runs at the
+    // Infinity-Cache rate — the host picks the pc with the smallest per-XCD working set.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int my_mblks = (nmblk - xcd + 7) >> 3;
-    const int my_tiles = my_mblks * tilesN;
-    if (slot >= my_tiles) return;
+    const int pr = 8 / pc, xr = xcd / pc, xc = xcd - xr * pc;
+    const int my_mblks = (nmblk - xr + pr - 1) / pr;
+    const int my_tns = (tilesN - xc + pc - 1) / pc;
+    const int my_tiles = my_mblks * my_tns;
+    if (slot >= my_tiles || my_tns <= 0) return;
+    auto tile_m = [&](int t) { return xr + pr * (t / my_tns); };      // row block / column tile of this XCD's t-th tile
+    auto tile_n = [&](int t) { return xc + pc * (t % my_tns); };
     const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
     const unsigned ring_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0]);
@@ -154,8 +199,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     int issued = 0;                                           // its stages issued so far
     unsigned ibase = ring_base;                               // ring slot (LDS byte address) the next issue goes to
     int inflight = 0;                                         // stages issued and not yet consumed
-    gn_init<BM, WAVES, 0>(A, a, (int64_t)(xcd + 8 * (qn / tilesN)) * BM, M, lda, wave, lane);
-    gn_init<BN, WAVES, TN>(B, b, (qn % tilesN) * BN, N, ldb, wave, lane);
+    gn_init<BM, WAVES, 0>(A, a, (int64_t)tile_m(qn) * BM, M, lda, wave, lane);
+    gn_init<BN, WAVES, TN>(B, b, tile_n(qn) * BN, N, ldb, wave, lane);
     auto issue_next = [&]() {                                 // one stage of the flat (tile, stage) sequence, if any is left
         if (qn >= my_tiles) return;
         gn_issue<BM, WAVES>(A, ibase, wave);
@@ -166,8 +211,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
             issued = 0;
             qn += nslot;
             if (qn < my_tiles) {
-                gn_init<BM, WAVES, 0>(A, a, (int64_t)(xcd + 8 * (qn / tilesN)) * BM, M, lda, wave, lane);
-                gn_init<BN, WAVES, TN>(B, b, (qn % tilesN) * BN, N, ldb, wave, lane);
+                gn_init<BM, WAVES, 0>(A, a, (int64_t)tile_m(qn) * BM, M, lda, wave, lane);
+                gn_init<BN, WAVES, TN>(B, b, tile_n(qn) * BN, N, ldb, wave, lane);
             }
         }
     };
@@ -257,8 +302,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
         // ---- epilogue of tile q, from registers.  Swapped MFMA + permuted B rows: acc[i][j][r] =
         // C[m0 + wm + i*16 + lr][n0 + wn + (j>>1)*32 + lg*8 + (j&1)*4 + r]: the accumulator pair (2h, 2h+1) of a lane is
         // 8 consecutive columns = one 16-byte store, and the 4 lanes of a row write 64 contiguous bytes per instruction
-        const int64_t m0 = (int64_t)(xcd + 8 * (q / tilesN)) * BM;
-        const int n0 = (q % tilesN) * BN;
+        const int64_t m0 = (int64_t)tile_m(q) * BM;
+        const int n0 = tile_n(q) * BN;
         const int nl = n0 + wn + lg * 8;                      // this lane's first column (of the pair h = 0)
         const bool edge = m0 + BM > M || n0 + BN > N;         // wave-uniform
 #ifdef GN_ABL_NOSTORE
@@ -362,35 +407,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
 // unrolled over the two slots (every LDS address = per-lane constant + immediate), the 8 DMA pieces of a stage are one
 // asm block in the SGPR-base + 32-bit-VGPR-offset form (a stage advance = two scalar adds per operand), rows past the
 // edge are clamped.  Dispatch order keeps the N tiles of a row block on one XCD (as above).
-template <int NPIECE>
-__device__ __forceinline__ void gn_dma_block(unsigned lds, const unsigned (&v)[NPIECE], const bf16_t* base);
-template <>
-__device__ __forceinline__ void gn_dma_block<4>(unsigned lds, const unsigned (&v)[4], const bf16_t* base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %[keep], m0\n\t"
-        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
-        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
-        "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
-        "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
-        "s_mov_b32 m0, %[keep]"
-        : [keep] "=&s"(keep)
-        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [b] "s"(base)
-        : "memory", "scc");
-}
-template <>
-__device__ __forceinline__ void gn_dma_block<2>(unsigned lds, const unsigned (&v)[2], const bf16_t* base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %[keep], m0\n\t"
-        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
-        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
-        "s_mov_b32 m0, %[keep]"
-        : [keep] "=&s"(keep)
-        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [b] "s"(base)
-        : "memory", "scc");
-}
-
 template <int BN, int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_nt_lean_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                               const float* __restrict__ bias, const bf16_t* __restrict__ aux,
@@ -609,10 +625,12 @@ __global__ void __launch_bounds__(256) transpose_batch_kernel(const bf16_t* __re
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int R>
 int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, const bf16_t* aux,
-              bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk) {
+              bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk,
+              int pc = 1) {
 #define GN_GO(E)                                                                                                         \
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, R, E>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, st, \
-                       a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, tilesN, nmblk)
+                       a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, tilesN, nmblk, (const float*)nullptr,             \
+                       (const float*)nullptr, pc)
     switch (epi) {
         case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
         case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
@@ -629,10 +647,10 @@ int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf1
 template <int BM, int BN, int WAVES_M, int WAVES_N, int R>
 int gn_launch_fp8(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, bf16_t* c,
                   bf16_t* c2, int64_t M, int N, int K2, int64_t lda2, int64_t ldb2, int64_t ldc, int tilesN, int nmblk,
-                  const float* sa, const float* sb) {
+                  const float* sa, const float* sb, int pc = 1) {
 #define GN_GO(E)                                                                                                         \
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, R, E, true>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, \
-                       st, a, b, bias, (const bf16_t*)nullptr, c, c2, M, N, K2, lda2, ldb2, ldc, tilesN, nmblk, sa, sb)
+                       st, a, b, bias, (const bf16_t*)nullptr, c, c2, M, N, K2, lda2, ldb2, ldc, tilesN, nmblk, sa, sb, pc)
     switch (epi) {
         case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
         case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
@@ -641,6 +659,21 @@ int gn_launch_fp8(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const
     }
 #undef GN_GO
     return clv_check_launch();
+}
+
+// Column partitions of the XCD split (see the kernel): the pc in {1, 2, 4, 8} with the smallest per-XCD operand footprint
+// A_bytes * pc / 8 + B_bytes / pc, among those that leave every XCD at least one column tile.
+int gn_pick_pc(int64_t a_bytes, int64_t b_bytes, int tilesN) {
+    static const int forced = getenv("CLV_GEMM_PC") ? atoi(getenv("CLV_GEMM_PC")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced <= tilesN ? forced : 1;
+    int best = 1;
+    int64_t best_ws = a_bytes / 8 + b_bytes;
+    for (int pc = 2; pc <= 8; pc *= 2) {
+        if (pc > tilesN) break;
+        const int64_t ws = a_bytes * pc / 8 + b_bytes / pc;
+        if (ws < best_ws) { best = pc; best_ws = ws; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -660,16 +693,17 @@ extern "C" int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, 
     if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELUD) && !bias) return CLV_ERR_ARG;
     if (epilogue == GN_EPI_GELUD && !c2) return CLV_ERR_ARG;
     int BM = 128;
-    if (K >= 1024 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) BM = 64;      // same rule as clv_gemm_nt (K in bytes here)
+    if (K >= 1024 && ((M + 127) / 128) * ((N + 127) / 128) <= 384) BM = 64;      // same rule as clv_gemm_nt (K in bytes here)
     const int BN = 128;
     const int tilesN = (N + BN - 1) / BN;
     const int nmblk = (int)((M + BM - 1) / BM);
-    const int max_tiles_xcd = ((nmblk + 7) / 8) * tilesN;
+    const int pc = gn_pick_pc((int64_t)M * K, (int64_t)N * K, tilesN);
+    const int max_tiles_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc);
     const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 64 ? max_tiles_xcd : 64));
     hipStream_t st = (hipStream_t)stream;
     // the staging code moves bytes: hand it the operands in 2-byte units
 #define GN_ARGS8 epilogue, st, grid, (const bf16_t*)a8, (const bf16_t*)b8, bias, (bf16_t*)c, (bf16_t*)c2, M, N, K / 2, lda / 2, \
-                 ldb / 2, ldc, tilesN, nmblk, sa, sb
+                 ldb / 2, ldc, tilesN, nmblk, sa, sb, pc
     if (BM == 128) return gn_launch_fp8<128, 128, 2, 2, 2>(GN_ARGS8);
     return gn_launch_fp8<64, 128, 2, 2, 3>(GN_ARGS8);
 #undef GN_ARGS8
@@ -705,9 +739,10 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
                                   (bf16_t*)c, (bf16_t*)c2, M, N, K, lda, ldb, ldc, tilesN, nmblk);
     }
     int BM = 128, BN = 128, W = 4;
-    // few tiles and a long contraction (Swin stage 3, fusion encoder, text tower: <= 512 tiles of 128 x 128 for 512
-    // workgroup slots): 64 x 128 tiles double the workgroups that share the DMA latency (tools/probes/gemm_tiles.py)
-    if (!force && K >= 512 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) BM = 64;
+    // few tiles and a long contraction (Swin stage 3 proj / fc2 / merge, fusion and text encoders: <= 384 tiles of
+    // 128 x 128 for 512 workgroup slots): 64 x 128 tiles double the workgroups that share the DMA latency
+    // (tools/probes/gemm_tiles.py; with the XCD column split the 450-tile qkv of stage 3 is faster on 128 x 128)
+    if (!force && K >= 512 && ((M + 127) / 128) * ((N + 127) / 128) <= 384) BM = 64;
     if (force) {
         BM = atoi(force);
         const char* x = strchr(force, 'x');
@@ -719,11 +754,12 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     const int nmblk = (int)((M + BM - 1) / BM);
     // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's tiles
     const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : 1;
-    const int max_tiles_xcd = ((nmblk + 7) / 8) * tilesN;
+    const int pc = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
+    const int max_tiles_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc);
     const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 32 * per_cu ? max_tiles_xcd : 32 * per_cu));
     hipStream_t st = (hipStream_t)stream;
 #define GN_ARGS epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux, (bf16_t*)c, (bf16_t*)c2, M, N, K, \
-                lda, ldb, ldc, tilesN, nmblk
+                lda, ldb, ldc, tilesN, nmblk, pc
     if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
     if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4

@@ -29,7 +29,7 @@ SH = [(50176, 192, 768, 'fc2 s1'), (12544, 384, 1536, 'fc2 s2'), (12544, 384, 76
       (3136, 2304, 768, 'qkv s3'), (3136, 768, 768, 'proj s3'), (3136, 3072, 768, 'fc1 s3'), (3136, 768, 3072, 'fc2 s3'),
       (3648, 2304, 768, 'qkv fu'), (3648, 768, 768, 'out fu'), (3648, 3072, 768, 'fc1 fu'), (3648, 768, 3072, 'fc2 fu'),
       (512, 2304, 768, 'qkv bert'), (512, 768, 768, 'out bert'), (512, 3072, 768, 'fc1 bert'), (512, 768, 3072, 'fc2 bert')]
-TILES = [None, '64x128w4', '64x64w2', '256x128w8', '128x128w8']
+TILES = [None, '128x128w4', '64x128w4', '256x128w8', '128x128w8']
 for (M, N, K, name) in SH:
     x = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device='cuda'); bb = b.to(torch.bfloat16)
