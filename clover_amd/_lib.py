@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -37,7 +37,7 @@ FOLD_MAX = 64
 class ClvWgradEntry(C.Structure):
     _fields_ = [('dy', _p), ('x', _p), ('work', _p), ('dw', _p), ('db', _p), ('M', _i64), ('work_floats', _i64),
                 ('N', _i32), ('K', _i32),
-                ('ldy', _i32), ('ldx', _i32), ('want_bias', _i32), ('splits', _i32)]
+                ('ldy', _i32), ('ldx', _i32), ('want_bias', _i32), ('splits', _i32), ('overwrite', _i32), ('pad', _i32)]
 
 
 WGRAD_GROUP_MAX = 40

@@ -345,7 +345,8 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
                                                 const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                 float* __restrict__ out, float* __restrict__ out_b, int64_t M, int N, int K,
                                                 int ldy, int ldx, int tiles, int tilesK, int nsplits,
-                                                int64_t rows_per_split, int want_bias, int xcd_rot = 0) {
+                                                int64_t rows_per_split, int want_bias, int xcd_rot = 0,
+                                                int overwrite = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     int split, tile;
     if (nsplits > 0 && xcd_rot >= 0) {                                       // see wgrad_dma_kernel
@@ -499,7 +500,8 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
     if (ACCUM && RMW) {
         // one M-slice: this workgroup is the only writer of its dW elements in this launch (and the engine orders the
         // launches that share a parameter), so "+=" is a 16-byte load / add / store per lane in the swapped layout —
-        // 2 x 4 B of traffic per element instead of a memory-side atomic each (~190 G/s: 12 us for a 768 x 3072 matrix)
+        // 2 x 4 B of traffic per element instead of a memory-side atomic each (~190 G/s: 12 us for a 768 x 3072 matrix).
+        // overwrite: the step's FIRST gradient of this weight — dW is stale (the engine did not clear it): store, no load
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn + i * 16 + lr;
@@ -508,7 +510,8 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + wk + j * 16 + lg * 4;
-                if (k < K) old[j] = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k]);
+                old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && !overwrite) old[j] = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -579,7 +582,8 @@ struct WgProblem {
     float* work;                                             // partials, or dW itself (in_place)
     float* db;                                               // in_place only
     int64_t M, rows_per_split;
-    int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin, xcd_rot, in_place, pad;
+    int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin, xcd_rot, in_place;
+    int overwrite;                                           // in_place only: dW = (store), the step's first gradient of the weight
 };
 struct WgGroup {
     WgProblem p[WG_GROUP_MAX];
@@ -594,7 +598,7 @@ __global__ void __launch_bounds__(WG_THREADS, WG_RING == 3 ? 3 : 2) wgrad_dma2_g
     if (pr.in_place)                                         // few-row problems: one slice, dW += in place
         wgrad_dma2_body<true, true>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N, pr.K,
                                     pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
-                                    pr.xcd_rot);
+                                    pr.xcd_rot, pr.overwrite);
     else
         wgrad_dma2_body<false>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M, pr.N, pr.K,
                                pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
@@ -623,7 +627,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
                                                const bf16_t* __restrict__ x, float* __restrict__ out,
                                                float* __restrict__ out_b, int64_t M, int N, int K, int ldy, int ldx,
                                                int tiles, int tilesK, int nsplits, int64_t rows_per_split, int want_bias,
-                                               int xcd_rot) {
+                                               int xcd_rot, int overwrite = 0) {
     constexpr int P = PN + PK, W = 4 * PN * PK, IPW = 8 * P / W, GB = 2 * PK, R = BIG_RING;
     // LDS image: [panel][slot][8 KiB] — a wave's transpose reads of all slots then lie within the 64 KiB reach of the
     // ds immediate offset from ONE address register (slot-major order needed a register set per slot: spills)
@@ -781,7 +785,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
             if (k >= K) continue;
             float4* dst = reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]);
             float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (ACCUM) {
+            if (ACCUM && !overwrite) {
                 const float4 o = *dst;
                 v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
             }
@@ -807,7 +811,7 @@ __global__ void __launch_bounds__(256 * PN * PK) wgrad_big_group_kernel(WgGroup 
     if (pr.in_place)
         wgrad_big_body<PN, PK, true>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N,
                                      pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
-                                     pr.want_bias, pr.xcd_rot);
+                                     pr.want_bias, pr.xcd_rot, pr.overwrite);
     else
         wgrad_big_body<PN, PK, false>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M,
                                       pr.N, pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
@@ -917,7 +921,9 @@ __global__ void __launch_bounds__(256) fold_batch_kernel(FoldTable tab) {
     if (!in) return;
     float* dst = e < NK ? dw + e : db + (e - NK);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!en.overwrite) o = *reinterpret_cast<const float4*>(dst);   // overwrite: a fresh temporary, never read (nor zeroed)
+    // overwrite (bit 0: dW, bit 1: db): the target is a fresh temporary, or the step's first gradient of the weight —
+    // never read (nor zeroed)
+    if (!(en.overwrite & (e < NK ? 1 : 2))) o = *reinterpret_cast<const float4*>(dst);
     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     *reinterpret_cast<float4*>(dst) = o;
 }
@@ -1165,7 +1171,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
             p.work = in_place ? e.dw : (float*)e.work;
             p.db = in_place ? e.db : nullptr;
             p.in_place = in_place;
-            p.pad = 0;
+            p.overwrite = in_place ? (e.overwrite & 1) : 0;
             p.M = e.M;
             p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
             p.tiles = tilesN * tilesK;

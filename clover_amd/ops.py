@@ -150,14 +150,48 @@ def _wgrad_custom(M, N, K):
     return M >= 2048 and N * K <= (1 << 20) or M <= 1024
 
 
+FRESH_LOG = None            # census (engine set-up): {data_ptr: [calls, numel]} of every sink linear_wgrad writes
+
+
+class FirstTouch:
+    """State of an engine's first-touch gradient sinks (engine._setup_first_touch): ``on`` and the set of sinks already
+    written since the engine last "cleared" the gradients.  The sink tensors (``param._clv_grad``) carry it as
+    ``_clv_ft``, so whoever runs a backward over these parameters — the engine or plain ``loss.backward()`` — sees the
+    same state."""
+
+    def __init__(self):
+        self.on = False
+        self.done = set()
+
+
+def first_touch(dw_out):
+    """True when dw_out is a sink whose previous content is STALE (a weight the engine does not zero: its first weight
+    gradient of a step overwrites instead of accumulating — 8 bytes of HBM traffic per parameter and step less: no
+    zero-fill, no read-modify-write).  Every later gradient of the same step accumulates as usual."""
+    if dw_out is None:
+        return False
+    if FRESH_LOG is not None:
+        ent = FRESH_LOG.setdefault(dw_out.data_ptr(), [0, dw_out.numel()])
+        ent[0] += 1
+        if ent[1] != dw_out.numel():
+            ent[0] += 1 << 20                              # two sinks of different extent at one address: never first-touch
+    st = getattr(dw_out, '_clv_ft', None)
+    if st is None or not st.on or id(dw_out) in st.done:
+        return False
+    st.done.add(id(dw_out))
+    return True
+
+
 def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
     """dW fp32 [N,K] and db fp32 [N] of y = x W^T + b for bf16 dy2 [M,N], x2 [M,K].
     With dw_out / db_out (fp32, e.g. views of the engine's flat gradient slab) the result is
-    ACCUMULATED into them in place and (None, None) is returned.  xstats = (mean, rstd): the GEMM
+    ACCUMULATED into them in place and (None, None) is returned — dW is STORED instead when the sink is a first-touch
+    one (first_touch()).  xstats = (mean, rstd): the GEMM
     operand is the row-standardised x (the LayerNorm output a fused forward never stored)."""
     M, N = dy2.shape
     K = x2.shape[1]
     sink = dw_out is not None
+    ow = first_touch(dw_out)
     if xstats is not None and not _wgrad_custom(M, N, K):
         x2 = ((x2.float() - xstats[0][:, None]) * xstats[1][:, None]).to(BF16)
         xstats = None
@@ -166,8 +200,10 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         if WGRAD_DEFER is not None and sink and xstats is None:
             # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
             # backward segment (dy2 / x2 stay alive in the list until then)
-            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K))
+            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K, 1 if ow else 0))
             return None, None
+        if ow:
+            dw_out.zero_()                     # the stand-alone launches only accumulate
         dw = dw_out if sink else torch.zeros(N, K, device=dy2.device, dtype=torch.float32)
         db = (db_out if sink else torch.zeros(N, device=dy2.device, dtype=torch.float32)) if want_bias else None
         work = torch.empty(L.clv_linear_wgrad_work_floats(M, N, K), device=dy2.device, dtype=torch.float32)
@@ -198,7 +234,10 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         else:
             db.add_(dy2.sum(0, dtype=torch.float32))
     if sink:
-        torch.addmm(dw_out, dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
+        if ow:
+            torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
+        else:
+            torch.addmm(dw_out, dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
         return None, None
     return torch.mm(dy2.t(), x2, out_dtype=torch.float32), db
 
@@ -270,12 +309,14 @@ def flush_wgrads(pending):
         work = torch.empty(max(1, sum(e.work_floats for e in arr)), device=chunk[0][0].device, dtype=torch.float32)
         off = 0
         for e, (dy2, x2, dw, db, M, N, K, *ow) in zip(arr, chunk):
+            flags = int(ow[0]) if ow else 0          # bit 0: dW is stored (first touch / temporary), bit 1: db too
             if e.work_floats == 0:                   # few-row problem: accumulated in place, nothing to fold
                 e.dw, e.db = dw.data_ptr(), (db.data_ptr() if db is not None else None)
+                e.overwrite = flags & 1
                 continue
             w = work[off:off + e.work_floats]
             e.work = w.data_ptr()
-            folds.append((w, dw, db, N, K, e.splits, bool(ow and ow[0])))
+            folds.append((w, dw, db, N, K, e.splits, flags))
             off += e.work_floats
         if PROF is None:
             check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
@@ -315,7 +356,7 @@ def flush_folds(pending):
         for e, (work, dw, db, N, K, slices, *ow) in zip(arr, chunk):
             e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
             e.nk, e.e2, e.splits = N * K, N * K + N, slices
-            e.overwrite = int(bool(ow and ow[0]))
+            e.overwrite = int(ow[0]) if ow else 0
         check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
 
 
@@ -683,7 +724,7 @@ def _wgrad_folded(dy2, xhat, xs, mean, rstd, weight, bias, gamma, beta):
             # partial slices + fold: the fold STORES into the temporary (no zero-fill launch); one in-place slice adds
             tmp = (torch.zeros if in_place else torch.empty)(N * K + N, device=dy2.device, dtype=torch.float32)
             dwf, dbf = tmp[:N * K].view(N, K), tmp[N * K:]
-            WGRAD_DEFER.append((dy2, xhat, dwf, dbf, M, N, K, not in_place))
+            WGRAD_DEFER.append((dy2, xhat, dwf, dbf, M, N, K, 0 if in_place else 3))
             POST_DEFER.append(lambda: _unfold_grads(dwf, dbf, weight, bias, gamma, beta))
             return None, None, None, None
     dwf, dbf = linear_wgrad(dy2, xhat, True) if xhat is not None else linear_wgrad(dy2, xs, True, xstats=(mean, rstd))

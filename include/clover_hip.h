@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 6
+#define CLV_ABI_VERSION 7
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -236,7 +236,8 @@ typedef struct ClvFoldEntry {
     void* db;              /* float [N] or NULL */
     int64_t nk, e2;        /* N*K and N*K + N */
     int32_t splits, sg_shift, block_begin;
-    int32_t overwrite;     /* != 0: dw / db = the sum (an uninitialised temporary), instead of += */
+    int32_t overwrite;     /* bit 0: dw = the sum, bit 1: db = the sum (an uninitialised temporary, or the step's first
+                              gradient of a weight the engine does not clear), instead of += */
 } ClvFoldEntry;
 /* Grouped launch: the weight gradients of up to 40 Linear layers (a whole backward segment: nothing reads a weight
  * gradient before the optimizer) as ONE grid.  clv_linear_wgrad_batch_plan fills splits and work_floats of every entry
@@ -251,6 +252,8 @@ typedef struct ClvWgradEntry {
     float* db;                 /*   float [N][K] / [N] (or NULL) gradients, accumulated in place                        */
     int64_t M, work_floats;
     int32_t N, K, ldy, ldx, want_bias, splits;
+    int32_t overwrite;         /* work_floats == 0 only; bit 0: dw = (stored, not added: its previous content is stale) */
+    int32_t pad;
 } ClvWgradEntry;
 int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n);
 /* 1 if the plan gives this problem work_floats == 0 (one slice added into dw / db in place, without atomics): two such

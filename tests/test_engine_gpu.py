@@ -143,7 +143,10 @@ def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():
     eng.optimizer_step()
     for sg, (p0, m0) in zip(eng.segments, snap):
         assert torch.equal(sg.flat_p, p0) and torch.equal(sg.exp_avg, m0)
-        assert float(sg.flat_g.abs().nan_to_num(0).max()) == 0.0            # gradients are cleared all the same
+    # gradients are cleared all the same: what accumulates is zero again, the first-touch slots are marked stale
+    for v in (eng._zero_views if eng._zero_views is not None else [sg.flat_g for sg in eng.segments]):
+        assert float(v.abs().nan_to_num(0).max()) == 0.0
+    assert not eng._ft.done
     st = eng.optimizer_state()
     assert st['step'] == 1 and st['skipped'] == 1 and st['calls'] == 2 and eng.lr_iter == 2
     eng.step(b)
@@ -485,3 +488,83 @@ def test_tools_train_cli_two_loaders(tmp_path):
     recs = [ln for ln in out.stdout.splitlines() if "'mlm_loss'" in ln]
     assert len(recs) == 4, out.stdout[-2000:]
     assert os.path.exists(os.path.join(str(tmp_path), 'epoch_1.pth'))
+
+
+def test_first_touch_gradients_match_cleared_slabs(monkeypatch):
+    """Weights whose gradient arrives through ONE weight-gradient launch per step are not cleared between steps: that
+    launch stores (engine._setup_first_touch).  Against an engine that clears everything (CLOVER_GRAD_FIRST_TOUCH=0) on
+    the same weights: the same gradients from an eager backward and from the captured hipGraphs — twice in a row, the
+    second time over the first one's stale content — and the same loss trajectory; between steps the uncleared slots
+    hold the last gradient (never zero-filled), and a slot a backward does not reach is cleared like the others."""
+    from clover_amd.engine import CloverEngine
+    b = batch(tag='ft')
+    grads, traj = {}, {}
+    for ft in ('0', '1'):
+        monkeypatch.setenv('CLOVER_GRAD_FIRST_TOUCH', ft)
+        for mode in ('eager', 'graph'):
+            eng = CloverEngine(make_model(), b, lr=1e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+            if ft == '1':
+                assert eng.first_touch_params > 0.5 * eng.num_params, (eng.first_touch_params, eng.num_params)
+                assert sum(v.numel() for v in eng._zero_views) + eng.first_touch_params == \
+                    sum(sg.flat_g.numel() for sg in eng.segments)
+            else:
+                assert eng.first_touch_params == 0 and eng._zero_views is None
+            if mode == 'graph':
+                eng.dry_step(b)
+                assert eng.capture(b)
+            got = []
+            for _ in range(2):
+                eng.zero_grads()
+                if mode == 'graph':
+                    eng._graphed_forward_backward(b)
+                else:
+                    out = eng.model.train_step(b, None)
+                    eng._backward(lambda: out['loss'].backward())
+                got.append(torch.cat([sg.flat_g for sg in eng.segments]).clone())
+            grads[ft, mode] = got
+            eng.zero_grads()
+            traj[ft, mode] = [float(eng.step(b)['log_vars']['loss']) for _ in range(4)]
+            if ft == '1':
+                # between steps the first-touch slots keep the last gradient; everything else is zero
+                assert all(float(v.abs().max()) == 0.0 for v in eng._zero_views)
+                assert any(float(sg.flat_g.abs().max()) > 0 for sg in eng.segments)
+                # a first-touch slot the backward does not write counts as stale (cleared before the optimizer)
+                key, (sink, si, off, n) = next(iter(eng._fresh_sinks.items()))
+                eng._ft.done.clear()
+                assert any(v.data_ptr() == sink.data_ptr() for v in eng._stale_sinks())
+                eng._ft.done.add(key)
+                assert not any(v.data_ptr() == sink.data_ptr() for v in eng._stale_sinks())
+                eng._ft.done.clear()
+    for mode in ('eager', 'graph'):
+        ref = grads['0', mode][0]
+        for g in grads['1', mode] + grads['0', mode][1:]:
+            assert bool(torch.isfinite(g).all())
+            assert float((g - ref).norm()) <= 1e-3 * float(ref.norm()), (mode, float((g - ref).norm()), float(ref.norm()))
+        for x, y in zip(traj['1', mode], traj['0', mode]):
+            assert abs(x - y) <= 2e-2 * abs(y), (mode, traj)
+
+
+def test_first_touch_sink_semantics():
+    """ops.linear_wgrad on a first-touch sink: the first call after the state is cleared STORES over stale content, the
+    second accumulates; grouped (deferred) and stand-alone launches, in-place and partial + fold shapes, library shapes."""
+    from clover_amd import ops
+    torch.manual_seed(5)
+    for (M, N, K) in ((512, 768, 768), (3136, 768, 3072), (12544, 384, 384), (256, 1000, 768)):
+        dy = (torch.randn(M, N, device=DEV) * 0.1).to(torch.bfloat16)
+        x = (torch.randn(M, K, device=DEV) * 0.1).to(torch.bfloat16)
+        ref = dy.float().t() @ x.float()
+        for deferred in (False, True):
+            sink = torch.full((N, K), float('nan'), device=DEV)          # stale content: must never be read
+            bsink = torch.zeros(N, device=DEV)
+            st = ops.FirstTouch()
+            st.on = True
+            sink._clv_ft = st
+            for rep in (1, 2):
+                if deferred:
+                    with ops.defer_folds():
+                        ops.linear_wgrad(dy, x, True, sink, bsink)
+                else:
+                    ops.linear_wgrad(dy, x, True, sink, bsink)
+                err = float((sink - rep * ref).abs().max())
+                assert err <= 2e-3 * rep * float(ref.abs().max()), (M, N, K, deferred, rep, err)
+            assert float((bsink - 2 * dy.float().sum(0)).abs().max()) <= 2e-3 * float(dy.float().sum(0).abs().max()) + 1e-3

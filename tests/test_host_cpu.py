@@ -106,6 +106,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(so, name), name
     assert _lib.lib().clv_abi_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.ClvAttnGeom) == 23 * 4 + 4 + 8 + 8  # 21 int32 + scale + dropout_p, padding, dbias_index + work pointers
+    assert ctypes.sizeof(_lib.ClvWgradEntry) == 88                # ... + overwrite / pad (first-touch gradient sinks)
     assert ctypes.sizeof(_lib.ClvLnExtra) == 80                   # ... + q8 / qscale pointers (round 3)
 
 
