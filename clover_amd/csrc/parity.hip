@@ -85,14 +85,15 @@ __global__ void __launch_bounds__(256) sgemm_tiled_kernel(const float* __restric
 // rows): C[i][j] (ldc) (+)= sum_k A(i,k) B(j,k) (+ bias[j]),  A(i,k) = A[i*sai + k*sak],  B(j,k) = B[j*sbj + k*sbk] — one
 // wave per 16 x 16 tile on the exact-f32 MFMA, so that forward (x W^T), input gradient (dy W) and weight gradient
 // (dy^T x, accumulated into the fp32 gradient slab) of such a layer are the SAME kernel with different strides.
-constexpr int SS_WAVES = 8;
+template <int SS_WAVES>
 __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ bias, float* __restrict__ C, int M,
                                                            int N, int K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk,
                                                            int64_t ldc, int accumulate) {
     // 8 waves share one 16 x 16 output tile and split the contraction (these layers have 8-64 rows: a tile per wave left
-    // under a hundred waves walking K = 768..1536 alone: 29 us per launch); partial tiles meet in LDS
-    __shared__ float red[SS_WAVES - 1][64][4];
+    // under a hundred waves walking K = 768..1536 alone: 29 us per launch); partial tiles meet in LDS.  The weight-gradient
+    // form of the same layers contracts over those 8-64 rows and has 2 304 tiles: one wave per tile (SS_WAVES = 1).
+    __shared__ float red[SS_WAVES > 1 ? SS_WAVES - 1 : 1][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     const int i = blockIdx.y * 16 + lr, j = blockIdx.x * 16 + lr;
     const bool av = i < M, bv = j < N;
@@ -101,22 +102,25 @@ __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const floa
     const int kchunk = ((K + SS_WAVES * 16 - 1) / (SS_WAVES * 16)) * 16;     // per wave, a multiple of 16
     const int kb = wave * kchunk, ke = min(K, kb + kchunk);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kb; k0 < ke; k0 += 32) {                    // two 16-deep blocks per trip: 16 loads in flight
-        float a[8], b[8];
+    constexpr int KT = 8;                                     // two 16-deep blocks per trip: 16 loads in flight
+    for (int k0 = kb; k0 < ke; k0 += 4 * KT) {
+        float a[KT], b[KT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < KT; ++e) {
             const int k = k0 + e * 4 + lg;                    // k-step e: lane group lg holds k = k0 + 4e + lg
             a[e] = (av && k < ke) ? ap[k * sak] : 0.f;
             b[e] = (bv && k < ke) ? bp[k * sbk] : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+        for (int e = 0; e < KT; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
     }
-    if (wave > 0) {
+    if (SS_WAVES > 1) {
+        if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+            for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0 && j < N) {
 #pragma unroll
         for (int w = 0; w < SS_WAVES - 1; ++w)
@@ -142,8 +146,13 @@ extern "C" int clv_sgemm_strided(const float* A, const float* B, const float* bi
     if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || ldc < N) return CLV_ERR_ARG;
     if (M == 0) return CLV_OK;
     if (M > 0x7fffffff) return CLV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sgemm_strided_kernel, dim3((N + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64 * SS_WAVES), 0, (hipStream_t)stream,
-                       A, B, bias, C, (int)M, N, K, sai, sak, sbj, sbk, ldc, accumulate);
+    const dim3 grid((N + 15) / 16, (unsigned)((M + 15) / 16));
+    if (K <= 96)                                             // a short contraction (weight-gradient form): nothing to split
+        hipLaunchKernelGGL(sgemm_strided_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K, sai,
+                           sak, sbj, sbk, ldc, accumulate);
+    else
+        hipLaunchKernelGGL(sgemm_strided_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K, sai,
+                           sak, sbj, sbk, ldc, accumulate);
     return clv_check_launch();
 }
 
