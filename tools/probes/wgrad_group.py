@@ -14,6 +14,10 @@ for _ in range(2):
 P += [(50176, 192, 384)]
 for _ in range(2):
     P += [(200704, 96, 384), (200704, 96, 96)]
+only = os.environ.get('ONLY', '')          # 's0' / 's1' / 's2' / 's3': one stage's problems only
+if only:
+    rows = {'s0': 200704, 's1': 50176, 's2': 12544, 's3': 3136}[only]
+    P = [p for p in P if p[0] == rows]
 order = os.environ.get('ORDER', '')
 if order == 'bigfirst':
     P.sort(key=lambda p: -p[0])
