@@ -327,7 +327,8 @@ def main():
             'config': {'workload': f'VideoSwin-{args.variant} + BERT-base + 3-layer fusion, MLM + tri-modal '
                                    f'exclusive InfoNCE + rank losses, {args.frames}f x 224^2, {args.tokens}-tok',
                        'per_gpu_batch': args.batch, 'global_batch': gb, 'parallelism': f'dp{world}',
-                       'params_M': round(engine.num_params / 1e6, 1)},
+                       'params_M': round(engine.num_params / 1e6, 1),
+                       'first_touch_params_M': round(getattr(engine, 'first_touch_params', 0) / 1e6, 1)},
             'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
             'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
             'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
