@@ -338,24 +338,23 @@ class CloverEngine:
             dbg = os.environ.get('CLOVER_FT_DEBUG') == '1'
             if dbg:
                 print(f'[first-touch] sinks {len(sinks)}  logged {len(log)}  candidates {len(cand)}', flush=True)
-            if cand:
-                got = run(cand)
-                ok = [ptr for ptr in cand if same(span(got, ptr), span(ref, ptr))]
-                if dbg:
-                    bad = [ptr for ptr in cand if ptr not in ok]
-                    print(f'[first-touch] pass {len(ok)}  fail {len(bad)}', flush=True)
-                    for ptr in bad[:6]:
-                        a, r = span(got, ptr), span(ref, ptr)
-                        print('   fail numel', sinks[ptr][3], 'finite', bool(torch.isfinite(a).all()),
-                              'relerr', float((a - r).norm() / (r.norm() + 1e-30)), flush=True)
-            if ok:
-                got = run(ok)
-                if dbg:
-                    for si, (g, r) in enumerate(zip(got, ref)):
-                        print(f'[first-touch] validation slab {si}: finite {bool(torch.isfinite(g).all())} relerr '
-                              f'{float((g - r).norm() / (r.norm() + 1e-30)):.3e}', flush=True)
-                if not all(same(g, r) for g, r in zip(got, ref)):
-                    ok = []
+            # exactly three passes on every rank, whatever they find: the step contains collectives (feature all-gather)
+            got = run(cand)
+            ok = [ptr for ptr in cand if same(span(got, ptr), span(ref, ptr))]
+            if dbg:
+                bad = [ptr for ptr in cand if ptr not in ok]
+                print(f'[first-touch] pass {len(ok)}  fail {len(bad)}', flush=True)
+                for ptr in bad[:6]:
+                    a, r = span(got, ptr), span(ref, ptr)
+                    print('   fail numel', sinks[ptr][3], 'finite', bool(torch.isfinite(a).all()),
+                          'relerr', float((a - r).norm() / (r.norm() + 1e-30)), flush=True)
+            got = run(ok)
+            if dbg:
+                for si, (g, r) in enumerate(zip(got, ref)):
+                    print(f'[first-touch] validation slab {si}: finite {bool(torch.isfinite(g).all())} relerr '
+                          f'{float((g - r).norm() / (r.norm() + 1e-30)):.3e}', flush=True)
+            if not all(same(g, r) for g, r in zip(got, ref)):
+                ok = []
         finally:
             ops.FRESH_LOG = None
             self.reducer.reset()
