@@ -190,7 +190,9 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
     const int N = G.g.N;
     const int s0 = sp * G.pt16, Ns = min(N - s0, G.pt16);     // staged keys [s0, s0 + Ns); one part: all N
 
-    int* row_s = reinterpret_cast<int*>(aux + 2 * NK);
+    // window mode keeps no additive key array (its only term is -inf on the pad keys of the last tile: computed): with
+    // 13 key tiles the workgroup then needs < 40 KB of LDS and FOUR share a CU instead of three
+    int* row_s = reinterpret_cast<int*>(aux + (MODE == 1 ? 1 : 2) * NK);
     int* linb_s = row_s + NK;                                // mode 1 + bias: 4 * lin(n)
     float* tab_s = reinterpret_cast<float*>(linb_s + NK);    //                the head's bias table
     int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);     // "window straddles shift regions"
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             rid_s[n] = rv;
             if (n < N) differs |= rv != rid[wloc * N];
         }
-        kadd[n] = (n < Ns) ? ((MODE == 0 && kmask) ? kmask[(int64_t)grp * N + s0 + n] * LOG2E : 0.f) : -INFINITY;
+        if (MODE == 0) kadd[n] = (n < Ns) ? (kmask ? kmask[(int64_t)grp * N + s0 + n] * LOG2E : 0.f) : -INFINITY;
     }
     // a shifted block's windows that lie inside ONE region (all but the last row / column of windows: 49 of 64 at
     // 56 x 56) need no mask: 12 VALU operations per key tile and query less
@@ -272,9 +274,12 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             const float4 bv = bnext;
             if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
             f32x4_t acc = {bv.x, bv.y, bv.z, bv.w};                   // additive terms first, the MFMA adds q.k on top
-            if (MODE == 0 || (t + 1) * 16 > Ns) {                     // key mask (mode 0) / -inf on the pad keys of the last tiles
+            if (MODE == 0) {                                          // key mask, -inf on the pad keys of the last tile
                 const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
                 acc[0] += ka.x; acc[1] += ka.y; acc[2] += ka.z; acc[3] += ka.w;
+            } else if ((t + 1) * 16 > Ns) {                           // window mode: only the pad keys of the last tile(s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (key0 + r < Ns) ? acc[r] : -INFINITY;
             }
             if (masked) {                                             // workgroup-uniform: window straddles shift regions
                 const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
@@ -1017,7 +1022,7 @@ inline int64_t ds_scratch_bytes(const Geom& G, int nkt) {
 }
 
 template <int HD, int NKT>
-size_t fwd_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
+size_t fwd_lds(int tls, bool window = false) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + (window ? 3 : 4) * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 template <int HD, int NKT>
 size_t dq_lds(int tls) { return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 4 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16; }
 template <int HD, int NKT>
@@ -1057,7 +1062,7 @@ template <int HD, int NKT>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
                const int32_t* rid, const float* kmask, const unsigned long long* seed, const Geom& G, hipStream_t st) {
     const int bl = bias ? G.tls : 0;
-    const size_t lds = fwd_lds<HD, NKT>(bl);
+    const size_t lds = fwd_lds<HD, NKT>(bl, G.g.mode == 1);
     if (lds > MAX_LDS || dq_lds<HD, NKT>(bl) > MAX_LDS || dkv_lds<HD, NKT>(bl) > MAX_LDS) return CLV_ERR_UNSUPPORTED;
     if (G.g.mode == 1 && G.drop_thresh) return CLV_ERR_UNSUPPORTED;
     set_attrs<HD, NKT>();
