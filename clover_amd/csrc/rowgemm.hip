@@ -33,8 +33,8 @@ struct RGCfg {
     static constexpr int LDO = TN + 8;
 };
 
-template <int KS, bool STD, int EPI>
-__global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
+template <int KS, bool STD, int EPI, int NW = RG_WAVES>
+__global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ sum_out,
     float* __restrict__ mean, float* __restrict__ rstd, bf16_t* __restrict__ xhat_out, const bf16_t* __restrict__ wt,
     const float* __restrict__ bias, const bf16_t* __restrict__ pre_in, bf16_t* __restrict__ y,
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     constexpr int K = C::K, TN = C::TN, LDW = C::LDW, LDO = C::LDO, NT = TN / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* stage = Ws + TN * LDW;                          // [RG_WAVES][EPI ? 2 : 1][16 * LDO]
+    bf16_t* stage = Ws + TN * LDW;                          // [NW][EPI ? 2 : 1][16 * LDO]
     constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     const bool first_col = by == 0;
 
     // ---- weight tile -> LDS (rows >= N zero)
-    for (int idx = tid; idx < TN * (K / 8); idx += RG_THREADS) {
+    for (int idx = tid; idx < TN * (K / 8); idx += 64 * NW) {
         const int r = idx / (K / 8), c8 = idx - r * (K / 8);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (n0 + r < N) v = *reinterpret_cast<const uint4*>(wt + (int64_t)(n0 + r) * K + c8 * 8);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     bf16_t* st0 = stage + (wave * NST) * 16 * LDO;
     bf16_t* st1 = st0 + 16 * LDO;
     const int64_t ntiles = (M + 15) / 16;
-    for (int64_t tile = (int64_t)bx * RG_WAVES + wave; tile < ntiles; tile += (int64_t)gx * RG_WAVES) {
+    for (int64_t tile = (int64_t)bx * NW + wave; tile < ntiles; tile += (int64_t)gx * NW) {
         const int64_t m0 = tile * 16;
         const int64_t row = m0 + lr;
         const bool rv = row < M;
@@ -205,22 +205,45 @@ __global__ void __launch_bounds__(RG_THREADS) rowgemm_kernel(
     }
 }
 
-template <int KS, bool STD, int EPI>
+template <int KS, bool STD, int EPI, int NW = RG_WAVES>
 int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out, const void* wt,
               const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int N, int ldx, int ldy,
               float eps, hipStream_t st) {
     using C = RGCfg<KS>;
     constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
-    const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)RG_WAVES * NST * 16 * C::LDO * 2;
+    const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)NW * NST * 16 * C::LDO * 2;
     if (lds > 160 * 1024) return CLV_ERR_UNSUPPORTED;
+    // a weight tile of >= 64 KB leaves ONE workgroup per CU: eight waves share it instead of four (K = 288 / 384: the
+    // stage-0 qkv input gradient and fc2)
+    if constexpr (NW == RG_WAVES && KS >= 9 && KS <= 12) {
+        static const int wv = getenv("CLV_RG_WAVES") ? atoi(getenv("CLV_RG_WAVES")) : 8;
+        const size_t wbytes = (size_t)C::TN * C::LDW * 2, per_wave = (size_t)NST * 16 * C::LDO * 2;
+        if (wbytes >= 64 * 1024) {
+            if (wv == 12 && wbytes + 12 * per_wave <= 160 * 1024)
+                return launch_rg<KS, STD, EPI, 12>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
+                                                   ldy, eps, st);
+            if (wv >= 8 && wbytes + 8 * per_wave <= 160 * 1024)
+                return launch_rg<KS, STD, EPI, 8>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
+                                                  ldy, eps, st);
+        }
+    }
+    // K <= 128 with the GELU' epilogue (fc1's input gradient at stage 0: 70 VGPRs): 8-wave workgroups put 24 waves on a CU
+    // where five 4-wave ones (LDS) put 20: 108 -> 91 us.  The LayerNorm-prologue variants need 92 VGPRs and spill under
+    // the 80 that 24 waves allow (165 -> 197 us): they stay at 4 waves.
+    if constexpr (NW == RG_WAVES && KS <= 4 && !STD && EPI == EPI_GELU_BWD) {
+        static const int w3 = getenv("CLV_RG_WAVES3") ? atoi(getenv("CLV_RG_WAVES3")) : 8;
+        if (w3 == 8)
+            return launch_rg<KS, STD, EPI, 8>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy,
+                                              eps, st);
+    }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KS, STD, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KS, STD, EPI, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int ny = (N + C::TN - 1) / C::TN;
-    const int64_t row_blocks = ((M + 15) / 16 + RG_WAVES - 1) / RG_WAVES;
+    const int64_t row_blocks = ((M + 15) / 16 + NW - 1) / NW;
     // persistent workgroups, exactly as many as are resident at once (LDS-limited): every workgroup loads its weight
     // tile (up to 100 KB) ONCE and then streams its share of the rows — with more workgroups than that the tile
     // reload dominates (measured: 1536 workgroups of 2 row tiles per wave ran fc2 at a third of this)
@@ -237,7 +260,7 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
     gx *= mult;
     if (gx < 8) gx = 8;
     if (gx > row_blocks) gx = row_blocks;
-    rowgemm_kernel<KS, STD, EPI><<<dim3((unsigned)(gx * ny)), dim3(RG_THREADS), lds, st>>>(
+    rowgemm_kernel<KS, STD, EPI, NW><<<dim3((unsigned)(gx * ny)), dim3(64 * NW), lds, st>>>(
         (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)sum_out, mean, rstd, (bf16_t*)xhat_out, (const bf16_t*)wt, bias,
         (const bf16_t*)pre_in, (bf16_t*)y, (bf16_t*)pre_out, M, N, ldx, ldy, eps);
     return clv_check_launch();
