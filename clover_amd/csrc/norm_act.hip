@@ -467,9 +467,13 @@ __global__ void __launch_bounds__(LN_THREADS) lnv_fwd_kernel(
     }
 }
 
+#ifndef LNV_BWD_WAVES
+#define LNV_BWD_WAVES 5
+#endif
 // dx = d t * (x multiplier) [-> dx], d t itself [-> dres, when given];  d t = LN-backward(dy (+ dy2)) (+ dsum)
 template <int GROUP, int ITERS, typename T, bool XF>
-__global__ void __launch_bounds__(LN_THREADS) lnv_bwd_kernel(
+// one 16-byte chunk per lane (ITERS == 1): 96 VGPRs = 5 waves per SIMD (the transform variants wanted 98-112: 4)
+__global__ void __launch_bounds__(LN_THREADS, ITERS == 1 ? LNV_BWD_WAVES : 1) lnv_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x, const T* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     const T* __restrict__ dsum, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial,

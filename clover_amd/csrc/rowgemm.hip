@@ -78,14 +78,10 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
     // The MFMAs below run with SWAPPED operands (D = W-rows x X-rows), so a lane ends up with 4 CONSECUTIVE output
     // columns (nt*16 + lg*4 + r) of ONE row (lr): the epilogue then packs 4 bf16 into one 8-byte LDS access where the
     // natural orientation needs four 2-byte ones.  bias per lane accordingly: 4 values per column tile.
-    float bn[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + nt * 16 + lg * 4 + r;
-            bn[nt][r] = (bias && n < N) ? bias[n] : 0.f;
-        }
+    // (the TN bias values sit in LDS, one 16-byte read per column tile: held in registers they cost 4 NT VGPRs, which is
+    // what kept the LayerNorm-prologue variants from a sixth wave per SIMD)
+    float* bias_s = reinterpret_cast<float*>(stage + NW * NST * 16 * LDO);
+    for (int n = tid; n < TN; n += 64 * NW) bias_s[n] = (bias && n0 + n < N) ? bias[n0 + n] : 0.f;
     __syncthreads();
 
     bf16_t* st0 = stage + (wave * NST) * 16 * LDO;
@@ -172,8 +168,8 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
             }
             const int off = lr * LDO + nt * 16 + lg * 4;
             float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[nt][r];
+            const float4 bq = *reinterpret_cast<const float4*>(bias_s + nt * 16 + lg * 4);
+            v[0] = acc[0] + bq.x; v[1] = acc[1] + bq.y; v[2] = acc[2] + bq.z; v[3] = acc[3] + bq.w;
             if (EPI == EPI_GELU) {
                 // pre-activation (kept for the backward)
                 *reinterpret_cast<uint2*>(st1 + off) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -211,13 +207,13 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
               float eps, hipStream_t st) {
     using C = RGCfg<KS>;
     constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
-    const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)NW * NST * 16 * C::LDO * 2;
+    const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)NW * NST * 16 * C::LDO * 2 + (size_t)C::TN * 4;
     if (lds > 160 * 1024) return CLV_ERR_UNSUPPORTED;
     // a weight tile of >= 64 KB leaves ONE workgroup per CU: eight waves share it instead of four (K = 288 / 384: the
     // stage-0 qkv input gradient and fc2)
     if constexpr (NW == RG_WAVES && KS >= 9 && KS <= 12) {
         static const int wv = getenv("CLV_RG_WAVES") ? atoi(getenv("CLV_RG_WAVES")) : 8;
-        const size_t wbytes = (size_t)C::TN * C::LDW * 2, per_wave = (size_t)NST * 16 * C::LDO * 2;
+        const size_t wbytes = (size_t)C::TN * C::LDW * 2 + (size_t)C::TN * 4, per_wave = (size_t)NST * 16 * C::LDO * 2;
         if (wbytes >= 64 * 1024) {
             if (wv == 12 && wbytes + 12 * per_wave <= 160 * 1024)
                 return launch_rg<KS, STD, EPI, 12>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
@@ -227,10 +223,10 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
                                                   ldy, eps, st);
         }
     }
-    // K <= 128 with the GELU' epilogue (fc1's input gradient at stage 0: 70 VGPRs): 8-wave workgroups put 24 waves on a CU
-    // where five 4-wave ones (LDS) put 20: 108 -> 91 us.  The LayerNorm-prologue variants need 92 VGPRs and spill under
-    // the 80 that 24 waves allow (165 -> 197 us): they stay at 4 waves.
-    if constexpr (NW == RG_WAVES && KS <= 4 && !STD && EPI == EPI_GELU_BWD) {
+    // K <= 128 with the GELU' epilogue (fc1's input gradient at stage 0) or the LayerNorm prologue (qkv, fc1): 8-wave
+    // workgroups put 24 waves on a CU where five 4-wave ones (LDS) put 20 — 108 -> 91 us for the former.  The prologue
+    // variants fit the 80 VGPRs that 24 waves allow since the bias row moved to LDS (K = 96: 76-78; K = 128 spills: 4 waves).
+    if constexpr (NW == RG_WAVES && ((KS <= 4 && !STD && EPI == EPI_GELU_BWD) || (KS <= 3 && STD))) {
         static const int w3 = getenv("CLV_RG_WAVES3") ? atoi(getenv("CLV_RG_WAVES3")) : 8;
         if (w3 == 8)
             return launch_rg<KS, STD, EPI, 8>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy,
