@@ -211,11 +211,11 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
     if (lds > 160 * 1024) return CLV_ERR_UNSUPPORTED;
     // a weight tile of >= 64 KB leaves ONE workgroup per CU: eight waves share it instead of four (K = 288 / 384: the
     // stage-0 qkv input gradient and fc2)
-    if constexpr (NW == RG_WAVES && KS >= 9 && KS <= 12) {
+    if constexpr (NW == RG_WAVES && KS >= 6 && KS <= 12) {
         static const int wv = getenv("CLV_RG_WAVES") ? atoi(getenv("CLV_RG_WAVES")) : 8;
         const size_t wbytes = (size_t)C::TN * C::LDW * 2 + (size_t)C::TN * 4, per_wave = (size_t)NST * 16 * C::LDO * 2;
-        if (wbytes >= 64 * 1024) {
-            if (wv == 12 && wbytes + 12 * per_wave <= 160 * 1024)
+        if (wbytes >= 48 * 1024) {
+            if ((wv == 12 || (KS <= 8 && wv >= 8)) && wbytes + 12 * per_wave <= 160 * 1024)
                 return launch_rg<KS, STD, EPI, 12>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
                                                    ldy, eps, st);
             if (wv >= 8 && wbytes + 8 * per_wave <= 160 * 1024)
