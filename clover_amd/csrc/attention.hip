@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
 // windows and scatters the sums into the table gradient.
 template <int HD, int NKT, bool DROP, int MODE>
 // 13-tile windows (8 waves): 80 VGPRs = 6 waves per SIMD = THREE workgroups per CU (the kernel wanted 82: two)
-__global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : (NKT >= 13 && HD <= 32 && MODE == 1 ? 6 : 1))) attn_bwd_dq_kernel(
+__global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : ((NKT == 13 || NKT == 14) && HD == 32 && MODE == 1 ? 6 : 1))) attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, const float* __restrict__ kmask,
