@@ -743,6 +743,11 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     // 128 x 128 for 512 workgroup slots): 64 x 128 tiles double the workgroups that share the DMA latency
     // (tools/probes/gemm_tiles.py; with the XCD column split the 450-tile qkv of stage 3 is faster on 128 x 128)
     if (!force && K >= 512 && ((M + 127) / 128) * ((N + 127) / 128) <= 384) BM = 64;
+    // 128 x 128 tiles run on EIGHT waves (64 x 32 each) with a ring of 2: two workgroups = 16 waves per CU instead of 8 —
+    // 0-5 % on every shape of the class (gemm_tiles.py: fc1 s3 24.8 -> 23.6, fc1 s1 29.5 -> 27.9, dqkv s2 20.2 -> 19.7 us)
+    bool r2 = false;
+    static const int w8 = getenv("CLV_GEMM_W8") ? atoi(getenv("CLV_GEMM_W8")) : 1;
+    if (!force && BM == 128 && w8) { W = 8; r2 = true; }
     if (force) {
         BM = atoi(force);
         const char* x = strchr(force, 'x');
@@ -753,7 +758,8 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
     const int tilesN = (N + BN - 1) / BN;
     const int nmblk = (int)((M + BM - 1) / BM);
     // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's tiles
-    const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : 1;
+    if (force && strstr(force, "r2")) r2 = true;
+    const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : (BM == 128 && W == 8 && r2) ? 2 : 1;
     const int pc = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
     const int max_tiles_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc);
     const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 32 * per_cu ? max_tiles_xcd : 32 * per_cu));
@@ -762,6 +768,7 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
                 lda, ldb, ldc, tilesN, nmblk, pc
     if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
+    if (BM == 128 && BN == 128 && W == 8 && r2) return gn_launch<128, 128, 2, 4, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4
     if (BM == 64 && BN == 128 && W == 4) return gn_launch<64, 128, 2, 2, 3>(GN_ARGS);     // 24 KiB stages x 3, two WGs per CU
     if (BM == 64 && BN == 64 && W == 2) return gn_launch<64, 64, 1, 2, 3>(GN_ARGS);       // 16 KiB stages x 3, three WGs per CU

@@ -946,8 +946,11 @@ GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU, GEMM_EPI_BIAS_
 def _gemm_kname(M, N, K, epi, fp8):
     """Device-kernel name as rocprofv3 prints it (gemm_nt.hip: tile class by tile count, see clv_gemm_nt; K in 2-byte units
     for the fp8 entry point)."""
-    small = K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) <= 512
-    return f"gemm_nt_kernel<{64 if small else 128}, 128, 2, 2, {3 if small else 2}, {epi}, {'true' if fp8 else 'false'}>"
+    small = K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) <= 384
+    if small:
+        return f"gemm_nt_kernel<64, 128, 2, 2, 3, {epi}, {'true' if fp8 else 'false'}>"
+    # the bf16 128 x 128 class runs 8 waves (2 x 4) on a ring of 2, the fp8 one 4 waves (2 x 2)
+    return f"gemm_nt_kernel<128, 128, 2, {2 if fp8 else 4}, 2, {epi}, {'true' if fp8 else 'false'}>"
 
 
 def gemm_nt_supported(M, N, K):

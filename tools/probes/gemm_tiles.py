@@ -25,11 +25,15 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / (3 * n) * 1e3
 
 
+SHORTK = [(50176, 576, 192, 'qkv s1'), (50176, 192, 192, 'proj s1'), (50176, 768, 192, 'fc1 s1'), (50176, 192, 576, 'dqkv s1'),
+          (12544, 1152, 384, 'qkv s2'), (12544, 384, 384, 'proj s2'), (12544, 1536, 384, 'fc1 s2'), (12544, 384, 1152, 'dqkv s2')]
 SH = [(50176, 192, 768, 'fc2 s1'), (12544, 384, 1536, 'fc2 s2'), (12544, 384, 768, 'merge s2'), (3136, 768, 1536, 'merge s3'),
       (3136, 2304, 768, 'qkv s3'), (3136, 768, 768, 'proj s3'), (3136, 3072, 768, 'fc1 s3'), (3136, 768, 3072, 'fc2 s3'),
       (3648, 2304, 768, 'qkv fu'), (3648, 768, 768, 'out fu'), (3648, 3072, 768, 'fc1 fu'), (3648, 768, 3072, 'fc2 fu'),
       (512, 2304, 768, 'qkv bert'), (512, 768, 768, 'out bert'), (512, 3072, 768, 'fc1 bert'), (512, 768, 3072, 'fc2 bert')]
-TILES = [None, '128x128w4', '64x128w4', '256x128w8', '128x128w8']
+TILES = [None, '128x128w4', '128x128w8r2']
+if os.environ.get('SHAPES') == 'shortk':      # the short-contraction token-parallel layers of stages 1-2
+    SH = SHORTK
 for (M, N, K, name) in SH:
     x = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device='cuda'); bb = b.to(torch.bfloat16)
