@@ -704,6 +704,8 @@ extern "C" int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, 
     // the staging code moves bytes: hand it the operands in 2-byte units
 #define GN_ARGS8 epilogue, st, grid, (const bf16_t*)a8, (const bf16_t*)b8, bias, (bf16_t*)c, (bf16_t*)c2, M, N, K / 2, lda / 2, \
                  ldb / 2, ldc, tilesN, nmblk, sa, sb, pc
+    static const int w8 = getenv("CLV_GEMM_W8") ? atoi(getenv("CLV_GEMM_W8")) : 1;     // eight waves, as the bf16 class
+    if (BM == 128 && w8) return gn_launch_fp8<128, 128, 2, 4, 2>(GN_ARGS8);
     if (BM == 128) return gn_launch_fp8<128, 128, 2, 2, 2>(GN_ARGS8);
     return gn_launch_fp8<64, 128, 2, 2, 3>(GN_ARGS8);
 #undef GN_ARGS8

@@ -949,8 +949,7 @@ def _gemm_kname(M, N, K, epi, fp8):
     small = K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) <= 384
     if small:
         return f"gemm_nt_kernel<64, 128, 2, 2, 3, {epi}, {'true' if fp8 else 'false'}>"
-    # the bf16 128 x 128 class runs 8 waves (2 x 4) on a ring of 2, the fp8 one 4 waves (2 x 2)
-    return f"gemm_nt_kernel<128, 128, 2, {2 if fp8 else 4}, 2, {epi}, {'true' if fp8 else 'false'}>"
+    return f"gemm_nt_kernel<128, 128, 2, 4, 2, {epi}, {'true' if fp8 else 'false'}>"     # 8 waves (2 x 4), ring of 2
 
 
 def gemm_nt_supported(M, N, K):
