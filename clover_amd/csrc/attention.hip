@@ -257,89 +257,122 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
             load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
         }
 
-        float p[NKT][4];
+        constexpr int CH = NKT > 16 ? 14 : NKT;             // key tiles per softmax chunk
+        float p[CH][4];
         // relative-position bias from the LDS table: byte offset = 4 * (lin(q) + tcst) - 4 * lin(key)
         const bool tb = MODE == 1 && bias != nullptr;
         const char* tp = reinterpret_cast<const char*>(tab_s) + (tb ? linb_s[qv ? nq : 0] + 4 * G.tcst : 0);
         const int rq = (MODE == 1 && rid && qv) ? rid_s[nq] : 0;
         float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            Frag8 kf[KS];
-            lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
-            const int key0 = t * 16 + lg * 4;
-            asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
-            const float4 bv = bnext;
-            if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
-            f32x4_t acc = {bv.x, bv.y, bv.z, bv.w};                   // additive terms first, the MFMA adds q.k on top
-            if (MODE == 0) {                                          // key mask, -inf on the pad keys of the last tile
-                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-                acc[0] += ka.x; acc[1] += ka.y; acc[2] += ka.z; acc[3] += ka.w;
-            } else if ((t + 1) * 16 > Ns) {                           // window mode: only the pad keys of the last tile(s)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = (key0 + r < Ns) ? acc[r] : -INFINITY;
-            }
-            if (masked) {                                             // workgroup-uniform: window straddles shift regions
-                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
-                acc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
-                acc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
-                acc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
-                acc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[t][r] = acc[r];
-                m = fmaxf(m, acc[r]);
-            }
-        }
-        m = grp4_max(m);                                     // log2 units
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(p[t][r] - m);
-                p[t][r] = e;
-                if (DROP) sum += e;
-            }
-        if (DROP) {                                        // dropout on the probabilities (after softmax)
-            sum = grp4_sum(sum);
-            const unsigned long long sd = *seedp;
-            const unsigned rowid = (unsigned)((grp * G.g.nH + h) * N + nq);
-#pragma unroll
-            for (int t = 0; t < NKT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    p[t][r] *= keep_scale(sd, rowid, (unsigned)(s0 + t * 16 + lg * 4 + r), G.drop_thresh, G.inv_keep);
-        }
-
+        // Long windows / sequences (25 / 28 key tiles) walk their keys in TWO chunks of <= 14 tiles with a running row
+        // maximum (the accumulators and the denominator are rescaled by exp2(m_old - m_new) between them): 56 score
+        // registers instead of 100-112, so that the kernel fits 168 VGPRs = 3 waves per SIMD and two workgroups share a CU
+        // (one workgroup of one wave per SIMD before: 260 us per stage-0 block of Swin-B at 16 frames).
         f32x4_t oacc[NC];
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};                 // row sums of P from the matrix pipe (all-ones "V" block)
 #pragma unroll
         for (int c = 0; c < NC; ++c) oacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, sum = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) {
-            constexpr bool ODD = (NKT & 1) != 0;             // odd tile count (N = 196 -> 13): the last k-step is half empty
-            const bool tail = ODD && s2 == NKT / 2;
-            Frag8 pf;
-            pf.u[0] = pack2bf(p[2 * s2][0], p[2 * s2][1]);
-            pf.u[1] = pack2bf(p[2 * s2][2], p[2 * s2][3]);
-            pf.u[2] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][0], p[tail ? 0 : 2 * s2 + 1][1]);
-            pf.u[3] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][2], p[tail ? 0 : 2 * s2 + 1][3]);
+        for (int c0 = 0; c0 < NKT; c0 += CH) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ct = (NKT - c0) < CH ? (NKT - c0) : CH;  // tiles of this chunk (compile-time after unrolling)
+            float mc = -INFINITY;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                Frag8 vf;   // A[hd c*16+lr][kappa] = V[key(kappa)][hd]
-                vf.u2[0] = tr4(Vs, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
-                vf.u2[1] = tail ? make_uint2(0u, 0u) : tr4(Vs, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
-                oacc[c] = mfma16(vf, pf, oacc[c]);
+            for (int tt = 0; tt < CH; ++tt) {
+                if (tt >= ct) break;
+                const int t = c0 + tt;
+                Frag8 kf[KS];
+                lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
+                const int key0 = t * 16 + lg * 4;
+                asm volatile("" ::: "memory");               // keep the gathers one tile ahead, not all up front
+                const float4 bv = bnext;
+                if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
+                f32x4_t acc = {bv.x, bv.y, bv.z, bv.w};               // additive terms first, the MFMA adds q.k on top
+                if (MODE == 0) {                                      // key mask, -inf on the pad keys of the last tile
+                    const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+                    acc[0] += ka.x; acc[1] += ka.y; acc[2] += ka.z; acc[3] += ka.w;
+                } else if ((t + 1) * 16 > Ns) {                       // window mode: only the pad keys of the last tile(s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = (key0 + r < Ns) ? acc[r] : -INFINITY;
+                }
+                if (masked) {                                         // workgroup-uniform: window straddles shift regions
+                    const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
+                    acc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
+                    acc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
+                    acc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
+                    acc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = mfma16(kf[s], qf[s], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[tt][r] = acc[r];
+                    mc = fmaxf(mc, acc[r]);
+                }
             }
-            // without dropout the softmax denominator is the sum of the SAME bf16 probabilities the P.V product uses:
-            // seven idle-pipe MFMAs instead of 56 adds and two shuffles per query tile
-            if (!DROP) sacc = mfma16(onesf, pf, sacc);
+            mc = grp4_max(mc);                               // log2 units
+            if (CH < NKT) {                                  // several chunks: running maximum, rescale what is accumulated
+                const float mn = fmaxf(m, mc);
+                const float sc = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+                if (c0 > 0) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oacc[c][r] *= sc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[r] *= sc;
+                    sum *= sc;
+                }
+                m = mn;
+            } else {
+                m = mc;
+            }
+            float csum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt) {
+                if (tt >= ct) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(p[tt][r] - m);
+                    p[tt][r] = e;
+                    if (DROP) csum += e;
+                }
+            }
+            if (DROP) {                                    // dropout on the probabilities (after softmax)
+                sum += grp4_sum(csum);
+                const unsigned long long sd = *seedp;
+                const unsigned rowid = (unsigned)((grp * G.g.nH + h) * N + nq);
+#pragma unroll
+                for (int tt = 0; tt < CH; ++tt) {
+                    if (tt >= ct) break;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        p[tt][r] *= keep_scale(sd, rowid, (unsigned)(s0 + (c0 + tt) * 16 + lg * 4 + r), G.drop_thresh, G.inv_keep);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < (CH + 1) / 2; ++s2) {
+                if (2 * s2 >= ct) break;
+                const bool tail = 2 * s2 + 1 >= ct;          // odd tile count of the (last) chunk: half-empty k-step
+                Frag8 pf;
+                pf.u[0] = pack2bf(p[2 * s2][0], p[2 * s2][1]);
+                pf.u[1] = pack2bf(p[2 * s2][2], p[2 * s2][3]);
+                pf.u[2] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][0], p[tail ? 0 : 2 * s2 + 1][1]);
+                pf.u[3] = tail ? 0u : pack2bf(p[tail ? 0 : 2 * s2 + 1][2], p[tail ? 0 : 2 * s2 + 1][3]);
+                const int kt = c0 + 2 * s2;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    Frag8 vf;   // A[hd c*16+lr][kappa] = V[key(kappa)][hd]
+                    vf.u2[0] = tr4(Vs, LDR, kt * 16 + lg * 4, c * 16, lr);
+                    vf.u2[1] = tail ? make_uint2(0u, 0u) : tr4(Vs, LDR, (kt + 1) * 16 + lg * 4, c * 16, lr);
+                    oacc[c] = mfma16(vf, pf, oacc[c]);
+                }
+                // without dropout the softmax denominator is the sum of the SAME bf16 probabilities the P.V product uses:
+                // seven idle-pipe MFMAs instead of 56 adds and two shuffles per query tile
+                if (!DROP) sacc = mfma16(onesf, pf, sacc);
+            }
         }
         if (!DROP) sum = sacc[0];
         // one part: the final o / lse.  Several: this key part's normalised o and its lse into the caller's scratch (part
