@@ -429,17 +429,22 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : ((NKT == 13 
     // q / dO / o fragments of all this wave's query tiles go out before the K / V staging loads (see attn_fwd_kernel)
     constexpr int NWAVES = DKV_THREADS(NKT) / 64;
     constexpr int PRE = (NKT + NWAVES - 1) / NWAVES;
+    // long windows (25 / 28 tiles, 4 query tiles per wave) load the fragments per tile instead: 36 VGPRs that decide
+    // between one and two 8-wave workgroups per CU (128-VGPR step)
+    constexpr bool PREF = NKT <= 16;
     const int nqt = (N + 15) >> 4;
-    Frag8 qpre[PRE][KS], dopre[PRE][KS], opre[PRE][KS];
+    Frag8 qpre[PREF ? PRE : 1][KS], dopre[PREF ? PRE : 1][KS], opre[PREF ? PRE : 1][KS];
+    if (PREF) {
 #pragma unroll
-    for (int ti = 0; ti < PRE; ++ti) {
-        const int qt = wave + nwaves * part + ti * nwaves * G.tsplit;
-        const int nq = qt * 16 + (lane & 15);
-        const bool qv = qt < nqt && nq < N;
-        const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
-        load_frags<HD>(qpre[ti], q + qrow * G.g.ldq + h * HD, qv, lane);
-        load_frags<HD>(dopre[ti], dout + qrow * G.g.ldo + h * HD, qv, lane);
-        load_frags<HD>(opre[ti], o + qrow * G.g.ldo + h * HD, qv, lane);
+        for (int ti = 0; ti < PRE; ++ti) {
+            const int qt = wave + nwaves * part + ti * nwaves * G.tsplit;
+            const int nq = qt * 16 + (lane & 15);
+            const bool qv = qt < nqt && nq < N;
+            const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
+            load_frags<HD>(qpre[ti], q + qrow * G.g.ldq + h * HD, qv, lane);
+            load_frags<HD>(dopre[ti], dout + qrow * G.g.ldo + h * HD, qv, lane);
+            load_frags<HD>(opre[ti], o + qrow * G.g.ldo + h * HD, qv, lane);
+        }
     }
     // K staged as K * scale * log2(e), additive terms in log2 units, MFMA started from them (see attn_fwd_kernel);
     // dQ = dS . K * scale then is (dS . K') / log2(e)
@@ -470,8 +475,14 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : ((NKT == 13 
         const bool qv = nq < N;
         const int64_t qrow = loop_row(G, row_s, grp, qv ? nq : 0);
         Frag8 qf[KS], dof[KS], of[KS];
+        if (PREF) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { qf[s] = qpre[ti][s]; dof[s] = dopre[ti][s]; of[s] = opre[ti][s]; }
+            for (int s = 0; s < KS; ++s) { qf[s] = qpre[PREF ? ti : 0][s]; dof[s] = dopre[PREF ? ti : 0][s]; of[s] = opre[PREF ? ti : 0][s]; }
+        } else {
+            load_frags<HD>(qf, q + qrow * G.g.ldq + h * HD, qv, lane);
+            load_frags<HD>(dof, dout + qrow * G.g.ldo + h * HD, qv, lane);
+            load_frags<HD>(of, o + qrow * G.g.ldo + h * HD, qv, lane);
+        }
         float dsm = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -489,63 +500,75 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT), (NKT > 16 ? 2 : ((NKT == 13 
         bf16_t* dsfrag = (tb && ds_out)
             ? ds_out + ((((int64_t)(grp - G.grp0) * G.g.nH + h) * nqt + qt) * NKT * 64 + lane) * 4 : nullptr;
 
-        Frag8 dsf[(NKT + 1) / 2];
-        if (NKT & 1) dsf[NKT / 2].u[2] = dsf[NKT / 2].u[3] = 0u;   // the missing second half of an odd tile count
-        float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            asm volatile("" ::: "memory");                   // keep the gathers one tile ahead, not all up front
-            const float4 bv = bnext;
-            if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
-            f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
-            const int key0 = t * 16 + lg * 4;
-            if (MODE == 0 || (t + 1) * 16 > Ns) {
-                const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
-                sacc[0] += ka.x; sacc[1] += ka.y; sacc[2] += ka.z; sacc[3] += ka.w;
-            }
-            if (masked) {
-                const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
-                sacc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
-                sacc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
-                sacc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
-                sacc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
-            }
-            Frag8 kf[KS], vf[KS];
-            lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
-            lds_frags<HD>(vf, Vs + (t * 16 + lr) * LDR, lane);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                sacc = mfma16(kf[s], qf[s], sacc);
-                pacc = mfma16(vf[s], dof[s], pacc);
-            }
-            float ds[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = __builtin_amdgcn_exp2f(sacc[r] + nL2);           // pad keys: exp2(-inf) = 0
-                float dp = pacc[r];
-                if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(s0 + key0 + r), G.drop_thresh, G.inv_keep);
-                ds[r] = pr * (dp - dsm);
-            }
-            dsf[t >> 1].u[(t & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
-            dsf[t >> 1].u[(t & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
-            if (dsfrag)
-                *reinterpret_cast<uint2*>(dsfrag + t * 256) =
-                    make_uint2(dsf[t >> 1].u[(t & 1) * 2 + 0], dsf[t >> 1].u[(t & 1) * 2 + 1]);
-        }
+        // long windows walk their key tiles in chunks of 14: the packed dS of a chunk feeds the dQ MFMAs right away, so
+        // 7 instead of 13-14 fragment registers stay live (with the per-tile fragment loads: 165 -> <= 128 VGPRs)
+        constexpr int CH = NKT > 16 ? 14 : NKT;
+        Frag8 dsf[(CH + 1) / 2];
         f32x4_t qacc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) qacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        float4 bnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tb) bnext = table_bias4(tp, linb_s + lg * 4);
 #pragma unroll
-        for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2)
+        for (int c0 = 0; c0 < NKT; c0 += CH) {
+            const int ct = (NKT - c0) < CH ? (NKT - c0) : CH;
+            if (ct & 1) dsf[ct / 2].u[2] = dsf[ct / 2].u[3] = 0u;   // the missing second half of an odd tile count
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                Frag8 kf;   // A[hd c*16+lr][kappa] = K[key(kappa)][hd]
-                kf.u2[0] = tr4(Ks, LDR, (2 * s2) * 16 + lg * 4, c * 16, lr);
-                kf.u2[1] = ((NKT & 1) && s2 == NKT / 2) ? make_uint2(0u, 0u)
-                                                         : tr4(Ks, LDR, (2 * s2 + 1) * 16 + lg * 4, c * 16, lr);
-                qacc[c] = mfma16(kf, dsf[s2], qacc[c]);
+            for (int tt = 0; tt < CH; ++tt) {
+                if (tt >= ct) break;
+                const int t = c0 + tt;
+                asm volatile("" ::: "memory");               // keep the gathers one tile ahead, not all up front
+                const float4 bv = bnext;
+                if (tb && t + 1 < NKT) bnext = table_bias4(tp, linb_s + (t + 1) * 16 + lg * 4);
+                f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
+                const int key0 = t * 16 + lg * 4;
+                if (MODE == 0 || (t + 1) * 16 > Ns) {
+                    const float4 ka = *reinterpret_cast<const float4*>(kadd + key0);
+                    sacc[0] += ka.x; sacc[1] += ka.y; sacc[2] += ka.z; sacc[3] += ka.w;
+                }
+                if (masked) {
+                    const int4 rk = *reinterpret_cast<const int4*>(rid_s + key0);
+                    sacc[0] += (rk.x != rq) ? -100.0f * LOG2E : 0.0f;
+                    sacc[1] += (rk.y != rq) ? -100.0f * LOG2E : 0.0f;
+                    sacc[2] += (rk.z != rq) ? -100.0f * LOG2E : 0.0f;
+                    sacc[3] += (rk.w != rq) ? -100.0f * LOG2E : 0.0f;
+                }
+                Frag8 kf[KS], vf[KS];
+                lds_frags<HD>(kf, Ks + (t * 16 + lr) * LDR, lane);
+                lds_frags<HD>(vf, Vs + (t * 16 + lr) * LDR, lane);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    sacc = mfma16(kf[s], qf[s], sacc);
+                    pacc = mfma16(vf[s], dof[s], pacc);
+                }
+                float ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(sacc[r] + nL2);           // pad keys: exp2(-inf) = 0
+                    float dp = pacc[r];
+                    if (DROP) dp *= keep_scale(sd, rowid, (unsigned)(s0 + key0 + r), G.drop_thresh, G.inv_keep);
+                    ds[r] = pr * (dp - dsm);
+                }
+                dsf[tt >> 1].u[(tt & 1) * 2 + 0] = pack2bf(ds[0], ds[1]);
+                dsf[tt >> 1].u[(tt & 1) * 2 + 1] = pack2bf(ds[2], ds[3]);
+                if (dsfrag)
+                    *reinterpret_cast<uint2*>(dsfrag + t * 256) =
+                        make_uint2(dsf[tt >> 1].u[(tt & 1) * 2 + 0], dsf[tt >> 1].u[(tt & 1) * 2 + 1]);
             }
+#pragma unroll
+            for (int s2 = 0; s2 < (CH + 1) / 2; ++s2) {
+                if (2 * s2 >= ct) break;
+                const bool tail = 2 * s2 + 1 >= ct;
+                const int kt = c0 + 2 * s2;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    Frag8 kf;   // A[hd c*16+lr][kappa] = K[key(kappa)][hd]
+                    kf.u2[0] = tr4(Ks, LDR, kt * 16 + lg * 4, c * 16, lr);
+                    kf.u2[1] = tail ? make_uint2(0u, 0u) : tr4(Ks, LDR, (kt + 1) * 16 + lg * 4, c * 16, lr);
+                    qacc[c] = mfma16(kf, dsf[s2], qacc[c]);
+                }
+            }
+        }
         if (qv) {
             bf16_t* drow = dq + sp * G.dq_ps + qrow * G.lddq + h * HD + lg * 4;    // several key parts: partial dq each
 #pragma unroll
