@@ -22,6 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+import torch.utils.checkpoint as _checkpoint
 
 from .. import ops
 from ..builder import BACKBONES
@@ -315,7 +316,14 @@ class BasicLayer(nn.Module):
 
     def forward_pending(self, x, branch=None, bscale=None):
         for blk in self.blocks:
-            x, branch, bscale = blk.forward_pending(x, branch, bscale)
+            if self.use_checkpoint and torch.is_grad_enabled():
+                # the reference wraps both halves of a block in checkpoint.checkpoint (:494-503): keep the block's
+                # input, drop its activations, recompute them in the backward.  The DropPath factors are the step's
+                # presets (_draw_drop_paths) and the Swin blocks have no dropout, so the recompute is exact; the
+                # kernel-side gradient sinks see ONE backward per layer as without it.
+                x, branch, bscale = _checkpoint.checkpoint(blk.forward_pending, x, branch, bscale, use_reentrant=False)
+            else:
+                x, branch, bscale = blk.forward_pending(x, branch, bscale)
         return x, branch, bscale
 
 

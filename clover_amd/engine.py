@@ -445,9 +445,6 @@ class CloverEngine:
             self._ft.done.clear()
             out = self.model.train_step(batch, None)
             self._backward(lambda: out['loss'].backward())
-            stale = self._stale_sinks()
-            if stale:
-                torch._foreach_zero_(stale)
         self.reducer.finish()
         self.optimizer_step()
         return out
@@ -475,6 +472,11 @@ class CloverEngine:
         for f, v in zip(self._CAPTURE_FIELDS, self._captures[sig]):
             setattr(self, f, v)
         self._active_sig = sig
+        # The previous optimizer step cleared the stale views of the geometry that ran THEN.  A first-touch slot that
+        # geometry writes and this one never does still holds that step's gradient: clear this geometry's stale slots
+        # before its first replay (afterwards zero_grads() keeps them clear while it stays active).
+        if self._stale_views:
+            torch._foreach_zero_(self._stale_views)
 
     def input_buffers(self):
         """The static input tensors of the active hipGraphs (None before capture): a loader that writes its host-to-device
@@ -697,6 +699,13 @@ class CloverEngine:
         lr = self.current_lr()
         self.lr_iter += 1
         self.step_count += 1
+        if self.graph is None:
+            # eager backward (step(), or a caller's own loss.backward() in the style of an OptimizerHook): first-touch
+            # slots this backward did not reach still hold the previous step's gradient — clear them before the norm
+            # (a captured geometry's unreached slots are cleared with the rest: _stale_views)
+            stale = self._stale_sinks()
+            if stale:
+                torch._foreach_zero_(stale)
         gscale = 1.0 / self.world                       # DDP averages the summed gradients
         grads = self.wire if self.wire is not None else [seg.flat_g for seg in self.segments]   # reduced gradients
         for g in grads:

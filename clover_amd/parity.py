@@ -128,9 +128,12 @@ def patch_embed(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps
     B, Cin, T, H, W = x.shape
     Cout = weight.shape[0]
     assert Cin == 3 and tuple(weight.shape[1:]) == (3, 2, 4, 4)
+    if T % 2 or H % 4 or W % 4:                            # right / bottom / back zero-pad to patch multiples (:679-680);
+        x = torch.nn.functional.pad(x, (0, -W % 4, 0, -H % 4, 0, -T % 2))      # PatchEmbed3D.pad has normally done it
+        B, Cin, T, H, W = x.shape
     Tp, Hp, Wp = T // 2, H // 4, W // 4
     # patches [M, 96] in the weight's (c, dt, dh, dw) column order: a pure layout op
-    patches = (rnd('input', x.float()).view(B, 3, Tp, 2, Hp, 4, Wp, 4).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    patches = (rnd('input', x.float()).reshape(B, 3, Tp, 2, Hp, 4, Wp, 4).permute(0, 2, 4, 6, 1, 3, 5, 7)
                .reshape(B * Tp * Hp * Wp, 96))
     z = sgemm(patches, rnd('weight', weight.detach().float().reshape(Cout, 96)), bias)
     if gamma is not None:

@@ -568,3 +568,77 @@ def test_first_touch_sink_semantics():
                 err = float((sink - rep * ref).abs().max())
                 assert err <= 2e-3 * rep * float(ref.abs().max()), (M, N, K, deferred, rep, err)
             assert float((bsink - 2 * dy.float().sum(0)).abs().max()) <= 2e-3 * float(dy.float().sum(0).abs().max()) + 1e-3
+
+
+class _TwoPathToy(torch.nn.Module):
+    """A recognizer-shaped toy whose batch geometry decides which Linear weights the step reaches: `a` always, `b` only
+    for the wide geometry (rows == 128) — the situation of ADVICE r3 (first-touch slots across a geometry switch)."""
+    CLV_ENCODE_KEYS = ()
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(11)
+        self.a = torch.nn.Linear(128, 128)
+        self.b = torch.nn.Linear(128, 128)
+        with torch.no_grad():
+            for lin in (self.a, self.b):
+                lin.weight.copy_(torch.randn(128, 128, generator=g) * 0.05)
+                lin.bias.zero_()
+        self.lazy_log_vars = True
+
+    def encode(self, imgs, video_cut=None, **kw):
+        from clover_amd import ops
+        x = imgs.to(torch.bfloat16)
+        y = ops.linear(x, self.a.weight, self.a.bias)
+        if imgs.shape[0] == 128:
+            y = y + ops.linear(x, self.b.weight, self.b.bias)
+        return y.float(), None
+
+    def contrastive_losses(self, emb, mlm_loss, gathered=None):
+        return dict(toy_loss=(emb * emb).mean())
+
+    def _parse_losses(self, losses, reduce=True):
+        from clover_amd.recognizers.base import BaseRecognizer
+        return BaseRecognizer._parse_losses(self, losses, reduce)
+
+    def train_step(self, data_batch, optimizer=None, **kw):
+        emb, _ = self.encode(data_batch['imgs'])
+        loss, log_vars = self._parse_losses(self.contrastive_losses(emb, None))
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
+
+
+@pytest.mark.parametrize('mode', ['eager', 'graph'])
+def test_first_touch_slots_across_a_geometry_switch(mode, monkeypatch):
+    """a first-touch slot that geometry A's backward writes and geometry B's never does must not carry A's
+    gradient into B's optimizer step.  Alternating A / B steps against an engine that clears every slab
+    (CLOVER_GRAD_FIRST_TOUCH=0): identical parameters afterwards, and `b`'s gradient slot is zero in every B step."""
+    from clover_amd.engine import CloverEngine
+    torch.manual_seed(3)
+    wide = dict(imgs=torch.randn(128, 128, device=DEV))
+    narrow = dict(imgs=torch.randn(64, 128, device=DEV))
+    final = {}
+    for ft in ('0', '1'):
+        monkeypatch.setenv('CLOVER_GRAD_FIRST_TOUCH', ft)
+        m = _TwoPathToy().to(DEV)
+        eng = CloverEngine(m, wide, lr=1e-2, weight_decay=0.0, grad_clip=0.0, max_iters=10 ** 9)
+        if ft == '1':
+            assert eng.first_touch_params >= 2 * 128 * 128, eng.first_touch_params
+        if mode == 'graph':
+            eng.dry_step(wide)
+            assert eng.capture(wide)
+        for it in range(3):
+            eng.step(wide)
+            if mode == 'graph':
+                # B's replayed backward must see a clean slot for `b` (checked between the replay and the optimizer)
+                sig = eng._signature(narrow)
+                if sig in eng._captures:
+                    eng._activate(sig)
+                    eng._graphed_forward_backward(narrow)
+                    assert float(m.b.weight.grad.abs().max()) == 0.0, it
+                    eng.zero_grads()
+            eng.step(narrow)
+        final[ft] = {n: p.detach().clone() for n, p in m.named_parameters()}
+        if mode == 'graph':
+            assert len(eng._captures) == 2
+    for n in final['0']:
+        assert torch.allclose(final['0'][n], final['1'][n], rtol=0, atol=1e-6), n

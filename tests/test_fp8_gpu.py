@@ -154,28 +154,27 @@ def test_patch_embed_fp8(C, B, T, HW, monkeypatch):
     assert rel(masked[sel].view(-1, C), mt.view(1, C).expand(int(wmap.sum()), C)) < 1e-2
 
 
+# |loss - oracle| of the fp8-forward step, B = 2, eval mode: ~2x the largest value measured over the three
+# configurations below (printed by the test; round 4 numbers in DESIGN.md section 5)
 FP8_LOSS_TOL = dict(mlm_loss=5e-2, nce_loss=2.5e-1, rank_t_tm_loss=2.5e-1, v_nce_loss=2.5e-1, rank_v_vm_loss=2.5e-1, loss=6e-1)
+# max|grad - oracle| / max|oracle| of gradients that cross every encoder (fp8 forward operands, bf16 backward)
+FP8_GRAD_TOL = 0.25
 
 
-@pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16)])
+@pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16), ('B', 32)])
 def test_fp8_step_losses_vs_oracle(variant, frames, monkeypatch):
-    """The step with fp8 forward GEMMs (Swin stages 1-3, text tower, fusion encoder) against the fp32 oracle, B = 2, eval
-    mode.  Tolerances: e4m3 operands carry 2^-4 relative rounding per element (32x the bf16 operand's), so the bound
-    asserted here is the bf16 path's (tests/test_step_gpu.py LOSS_TOL) scaled accordingly; the measured values are printed
-    and recorded in DESIGN.md."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+    """The step with fp8 forward GEMMs (Swin stages 0-3, text tower, fusion encoder) against the fp32 oracle, B = 2, eval
+    mode — BASELINE config 2's shapes, config 4's (Swin-B, 16 frames) and CONFIG 5's (Swin-B, 32 frames: (8,7,7) windows
+    with the (4,3,3) shift, 816-token fusion sequences).  Losses within FP8_LOSS_TOL, and the gradients of
+    test_step_gpu.FULL_GRAD_KEYS (7 / 10 parameters across the video encoder, the text tower, the fusion encoder and the
+    MLM head) within FP8_GRAD_TOL of the oracle's, relative to the gradient's max magnitude."""
+    import gutil
     import clover_amd
     from clover_amd import ops
-    from oracle import model as om
-    torch.manual_seed(4321)
-    cfg = bench.model_cfg(variant, frames)
+    from test_step_gpu import FULL_GRAD_KEYS
+    cfg, sd, batch, lv_ref, gref = gutil.full_size_oracle(variant, frames)
     m = clover_amd.build_model(cfg).eval()
-    P = {k: v.detach().float() for k, v in m.state_dict().items() if 'relative_position_index' not in k}
-    batch = bench.synthetic_batch(2, frames, 32, seed=77)
-    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
-    with torch.no_grad():
-        _, lv_ref = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
+    m.load_state_dict(sd)
     m = m.to(DEV)
     monkeypatch.setattr(ops, 'FP8', True)
     out = m.train_step({k: v.to(DEV) for k, v in batch.items()}, None)
@@ -185,5 +184,8 @@ def test_fp8_step_losses_vs_oracle(variant, frames, monkeypatch):
     for k, tol in FP8_LOSS_TOL.items():
         assert errs[k] <= tol, (k, lv[k], lv_ref[k])
     out['loss'].backward()
-    gn = sum(float(p.grad.float().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5
-    assert gn == gn and gn > 0
+    named = dict(m.named_parameters())
+    worst = {k: rel(named[k].grad, gref[k]) for k in FULL_GRAD_KEYS[variant]}
+    print(f'fp8 grad rel errors Swin-{variant} {frames}f', worst)
+    for k, e in worst.items():
+        assert e < FP8_GRAD_TOL, (k, e)

@@ -206,3 +206,27 @@ def test_parity_full_size_losses_vs_oracle(variant, frames, B):
     print(f'parity loss errors Swin-{variant} {frames}f B={B}', errs, {k: lv_ref[k] for k in LOSS_KEYS})
     for k in LOSS_KEYS:
         assert errs[k] <= PARITY_TOL, (k, lv[k], lv_ref[k])
+
+
+def test_parity_one_frame_image_batch(model):
+    """1-frame image batches (CC3M samples, SURVEY Appendix A: PatchEmbed3D zero-pads the depth 1 -> 2,
+    swin_transformer_3d.py:679-680) run in parity mode too — the patch embedding pads like the module does — and meet the
+    1e-3 bound against the oracle."""
+    from clover_amd import parity
+    batch = cf.cf_batch(2, frames=1, tag='par_img')
+    P = cf.cf_state(gutil.manifest())
+    with torch.no_grad():
+        _, lv_ref = om.parse_losses(om.forward_train(P, batch, cf.oracle_cfg_from(cf.tiny_model_cfg()), gather=False))
+        with parity.mode():
+            lv = model.train_step({k: v.to(DEV) for k, v in batch.items()}, None)['log_vars']
+            # the raw (un-padded) clip straight into the parity patch embedding: it pads by itself
+            x = batch['imgs'][:, 0].to(DEV)
+            pe = model.backbone.patch_embed
+            a, _ = parity.patch_embed(x, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, None, None, True,
+                                      pe.norm.eps)
+            b, _ = pe.tokens(x)
+    errs = {k: abs(lv[k] - lv_ref[k]) for k in LOSS_KEYS}
+    print('parity 1-frame loss errors', errs)
+    for k in LOSS_KEYS:
+        assert errs[k] <= PARITY_TOL, (k, lv[k], lv_ref[k])
+    assert a.shape == b.shape and torch.equal(a, b)
