@@ -10,7 +10,7 @@ R=$PWD
 rm -rf $R/gpurun_out/pmc_mfma; mkdir -p $R/gpurun_out/pmc_mfma
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
    --output-format csv -d $R/gpurun_out/pmc_mfma -o p -- \
-   python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_mfma/stdout.log 2>&1)
+   python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $R/gpurun_out/pmc_mfma/stdout.log 2>&1)
 echo "rc=$?"
 find gpurun_out/pmc_mfma -name '*kernel_trace.csv' -delete
 python3 - <<'PY' > gpurun_out/pmc_mfma.json
@@ -37,7 +37,7 @@ for k, d in acc.items():
                   mfma_insts_per_launch=round(m.get('SQ_INSTS_MFMA', 0)), gui_active_cycles=round(m['GRBM_GUI_ACTIVE']))
 import os
 res = dict(sorted(out.items(), key=lambda kv: -kv[1]['gui_active_cycles'] * kv[1]['launches']))
-res['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing')
+res['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ' + os.environ.get('BENCH_ARGS', ''))
 print(json.dumps(res, indent=1))
 PY
 head -c 1800 gpurun_out/pmc_mfma.json

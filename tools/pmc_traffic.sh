@@ -7,7 +7,7 @@ R=$PWD
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c; mkdir -p $R/gpurun_out/pmc_$c
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- \
-     python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmc_$c/stdout.log 2>&1)
+     python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $R/gpurun_out/pmc_$c/stdout.log 2>&1)
   echo "$c rc=$?"
   find gpurun_out/pmc_$c -name '*kernel_trace.csv' -delete
 done
