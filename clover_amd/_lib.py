@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -95,6 +95,8 @@ SIGNATURES = {
     'clv_adamw_step': (C.c_int, [_p] * 6 + [_i64] + [_f] * 9 + [_p]),
     'clv_gemm_nt_supported': (C.c_int, [_i64, _i32, _i32]),
     'clv_gemm_nt': (C.c_int, [_p] * 6 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p]),
+    'clv_gemm_nt_work_bytes': (C.c_int64, [_i64, _i32, _i32]),
+    'clv_gemm_nt_ex': (C.c_int, [_p] * 6 + [_i64, _i32, _i32, _i64, _i64, _i64, _i32, _p, _i64, _p]),
     'clv_transpose_batch': (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     'clv_layernorm_bwd_needs_reduce': (C.c_int, [_i64, _i32]),
     'clv_ln_reduce_batch': (C.c_int, [_p, _i32, _p]),

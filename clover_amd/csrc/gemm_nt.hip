@@ -23,6 +23,13 @@
 
 namespace {
 
+#ifdef GN_TRACE          // tools/probes/gemm_lab.cpp: per-workgroup cycle sums of the main loop's phases (wave 0)
+__device__ unsigned long long* gn_trace_buf = nullptr;
+#define GN_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define GN_T(var)
+#endif
+
 constexpr int GN_BK = 64;                                      // bf16 elements per stage row = 128 B (a full L2 line:
                                                                // 64-byte rows fetch at half the rate, tools/probes/dma_rate.cpp)
 constexpr int GN_MAX_BIAS = 3072;                              // bias row kept in LDS (as bf16)
@@ -32,6 +39,14 @@ __device__ __forceinline__ void gn_dma16(const bf16_t* src, unsigned lds_byte) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src), "s"(lds_byte)
+                 : "memory");
+}
+// One DMA piece (1 KiB) on its own: base (SGPR pair) + per-lane byte offset -> LDS byte address lds.
+__device__ __forceinline__ void gn_piece(unsigned lds, unsigned voff, const bf16_t* base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[b]\n\ts_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [lds] "s"(lds), [v] "v"(voff), [b] "s"(base)
                  : "memory");
 }
 template <int N_>
@@ -61,6 +76,17 @@ __device__ __forceinline__ void gn_dma_block<4>(unsigned lds, const unsigned (&v
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep)
         : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [b] "s"(base)
+        : "memory", "scc");
+}
+template <>
+__device__ __forceinline__ void gn_dma_block<1>(unsigned lds, const unsigned (&v)[1], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [b] "s"(base)
         : "memory", "scc");
 }
 template <>
@@ -126,7 +152,8 @@ __device__ __forceinline__ Frag8 gn_frag(const unsigned char* oper, int r, int k
 }
 
 enum { GN_EPI_NONE = CLV_GEMM_EPI_NONE, GN_EPI_BIAS = CLV_GEMM_EPI_BIAS, GN_EPI_GELU = CLV_GEMM_EPI_BIAS_GELU,
-       GN_EPI_DGELU = CLV_GEMM_EPI_DGELU, GN_EPI_GELUD = CLV_GEMM_EPI_BIAS_GELU_D, GN_EPI_MUL = CLV_GEMM_EPI_MUL };
+       GN_EPI_DGELU = CLV_GEMM_EPI_DGELU, GN_EPI_GELUD = CLV_GEMM_EPI_BIAS_GELU_D, GN_EPI_MUL = CLV_GEMM_EPI_MUL,
+       GN_EPI_PARTIAL = 6 };        // split-K slice: fp32 partial sums to the work slab, the epilogue runs in the reduce kernel
 
 __device__ __forceinline__ float gn_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float gn_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -162,12 +189,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                                                                 bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N,
                                                                 int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN,
                                                                 int nmblk, const float* __restrict__ sa = nullptr,
-                                                                const float* __restrict__ sb = nullptr, int pc = 1) {
+                                                                const float* __restrict__ sb = nullptr, int pc = 1,
+                                                                int splitk = 1, int rot_on = 0,
+                                                                float* __restrict__ partial = nullptr) {
     constexpr int WAVES = WAVES_M * WAVES_N, GN_THREADS = 64 * WAVES;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int P = GnOper<BM, WAVES>::PIECES + GnOper<BN, WAVES>::PIECES;     // DMA pieces per wave and stage
-    constexpr int S = TM * (TN / 2) * ((EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD) ? 2 : 1);      // store instructions per wave and epilogue
+    constexpr int S = TM * (TN / 2) * ((EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD || EPI == GN_EPI_PARTIAL) ? 2 : 1);      // store instructions per wave and epilogue
     constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD;
     static_assert((R - 2) * P + S <= 63, "vmcnt immediate");
     static_assert(TN % 2 == 0 && R >= 2, "tile shape");
@@ -185,35 +214,62 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     const int my_mblks = (nmblk - xr + pr - 1) / pr;
     const int my_tns = (tilesN - xc + pc - 1) / pc;
     const int my_tiles = my_mblks * my_tns;
-    if (slot >= my_tiles || my_tns <= 0) return;
+    // A work UNIT is a (tile, K slice) pair: splitk > 1 cuts the contraction of every tile into splitk slices of whole
+    // stages that run as units of their own (consecutive slots) and leave fp32 partial sums for the reduce kernel — the
+    // few-tile long-contraction layers (fc2 / fc1-dgrad of Swin stage 3, the fusion encoder, the text tower: 24-174 tiles
+    // of 128 x 128 against 512 workgroup slots, 48 stages each) fill the chip that way.
+    const int my_units = my_tiles * splitk;
+    if (slot >= my_units || my_tns <= 0) return;
     auto tile_m = [&](int t) { return xr + pr * (t / my_tns); };      // row block / column tile of this XCD's t-th tile
     auto tile_n = [&](int t) { return xc + pc * (t % my_tns); };
     const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
     const unsigned ring_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0]);
-    const int nst = K / GN_BK;
+    const int nst_all = K / GN_BK;
+    // stages [kb, kb + cnt) of unit u, and the stage its K walk starts at: with rot_on the tiles of an XCD start their
+    // walks at different stages (a Latin square over the XCD's row blocks x column tiles) and wrap around.  All the
+    // workgroups of a launch run in step, so without the rotation every A / B line of stage g is requested by its 6-9
+    // sharers AT ONCE and each of them waits for the miss (Infinity Cache / HBM: ~2 700 cycles against ~1 100 from L2);
+    // rotated, a line's first requester takes the miss and the others find it in L2 later.  fp32 sums over the stages in
+    // a different order per tile — deterministic for a given shape.
+    auto unit_span = [&](int u, int& kb, int& cnt, int& rot) {
+        const int t = u / splitk, z = u - t * splitk;
+        kb = (nst_all * z) / splitk;
+        cnt = (nst_all * (z + 1)) / splitk - kb;
+        rot = rot_on ? ((t / my_tns) + (t % my_tns) + z) % cnt : 0;
+        return t;
+    };
 
     GnOper<BM, WAVES> A;
     GnOper<BN, WAVES> B;
-    int qn = slot;                                            // tile whose stages are being issued
+    int qn = slot;                                            // unit whose stages are being issued
     int issued = 0;                                           // its stages issued so far
+    int icnt = 0, ikpos = 0;                                  // its stage count; position of the next issue inside its span
     unsigned ibase = ring_base;                               // ring slot (LDS byte address) the next issue goes to
     int inflight = 0;                                         // stages issued and not yet consumed
-    gn_init<BM, WAVES, 0>(A, a, (int64_t)tile_m(qn) * BM, M, lda, wave, lane);
-    gn_init<BN, WAVES, TN>(B, b, tile_n(qn) * BN, N, ldb, wave, lane);
-    auto issue_next = [&]() {                                 // one stage of the flat (tile, stage) sequence, if any is left
-        if (qn >= my_tiles) return;
+    auto init_unit = [&](int u) {
+        int kb, rot;
+        const int t = unit_span(u, kb, icnt, rot);
+        ikpos = rot;
+        gn_init<BM, WAVES, 0>(A, a + (int64_t)(kb + rot) * GN_BK, (int64_t)tile_m(t) * BM, M, lda, wave, lane);
+        gn_init<BN, WAVES, TN>(B, b + (int64_t)(kb + rot) * GN_BK, tile_n(t) * BN, N, ldb, wave, lane);
+    };
+    init_unit(qn);
+    auto issue_next = [&]() {                                 // one stage of the flat (unit, stage) sequence, if any is left
+        if (qn >= my_units) return;
         gn_issue<BM, WAVES>(A, ibase, wave);
         gn_issue<BN, WAVES>(B, ibase + A_BYTES, wave);
         ibase = ibase == ring_base + (R - 1) * STAGE ? ring_base : ibase + STAGE;
         ++inflight;
-        if (++issued == nst) {
+        if (++ikpos == icnt) {                                // wrap of a rotated walk: back to the span's first stage
+            ikpos = 0;
+            A.base -= (int64_t)icnt * GN_BK;
+            B.base -= (int64_t)icnt * GN_BK;
+        }
+        if (++issued == icnt) {
             issued = 0;
             qn += nslot;
-            if (qn < my_tiles) {
-                gn_init<BM, WAVES, 0>(A, a, (int64_t)tile_m(qn) * BM, M, lda, wave, lane);
-                gn_init<BN, WAVES, TN>(B, b, tile_n(qn) * BN, N, ldb, wave, lane);
-            }
+            if (qn < my_units) init_unit(qn);
         }
     };
 #pragma unroll
@@ -230,8 +286,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     }
     int cslot = 0;                                            // ring slot of the stage being multiplied
     int post_epi = 0;                                         // stage tops whose wait must also leave S stores in flight
+#ifdef GN_TRACE
+    unsigned long long tr_wait = 0, tr_bar = 0, tr_issue = 0, tr_comp = 0, tr_epi = 0, tr_stages = 0;
+    const unsigned long long tr_start = __builtin_amdgcn_s_memtime();
+#endif
 
-    for (int q = slot; q < my_tiles; q += nslot) {
+    for (int q = slot; q < my_units; q += nslot) {
+        int kb_q, nst, rot_q;
+        const int tq = unit_span(q, kb_q, nst, rot_q);
+        const int zq = q - tq * splitk;
         f32x4_t acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -241,6 +304,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
         for (int st = 0; st < nst; ++st) {
             // the oldest stage in flight must have landed; a full pipeline leaves R-2 younger stages (and, right after an
             // epilogue, its S stores) outstanding
+            GN_T(t0);
             if (inflight == R - 1) {
                 if (post_epi > 0) { gn_wait_vm<(R - 2) * P + S>(); --post_epi; }
                 else gn_wait_vm<(R - 2) * P>();
@@ -248,9 +312,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                 gn_wait_vm<0>();
                 post_epi = 0;
             }
+            GN_T(t1);
             __builtin_amdgcn_s_barrier();                     // everyone's pieces landed; slot of stage g-1 is drained
+            GN_T(t2);
             --inflight;
             issue_next();
+            GN_T(t3);
             const unsigned char* As = ring + cslot * STAGE;
             const unsigned char* Bs = As + A_BYTES;
             cslot = cslot == R - 1 ? 0 : cslot + 1;
@@ -297,13 +364,22 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
 #endif
             }
+#ifdef GN_TRACE
+            {
+                // the MFMAs have only been ISSUED: make the timestamp wait for the accumulators (a dependent no-op)
+                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][3]));
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                tr_wait += t1 - t0; tr_bar += t2 - t1; tr_issue += t3 - t2; tr_comp += t4 - t3; ++tr_stages;
+            }
+#endif
         }
+        GN_T(te0);
 
         // ---- epilogue of tile q, from registers.  Swapped MFMA + permuted B rows: acc[i][j][r] =
         // C[m0 + wm + i*16 + lr][n0 + wn + (j>>1)*32 + lg*8 + (j&1)*4 + r]: the accumulator pair (2h, 2h+1) of a lane is
         // 8 consecutive columns = one 16-byte store, and the 4 lanes of a row write 64 contiguous bytes per instruction
-        const int64_t m0 = (int64_t)tile_m(q) * BM;
-        const int n0 = tile_n(q) * BN;
+        const int64_t m0 = (int64_t)tile_m(tq) * BM;
+        const int n0 = tile_n(tq) * BN;
         const int nl = n0 + wn + lg * 8;                      // this lane's first column (of the pair h = 0)
         const bool edge = m0 + BM > M || n0 + BN > N;         // wave-uniform
 #ifdef GN_ABL_NOSTORE
@@ -331,6 +407,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
             for (int i = 0; i < TM; ++i) {
                 const int64_t m = m0 + wm + i * 16 + lr;
                 if (m >= M) continue;
+                if constexpr (EPI == GN_EPI_PARTIAL) {            // slice zq of the contraction: fp32 sums to slab zq
+                    float* pz = partial + ((int64_t)zq * M + m) * N + nh;
+                    *reinterpret_cast<f32x4_t*>(pz) = acc[i][2 * h];
+                    *reinterpret_cast<f32x4_t*>(pz + 4) = acc[i][2 * h + 1];
+                    continue;
+                }
                 const int64_t g = m * ldc + nh;
                 float v[8];
                 if constexpr (FP8) {
@@ -397,7 +479,391 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
         } else {
             post_epi = R - 1;
         }
+#ifdef GN_TRACE
+        tr_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
     }
+#ifdef GN_TRACE
+    if (gn_trace_buf && tid == 0) {
+        unsigned long long* o = gn_trace_buf + (size_t)blockIdx.x * 16;
+        o[0] = tr_wait; o[1] = tr_bar; o[2] = tr_issue; o[3] = tr_comp; o[4] = tr_epi; o[5] = tr_stages;
+        o[6] = __builtin_amdgcn_s_memtime() - tr_start; o[7] = tr_start;
+    }
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised version: NPROD producer waves issue ALL the LDS-DMA pieces, the WAVES_M x WAVES_N consumer waves only
+// read fragments and multiply.  Why (tools/probes/gemm_lab.cpp, per-stage cycle sums of gemm_nt_kernel): a wave is blocked
+// ~60 cycles per piece it issues — the CU's vector-memory path takes 1 KiB per ~16 cycles, i.e. 64 B/clk, and the 4-8 waves
+// of a workgroup burst all the pieces of a stage at once — and it feeds no MFMA meanwhile; then the memory path idles while
+// the waves multiply.  Issue and multiply each cost ~40 % of a stage, serially (64 x 128, 4 waves: 385 + 337 of 870 cycles;
+// 128 x 128: 596 + 697), whatever the order (pieces interleaved with the MFMAs, or half the waves issuing late: both
+// measured, both slower).  With the roles on different waves the matrix pipe and the memory path run side by side: a stage
+// costs max(pieces x ~16-20 cycles, MFMAs x 16 cycles) instead of the sum.
+// One barrier per stage for everybody: B_s says "stage s has landed and the slot of stage s-1 is free".  Producers wait
+// (counted vmcnt) for their pieces of stage s before B_s and issue stage s+R-1 after it; consumers read slot s % R after it.
+// Only the producers' vmcnt is ever waited on inside the pipeline, so the consumers' epilogue stores need no bookkeeping.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPROD, int R, int EPI>
+__global__ void __launch_bounds__(64 * (WAVES_M * WAVES_N + NPROD), 1)
+    gemm_ws_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ bias,
+                   const bf16_t* __restrict__ aux, bf16_t* __restrict__ c, bf16_t* __restrict__ c2, int64_t M, int N, int K,
+                   int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk, int pc, int splitk, float* __restrict__ partial) {
+    constexpr int NC = WAVES_M * WAVES_N, GN_THREADS = 64 * (NC + NPROD);
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int PA = BM / (8 * NPROD), PB = BN / (8 * NPROD), PP = PA + PB;     // pieces per producer wave and stage
+    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD;
+    static_assert((R - 2) * PP <= 63, "vmcnt immediate");
+    static_assert(TN % 2 == 0 && R >= 2 && BM % (8 * NPROD) == 0 && BN % (8 * NPROD) == 0, "tile shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[R * STAGE + (HAS_BIAS ? GN_MAX_BIAS * 2 : 0)];
+    bf16_t* bias_s = reinterpret_cast<bf16_t*>(ring + R * STAGE);
+
+    GN_T(t_entry);
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, lr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int pr = 8 / pc, xr = xcd / pc, xc = xcd - xr * pc;
+    const int my_mblks = (nmblk - xr + pr - 1) / pr;
+    const int my_tns = (tilesN - xc + pc - 1) / pc;
+    const int my_units = my_mblks * my_tns * splitk;
+    if (slot >= my_units || my_tns <= 0) return;
+    auto tile_m = [&](int t) { return xr + pr * (t / my_tns); };
+    auto tile_n = [&](int t) { return xc + pc * (t % my_tns); };
+    const int nst_all = K / GN_BK;
+    auto unit_span = [&](int u, int& kb, int& cnt) {
+        const int t = u / splitk, z = u - t * splitk;
+        kb = (nst_all * z) / splitk;
+        cnt = (nst_all * (z + 1)) / splitk - kb;
+        return t;
+    };
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&ring[0]);
+
+    if (wave >= NC) {
+        // ------------------------------------------------------------------ producer
+        const int pw = wave - NC;
+        GnOper<BM, NPROD> A;
+        GnOper<BN, NPROD> B;
+        int qn = slot, issued = 0, icnt = 0;
+        unsigned ibase = ring_base;
+        auto init_unit = [&](int u) {
+            int kb;
+            const int t = unit_span(u, kb, icnt);
+            gn_init<BM, NPROD, 0>(A, a + (int64_t)kb * GN_BK, (int64_t)tile_m(t) * BM, M, lda, pw, lane);
+            gn_init<BN, NPROD, TN>(B, b + (int64_t)kb * GN_BK, tile_n(t) * BN, N, ldb, pw, lane);
+        };
+        init_unit(qn);
+        auto issue_next = [&]() {
+            if (qn >= my_units) return;
+            const unsigned la = ibase + (unsigned)(pw * PA * 1024), lb = ibase + A_BYTES + (unsigned)(pw * PB * 1024);
+#pragma unroll
+            for (int j = 0; j < PA; ++j) gn_piece(la + j * 1024, A.voff[j], A.base);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) gn_piece(lb + j * 1024, B.voff[j], B.base);
+            A.base += GN_BK;
+            B.base += GN_BK;
+            ibase = ibase == ring_base + (R - 1) * STAGE ? ring_base : ibase + STAGE;
+            if (++issued == icnt) {
+                issued = 0;
+                qn += nslot;
+                if (qn < my_units) init_unit(qn);
+            }
+        };
+        int total = 0;                                        // stages of all this workgroup's units
+        for (int u = slot; u < my_units; u += nslot) {
+            int kb, cnt;
+            unit_span(u, kb, cnt);
+            total += cnt;
+        }
+        GN_T(t_init);
+#pragma unroll
+        for (int d = 0; d < R - 1; ++d) issue_next();
+        GN_T(t_primed);
+#ifdef GN_TRACE
+        unsigned long long tr_wait = 0, tr_issue = 0, t_first = 0;
+#endif
+        for (int s = 0; s < total; ++s) {
+            // stage s has landed when at most the R-2 younger stages are outstanding; near the end fewer are in flight
+            GN_T(t0);
+            if (total - 1 - s >= R - 2) gn_wait_vm<(R - 2) * PP>();
+            else gn_wait_vm<0>();
+            GN_T(t1);
+            __builtin_amdgcn_s_barrier();
+            GN_T(t2);
+            issue_next();
+#ifdef GN_TRACE
+            if (s == 0) t_first = t1;
+            tr_wait += t1 - t0;
+            tr_issue += __builtin_amdgcn_s_memtime() - t2;
+#endif
+        }
+#ifdef GN_TRACE
+        if (gn_trace_buf && pw == 0 && lane == 0) {
+            unsigned long long* o = gn_trace_buf + (size_t)blockIdx.x * 16;
+            o[0] = tr_wait; o[2] = tr_issue;
+            o[8] = t_init - t_entry; o[9] = t_primed - t_init; o[10] = t_first - t_primed;
+        }
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+    if (HAS_BIAS) {
+        for (int i = tid * 4; i < N; i += 64 * NC * 4) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + i);
+            *reinterpret_cast<uint2*>(bias_s + i) = make_uint2(pack2bf(bv.x, bv.y), pack2bf(bv.z, bv.w));
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): published by the first stage's barrier
+    }
+    int cslot = 0;
+#ifdef GN_TRACE
+    unsigned long long tr_bar = 0, tr_comp = 0, tr_epi = 0, tr_stages = 0;
+    const unsigned long long tr_start = __builtin_amdgcn_s_memtime();
+#endif
+    int total = 0;                                            // stages of all this workgroup's units (as the producers count)
+    for (int u = slot; u < my_units; u += nslot) {
+        int kb, cnt;
+        unit_span(u, kb, cnt);
+        total += cnt;
+    }
+    // The fragments of a stage (both k halves: (TM + TN) x 2 x 16 bytes per lane) are held in REGISTERS, double-buffered:
+    // while the MFMAs of stage s run on one set, the ds_reads of stage s+1 fill the other — a consumer wave is alone on its
+    // SIMD, so nothing else would cover the ~120 cycles between a ds_read and its first use (measured: 755 cycles per
+    // 512-cycle stage without this).  A wave arrives at barrier B_{s+1} once its reads of stage s have RETURNED, which is
+    // what frees slot s for the producers' next stage.
+    Frag8 fa0[2][TM], fb0[2][TN], fa1[2][TM], fb1[2][TN];
+    auto load_frags = [&](Frag8 (&fa)[2][TM], Frag8 (&fb)[2][TN]) {
+        const unsigned char* As = ring + cslot * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+        cslot = cslot == R - 1 ? 0 : cslot + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = gn_frag(Bs, wn + j * 16 + lr, ks * 4 + lg);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = gn_frag(As, wm + i * 16 + lr, ks * 4 + lg);
+        }
+    };
+    f32x4_t acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+    int q = slot, st = 0, gs = 0, nst, kb_q;
+    int tq = unit_span(q, kb_q, nst);
+    zero_acc();
+    auto epilogue = [&]() {
+        const int zq = q - tq * splitk;
+        GN_T(te0);
+        // ---- epilogue from registers (layout as in gemm_nt_kernel)
+        const int64_t m0 = (int64_t)tile_m(tq) * BM;
+        const int n0 = tile_n(tq) * BN;
+        const int nl = n0 + wn + lg * 8;
+#pragma unroll
+        for (int h = 0; h < TN / 2; ++h) {
+            const int nh = nl + h * 32;
+            if (nh >= N) continue;
+            float bn[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bn[e] = 0.f;
+            if (HAS_BIAS) {
+                const uint4 bv = *reinterpret_cast<const uint4*>(bias_s + nh);
+                const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bn[e] = (e & 1) ? gn_hi(bw[e >> 1]) : gn_lo(bw[e >> 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t m = m0 + wm + i * 16 + lr;
+                if (m >= M) continue;
+                if constexpr (EPI == GN_EPI_PARTIAL) {
+                    float* pz = partial + ((int64_t)zq * M + m) * N + nh;
+                    *reinterpret_cast<f32x4_t*>(pz) = acc[i][2 * h];
+                    *reinterpret_cast<f32x4_t*>(pz + 4) = acc[i][2 * h + 1];
+                    continue;
+                }
+                const int64_t g = m * ldc + nh;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bn[e];
+                if (EPI == GN_EPI_GELU) {
+                    *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                                   pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t r = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+                        v[e] = r.x; v[e + 1] = r.y;
+                    }
+                }
+                if (EPI == GN_EPI_GELUD) {
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t x2 = {v[e], v[e + 1]};
+                        f32x2_t cdf, ex;
+                        gelu_parts2(x2, cdf, ex);
+                        const f32x2_t r = x2 * cdf;
+                        const f32x2_t dd = __builtin_elementwise_fma(x2 * (f32x2_t){0.3989422804014327f, 0.3989422804014327f}, ex, cdf);
+                        v[e] = r.x; v[e + 1] = r.y;
+                        d[e] = dd.x; d[e + 1] = dd.y;
+                    }
+                    *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]),
+                                                                   pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+                }
+                if (EPI == GN_EPI_MUL || EPI == GN_EPI_DGELU) {
+                    const uint4 pa = *reinterpret_cast<const uint4*>(aux + g);
+                    const uint32_t pv[4] = {pa.x, pa.y, pa.z, pa.w};
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        if (EPI == GN_EPI_MUL) { v[e] *= gn_lo(pv[e >> 1]); v[e + 1] *= gn_hi(pv[e >> 1]); }
+                        else {
+                            const f32x2_t r = gelu_erf_grad2((f32x2_t){gn_lo(pv[e >> 1]), gn_hi(pv[e >> 1])});
+                            v[e] *= r.x; v[e + 1] *= r.y;
+                        }
+                    }
+                }
+                *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                                              pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+#ifdef GN_TRACE
+        tr_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
+    };
+    auto step = [&](Frag8 (&ca)[2][TM], Frag8 (&cb)[2][TN], Frag8 (&na)[2][TM], Frag8 (&nb)[2][TN]) {
+        GN_T(t0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this stage's fragments are in registers
+        if (gs + 1 < total) {
+            __builtin_amdgcn_s_barrier();                     // B_{gs+1}: the next stage has landed, this one's slot is free
+            load_frags(na, nb);
+        }
+        GN_T(t1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(cb[ks][j], ca[ks][i], acc[i][j]);   // swapped: D[n][m]
+#ifdef GN_TRACE
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][3]));
+        tr_bar += t1 - t0; tr_comp += __builtin_amdgcn_s_memtime() - t1; ++tr_stages;
+#endif
+        ++gs;
+        if (++st == nst) {
+            epilogue();
+            q += nslot;
+            st = 0;
+            if (q < my_units) {
+                tq = unit_span(q, kb_q, nst);
+                zero_acc();
+            }
+        }
+        return gs == total;
+    };
+    __builtin_amdgcn_s_barrier();                             // B_0
+#ifdef GN_TRACE
+    const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
+#endif
+    load_frags(fa0, fb0);
+    while (true) {
+        if (step(fa0, fb0, fa1, fb1)) break;
+        if (step(fa1, fb1, fa0, fb0)) break;
+    }
+#ifdef GN_TRACE
+    if (gn_trace_buf && tid == 0) {
+        unsigned long long* o = gn_trace_buf + (size_t)blockIdx.x * 16;
+        o[1] = tr_bar; o[3] = tr_comp; o[4] = tr_epi; o[5] = tr_stages;
+        o[6] = __builtin_amdgcn_s_memtime() - t_entry; o[7] = tr_start; o[11] = t_b0 - t_entry;
+    }
+#endif
+}
+
+// Second kernel of a split-K launch: c = epilogue(sum over the S slices of partial[s][m][n]).  One thread per 8 consecutive
+// columns (32-byte fp32 reads per slab, one 16-byte bf16 store); the slabs were written a kernel boundary ago, mostly still
+// in L2 / the Infinity Cache.
+template <int EPI>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int S, const float* __restrict__ bias,
+                                                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ c,
+                                                            bf16_t* __restrict__ c2, int64_t M, int N, int64_t ldc) {
+    const int n8 = N >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * n8) return;
+    const int64_t m = idx / n8;
+    const int nh = (int)(idx - m * n8) * 8;
+    const float* p = partial + m * N + nh;
+    const int64_t slab = M * (int64_t)N;
+    f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p), s1 = *reinterpret_cast<const f32x4_t*>(p + 4);
+    for (int z = 1; z < S; ++z) {
+        s0 += *reinterpret_cast<const f32x4_t*>(p + z * slab);
+        s1 += *reinterpret_cast<const f32x4_t*>(p + z * slab + 4);
+    }
+    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    constexpr bool HAS_BIAS = EPI == GN_EPI_BIAS || EPI == GN_EPI_GELU || EPI == GN_EPI_GELUD;
+    if (HAS_BIAS) {                                           // the bias as the bf16 operand the one-pass kernel uses
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + nh), b1 = *reinterpret_cast<const float4*>(bias + nh + 4);
+        const float bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(f2bf(bw[e]));
+    }
+    const int64_t g = m * ldc + nh;
+    if (EPI == GN_EPI_GELU) {
+        *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_t r = gelu_erf2((f32x2_t){v[e], v[e + 1]});
+            v[e] = r.x; v[e + 1] = r.y;
+        }
+    }
+    if (EPI == GN_EPI_GELUD) {
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_t x2 = {v[e], v[e + 1]};
+            f32x2_t cdf, ex;
+            gelu_parts2(x2, cdf, ex);
+            const f32x2_t r = x2 * cdf;
+            const f32x2_t dd = __builtin_elementwise_fma(x2 * (f32x2_t){0.3989422804014327f, 0.3989422804014327f}, ex, cdf);
+            v[e] = r.x; v[e + 1] = r.y;
+            d[e] = dd.x; d[e + 1] = dd.y;
+        }
+        *reinterpret_cast<uint4*>(c2 + g) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+    }
+    if (EPI == GN_EPI_MUL || EPI == GN_EPI_DGELU) {
+        const uint4 pa = *reinterpret_cast<const uint4*>(aux + g);
+        const uint32_t pv[4] = {pa.x, pa.y, pa.z, pa.w};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            if (EPI == GN_EPI_MUL) { v[e] *= gn_lo(pv[e >> 1]); v[e + 1] *= gn_hi(pv[e >> 1]); }
+            else {
+                const f32x2_t r = gelu_erf_grad2((f32x2_t){gn_lo(pv[e >> 1]), gn_hi(pv[e >> 1])});
+                v[e] *= r.x; v[e + 1] *= r.y;
+            }
+        }
+    }
+    *reinterpret_cast<uint4*>(c + g) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+
+int gn_launch_reduce(int epi, hipStream_t st, const float* partial, int S, const float* bias, const bf16_t* aux, bf16_t* c, bf16_t* c2,
+                     int64_t M, int N, int64_t ldc) {
+    const int64_t groups = M * (N >> 3);
+    const unsigned grid = (unsigned)((groups + 255) / 256);
+#define GN_GO(E) hipLaunchKernelGGL((splitk_reduce_kernel<E>), dim3(grid), dim3(256), 0, st, partial, S, bias, aux, c, c2, M, N, ldc)
+    switch (epi) {
+        case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
+        case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
+        case GN_EPI_GELU: GN_GO(GN_EPI_GELU); break;
+        case GN_EPI_DGELU: GN_GO(GN_EPI_DGELU); break;
+        case GN_EPI_GELUD: GN_GO(GN_EPI_GELUD); break;
+        case GN_EPI_MUL: GN_GO(GN_EPI_MUL); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef GN_GO
+    return clv_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -626,11 +1092,16 @@ __global__ void __launch_bounds__(256) transpose_batch_kernel(const bf16_t* __re
 template <int BM, int BN, int WAVES_M, int WAVES_N, int R>
 int gn_launch(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, const bf16_t* aux,
               bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk,
-              int pc = 1) {
+              int pc = 1, int splitk = 1, int rot = 0, float* partial = nullptr) {
 #define GN_GO(E)                                                                                                         \
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, R, E>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), 0, st, \
                        a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, tilesN, nmblk, (const float*)nullptr,             \
-                       (const float*)nullptr, pc)
+                       (const float*)nullptr, pc, splitk, rot, partial)
+    if (splitk > 1) {                                         // K slices leave fp32 partials; the epilogue runs in the reduce
+        GN_GO(GN_EPI_PARTIAL);
+        const int rc = clv_check_launch();
+        return rc != CLV_OK ? rc : gn_launch_reduce(epi, st, partial, splitk, bias, aux, c, c2, M, N, ldc);
+    }
     switch (epi) {
         case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
         case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
@@ -655,6 +1126,32 @@ int gn_launch_fp8(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const
         case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
         case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
         case GN_EPI_GELUD: GN_GO(GN_EPI_GELUD); break;
+        default: return CLV_ERR_UNSUPPORTED;
+    }
+#undef GN_GO
+    return clv_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPROD, int R>
+int gn_launch_ws(int epi, hipStream_t st, unsigned grid, const bf16_t* a, const bf16_t* b, const float* bias, const bf16_t* aux,
+                 bf16_t* c, bf16_t* c2, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tilesN, int nmblk,
+                 int pc, int splitk, float* partial) {
+#define GN_GO(E)                                                                                                          \
+    hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WAVES_M, WAVES_N, NPROD, R, E>), dim3(grid),                              \
+                       dim3(64 * (WAVES_M * WAVES_N + NPROD)), 0, st, a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, tilesN, \
+                       nmblk, pc, splitk, partial)
+    if (splitk > 1) {
+        GN_GO(GN_EPI_PARTIAL);
+        const int rc = clv_check_launch();
+        return rc != CLV_OK ? rc : gn_launch_reduce(epi, st, partial, splitk, bias, aux, c, c2, M, N, ldc);
+    }
+    switch (epi) {
+        case GN_EPI_NONE: GN_GO(GN_EPI_NONE); break;
+        case GN_EPI_BIAS: GN_GO(GN_EPI_BIAS); break;
+        case GN_EPI_GELU: GN_GO(GN_EPI_GELU); break;
+        case GN_EPI_DGELU: GN_GO(GN_EPI_DGELU); break;
+        case GN_EPI_GELUD: GN_GO(GN_EPI_GELUD); break;
+        case GN_EPI_MUL: GN_GO(GN_EPI_MUL); break;
         default: return CLV_ERR_UNSUPPORTED;
     }
 #undef GN_GO
@@ -715,16 +1212,68 @@ extern "C" int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K) {
     return M >= 1 && N >= 64 && N % 8 == 0 && N <= GN_MAX_BIAS && K >= 64 && K % GN_BK == 0;
 }
 
-extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
-                           int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream) {
+namespace {
+
+// Tile class and K split of one clv_gemm_nt call.
+struct GnPlan {
+    int BM, BN, W;
+    bool r2;
+    int splitk, rot;
+    int ws;                 // 0: gemm_nt_kernel; 1: gemm_ws_kernel<128,128, 8 consumers + 2 producers>; 2: <64,128, 4 + 2>
+};
+
+int gn_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Measured with cold weights (tools/probes/gemm_lab.cpp, us per launch):
+//  * few rows (M <= 1024: the text tower) — the wave-specialised 64 x 128 class (fc1 10.2 vs 11.2), and for a long
+//    contraction (K >= 1536: 48 tiles x 36-48 stages on 256 CUs) FOUR K slices as work units of their own + the reduce kernel
+//    (fc2 15.6 vs 25.9, qkv input gradient 14.3 vs 20.5).  The slices cost 4 fp32 slabs of M x N written and read once, which
+//    is why rows in the thousands never split: at M = 3 136 three slices of fc2 take 40 us against 29.
+//  * <= 256 tiles of 128 x 128 and K >= 1536 (fc2 / fc1-dgrad / qkv-dgrad / PatchMerging of Swin stage 3, fusion encoder):
+//    one workgroup per CU anyway, so the wave-specialised 128 x 128 class with its ring of 4 (fc2 s3 29.0 vs 33.9, fusion
+//    fc2 29.3 vs 34.9, dqkv s3 23.0 vs 27.2, merge s3 17.9 vs 20.3).
+//  * otherwise the one-kernel classes: 64 x 128 (<= 384 tiles, K >= 512) or 128 x 128 on eight waves, two workgroups per CU
+//    (the wave-specialised classes tie or lose there: 20.8 vs 19.7 for qkv s3, 34.5 vs 32.1 for fc2 s1).
+GnPlan gn_plan(int64_t M, int N, int K, bool allow_split) {
+    GnPlan p{128, 128, 4, false, 1, 0, 0};
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t tiles64 = ((M + 63) / 64) * ((N + 127) / 128);
+    if (K >= 512 && tiles128 <= 384) p.BM = 64;
+    // probe knobs, read per call (a few getenv: ~0.2 us of host time; the step replays hipGraphs)
+    const int w8 = gn_env_int("CLV_GEMM_W8", 1);
+    const int force_s = gn_env_int("CLV_GEMM_SPLITK", 0);                 // 0: auto, 1: off, n: n slices where allowed
+    const int ws = gn_env_int("CLV_GEMM_WS", 3);                          // bit 0: the 128 x 128 class, bit 1: the few-row class
+    const int nst = K / GN_BK;
+    p.rot = gn_env_int("CLV_GEMM_ROT", 0) && nst >= 3;                    // measured neutral (hot and cold operands): off
+    if ((ws & 2) && M <= 1024 && K >= 512 && tiles64 <= 256) {
+        p.ws = 2;
+        p.BM = 64;
+        if (allow_split && force_s != 1 && K >= 1536 && tiles64 <= 96) p.splitk = 4;
+    } else if ((ws & 1) && tiles128 <= 256 && K >= 1536) {
+        p.ws = 1;
+        p.BM = 128;
+    }
+    if (allow_split && force_s > 1 && nst / force_s >= 2 && K >= 1536 && tiles128 <= 256) p.splitk = force_s;
+    if (p.splitk > 1 && !p.ws) p.BM = 128;
+    if (p.BM == 128 && w8 && !p.ws) { p.W = 8; p.r2 = true; }
+    return p;
+}
+
+int gn_run(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M, int32_t N,
+           int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* work, int64_t work_bytes, void* stream) {
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return CLV_ERR_ARG;
     if (!clv_gemm_nt_supported(M, N, K)) return CLV_ERR_UNSUPPORTED;
     if ((lda & 7) || (ldb & 7) || (ldc & 7) || lda < K || ldb < K || ldc < N) return CLV_ERR_ARG;
-    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)c2) | ((uintptr_t)aux) | ((uintptr_t)bias)) & 15)
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)c2) | ((uintptr_t)aux) | ((uintptr_t)bias) |
+         ((uintptr_t)work)) & 15)
         return CLV_ERR_ARG;
     if ((epilogue == GN_EPI_BIAS || epilogue == GN_EPI_GELU || epilogue == GN_EPI_GELUD) && !bias) return CLV_ERR_ARG;
     if ((epilogue == GN_EPI_GELU || epilogue == GN_EPI_GELUD) && !c2) return CLV_ERR_ARG;
     if ((epilogue == GN_EPI_DGELU || epilogue == GN_EPI_MUL) && !aux) return CLV_ERR_ARG;
+    if (epilogue < GN_EPI_NONE || epilogue > GN_EPI_MUL) return CLV_ERR_UNSUPPORTED;
     const char* force = getenv("CLV_GEMM_TILE");             // probe override: "128x128", "256x128", "128x128w8"
     if (force && (!strcmp(force, "lean") || !strcmp(force, "lean64"))) {     // one tile per workgroup (measured 5-15 % behind)
         // 4 GiB of addressable operand per tile row block (32-bit lane offsets)
@@ -740,42 +1289,92 @@ extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, cons
         return gn_launch_lean<64>(epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux,
                                   (bf16_t*)c, (bf16_t*)c2, M, N, K, lda, ldb, ldc, tilesN, nmblk);
     }
-    int BM = 128, BN = 128, W = 4;
     // few tiles and a long contraction (Swin stage 3 proj / fc2 / merge, fusion and text encoders: <= 384 tiles of
     // 128 x 128 for 512 workgroup slots): 64 x 128 tiles double the workgroups that share the DMA latency
-    // (tools/probes/gemm_tiles.py; with the XCD column split the 450-tile qkv of stage 3 is faster on 128 x 128)
-    if (!force && K >= 512 && ((M + 127) / 128) * ((N + 127) / 128) <= 384) BM = 64;
+    // (tools/probes/gemm_tiles.py; with the XCD column split the 450-tile qkv of stage 3 is faster on 128 x 128).
     // 128 x 128 tiles run on EIGHT waves (64 x 32 each) with a ring of 2: two workgroups = 16 waves per CU instead of 8 —
     // 0-5 % on every shape of the class (gemm_tiles.py: fc1 s3 24.8 -> 23.6, fc1 s1 29.5 -> 27.9, dqkv s2 20.2 -> 19.7 us)
-    bool r2 = false;
-    static const int w8 = getenv("CLV_GEMM_W8") ? atoi(getenv("CLV_GEMM_W8")) : 1;
-    if (!force && BM == 128 && w8) { W = 8; r2 = true; }
+    GnPlan pl = gn_plan(M, N, K, work != nullptr);
+    if (pl.splitk > 1 && work_bytes < (int64_t)pl.splitk * M * N * 4) pl = gn_plan(M, N, K, false);
+    int BM = pl.BM, BN = pl.BN, W = pl.W;
+    bool r2 = pl.r2;
+    if (force && !strncmp(force, "ws", 2)) {                  // wave-specialised classes (probe names: ws128, ws128c8, ws64, ws64r3)
+        const int BMw = strstr(force, "64") ? 64 : 128;
+        const int tilesN = (N + 127) / 128;
+        const int nmblk = (int)((M + BMw - 1) / BMw);
+        const bool two = !strcmp(force, "ws64r3");            // 72 KiB ring: two workgroups per CU
+        const int pc = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
+        const int max_units_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc) * pl.splitk;
+        const int cap = 32 * (two ? 2 : 1);
+        const unsigned grid = (unsigned)(8 * (max_units_xcd < cap ? max_units_xcd : cap));
+        hipStream_t st = (hipStream_t)stream;
+#define GN_WARGS epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux, (bf16_t*)c, (bf16_t*)c2, M, N, K, \
+                 lda, ldb, ldc, tilesN, nmblk, pc, pl.splitk, (float*)work
+        if (!strcmp(force, "ws128")) return gn_launch_ws<128, 128, 2, 2, 2, 4>(GN_WARGS);     // 4 consumers (64 x 64) + 2 producers
+        if (!strcmp(force, "ws128c8")) return gn_launch_ws<128, 128, 2, 4, 2, 4>(GN_WARGS);   // 8 consumers (64 x 32) + 2 producers
+        if (!strcmp(force, "ws64")) return gn_launch_ws<64, 128, 2, 2, 1, 4>(GN_WARGS);       // 4 consumers (32 x 64) + 1 producer, ring of 4
+        if (!strcmp(force, "ws64p2")) return gn_launch_ws<64, 128, 2, 2, 2, 4>(GN_WARGS);
+        if (!strcmp(force, "ws64r3")) return gn_launch_ws<64, 128, 2, 2, 1, 3>(GN_WARGS);     // ring of 3: two workgroups per CU
+#undef GN_WARGS
+        return CLV_ERR_UNSUPPORTED;
+    }
     if (force) {
         BM = atoi(force);
         const char* x = strchr(force, 'x');
         if (x) BN = atoi(x + 1);
         const char* w = strchr(force, 'w');
         W = w ? atoi(w + 1) : (BM == 256 ? 8 : 4);
+        r2 = strstr(force, "r2") != nullptr;
     }
     const int tilesN = (N + BN - 1) / BN;
     const int nmblk = (int)((M + BM - 1) / BM);
-    // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's tiles
-    if (force && strstr(force, "r2")) r2 = true;
+    if (!force && pl.ws) {                                    // wave-specialised classes: one workgroup per CU
+        const int pcw = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
+        const int max_units = ((nmblk + 8 / pcw - 1) / (8 / pcw)) * ((tilesN + pcw - 1) / pcw) * pl.splitk;
+        const unsigned gridw = (unsigned)(8 * (max_units < 32 ? max_units : 32));
+        hipStream_t stw = (hipStream_t)stream;
+#define GN_WARGS epilogue, stw, gridw, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux, (bf16_t*)c, (bf16_t*)c2, M, N, \
+                 K, lda, ldb, ldc, tilesN, nmblk, pcw, pl.splitk, (float*)work
+        if (pl.ws == 1) return gn_launch_ws<128, 128, 2, 4, 2, 4>(GN_WARGS);
+        return gn_launch_ws<64, 128, 2, 2, 2, 4>(GN_WARGS);
+#undef GN_WARGS
+    }
+    // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's units
     const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : (BM == 128 && W == 8 && r2) ? 2 : 1;
     const int pc = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
-    const int max_tiles_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc);
-    const unsigned grid = (unsigned)(8 * (max_tiles_xcd < 32 * per_cu ? max_tiles_xcd : 32 * per_cu));
+    const int max_units_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc) * pl.splitk;
+    const unsigned grid = (unsigned)(8 * (max_units_xcd < 32 * per_cu ? max_units_xcd : 32 * per_cu));
     hipStream_t st = (hipStream_t)stream;
 #define GN_ARGS epilogue, st, grid, (const bf16_t*)a, (const bf16_t*)b, bias, (const bf16_t*)aux, (bf16_t*)c, (bf16_t*)c2, M, N, K, \
-                lda, ldb, ldc, tilesN, nmblk, pc
+                lda, ldb, ldc, tilesN, nmblk, pc, pl.splitk, pl.rot, (float*)work
     if (BM == 128 && BN == 128 && W == 4) return gn_launch<128, 128, 2, 2, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 256 && BN == 128 && W == 8) return gn_launch<256, 128, 4, 2, 3>(GN_ARGS);   // 48 KiB stages x 3
     if (BM == 128 && BN == 128 && W == 8 && r2) return gn_launch<128, 128, 2, 4, 2>(GN_ARGS);   // 32 KiB stages x 2, two WGs per CU
     if (BM == 128 && BN == 128 && W == 8) return gn_launch<128, 128, 2, 4, 4>(GN_ARGS);   // 32 KiB stages x 4
     if (BM == 64 && BN == 128 && W == 4) return gn_launch<64, 128, 2, 2, 3>(GN_ARGS);     // 24 KiB stages x 3, two WGs per CU
+    if (BM == 64 && BN == 128 && W == 8) return gn_launch<64, 128, 2, 4, 3>(GN_ARGS);     // the same ring on eight waves of 32 x 32
     if (BM == 64 && BN == 64 && W == 2) return gn_launch<64, 64, 1, 2, 3>(GN_ARGS);       // 16 KiB stages x 3, three WGs per CU
 #undef GN_ARGS
     return CLV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
+                           int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream) {
+    return gn_run(a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, epilogue, nullptr, 0, stream);
+}
+
+extern "C" int64_t clv_gemm_nt_work_bytes(int64_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || !clv_gemm_nt_supported(M, N, K)) return 0;
+    const GnPlan pl = gn_plan(M, N, K, true);
+    return pl.splitk > 1 ? (int64_t)pl.splitk * M * N * 4 : 0;
+}
+
+extern "C" int clv_gemm_nt_ex(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
+                              int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* work,
+                              int64_t work_bytes, void* stream) {
+    return gn_run(a, b, bias, aux, c, c2, M, N, K, lda, ldb, ldc, epilogue, work, work_bytes, stream);
 }
 
 extern "C" int clv_transpose_batch(const void* src_base, void* dst_base, const void* table, int32_t n_entries,

@@ -943,11 +943,18 @@ def mlp_gelu(x, w1, b1, w2, b2):
 GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU, GEMM_EPI_DGELU, GEMM_EPI_BIAS_GELU_D, GEMM_EPI_MUL = 0, 1, 2, 3, 4, 5
 
 
-def _gemm_kname(M, N, K, epi, fp8):
-    """Device-kernel name as rocprofv3 prints it (gemm_nt.hip: tile class by tile count, see clv_gemm_nt; K in 2-byte units
-    for the fp8 entry point)."""
-    small = K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) <= 384
-    if small:
+def _gemm_kname(M, N, K, epi, fp8, split=False):
+    """Device-kernel name as rocprofv3 prints it (gemm_nt.hip gn_plan: tile class by rows / tile count / contraction; K in
+    2-byte units for the fp8 entry point).  split: the K-slice launch (epilogue 6 = fp32 partials; its reduce kernel rides in
+    the same event bracket)."""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    t64 = ((M + 63) // 64) * ((N + 127) // 128)
+    ws = 0 if fp8 else int(os.environ.get('CLV_GEMM_WS', '3'))
+    if (ws & 2) and M <= 1024 and K >= 512 and t64 <= 256:
+        return f"gemm_ws_kernel<64, 128, 2, 2, 2, 4, {6 if split else epi}>"
+    if (ws & 1) and t128 <= 256 and K >= 1536:
+        return f"gemm_ws_kernel<128, 128, 2, 4, 2, 4, {6 if split else epi}>"
+    if K >= 512 and t128 <= 384:
         return f"gemm_nt_kernel<64, 128, 2, 2, 3, {epi}, {'true' if fp8 else 'false'}>"
     return f"gemm_nt_kernel<128, 128, 2, 4, 2, {epi}, {'true' if fp8 else 'false'}>"     # 8 waves (2 x 4), ring of 2
 
@@ -970,16 +977,19 @@ def gemm_nt(a, b, bias=None, aux=None, epilogue=GEMM_EPI_NONE, out=None):
         bias = bias.float()
     if aux is not None:
         assert aux.dtype == BF16 and aux.shape == (M, N) and aux.stride(1) == 1 and aux.stride(0) == c.stride(0)
+    L = _lib.lib()
+    wbytes = L.clv_gemm_nt_work_bytes(M, N, K)              # > 0: the contraction runs as slices (fp32 partials + a reduce)
+    work = torch.empty(wbytes, device=a.device, dtype=torch.uint8) if wbytes > 0 else None
     args = (_ptr(a), _ptr(b), _ptr(bias), _ptr(aux), _ptr(c), _ptr(c2), M, N, K, a.stride(0), b.stride(0), c.stride(0),
-            int(epilogue), _stream())
+            int(epilogue), _ptr(work), wbytes, _stream())
     if PROF is None:
-        check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
+        check(L.clv_gemm_nt_ex(*args), 'clv_gemm_nt_ex')
     else:
         nout = 2 if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else 1
         nin = 1 if epilogue in (GEMM_EPI_DGELU, GEMM_EPI_MUL) else 0
-        with _Timed(_gemm_kname(M, N, K, int(epilogue), False), 2 * M * N * K,
+        with _Timed(_gemm_kname(M, N, K, int(epilogue), False, split=wbytes > 0), 2 * M * N * K,
                     (M * K + N * K + (nout + nin) * M * N) * 2):
-            check(_lib.lib().clv_gemm_nt(*args), 'clv_gemm_nt')
+            check(L.clv_gemm_nt_ex(*args), 'clv_gemm_nt_ex')
     return (c, c2) if epilogue in (GEMM_EPI_BIAS_GELU, GEMM_EPI_BIAS_GELU_D) else c
 
 

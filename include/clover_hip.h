@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 7
+#define CLV_ABI_VERSION 8
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -375,6 +375,16 @@ int clv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, c
 int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
 int clv_gemm_nt(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
                 int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* stream);
+/* The same GEMM with a work buffer (ABI 8).  Few-tile long-contraction layers (K >= 1536 and <= 256 tiles of 128 x 128:
+ * fc2 / the fc1 input gradient of Swin stage 3 — swin_transformer_3d.py:262-268 —, of the fusion encoder and of the text
+ * tower) cut the contraction into slices that run as workgroups of their own: each slice leaves an fp32 partial sum in
+ * `work` ([slices][M][N]) and a second kernel adds the slices and applies the epilogue.  clv_gemm_nt_work_bytes(M, N, K) =
+ * the bytes that plan needs (0: the shape runs in one pass — then `work` may be NULL); with work == NULL or a buffer that
+ * is too small the call runs in one pass, as clv_gemm_nt does.  work: 16-byte aligned, used only inside the call. */
+int64_t clv_gemm_nt_work_bytes(int64_t M, int32_t N, int32_t K);
+int clv_gemm_nt_ex(const void* a, const void* b, const float* bias, const void* aux, void* c, void* c2, int64_t M,
+                   int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t epilogue, void* work,
+                   int64_t work_bytes, void* stream);
 /* Batched transposes of bf16 matrices in one launch (the engine's W^T shadows, refreshed after every optimizer step).
  * table: n_entries x {int64 src_off, dst_off (elements from src_base / dst_base); int32 rows, cols, tile_begin,
  * tiles_c} on the device; entry e covers ceil(rows/64) * tiles_c tiles starting at tile_begin (tiles_c =

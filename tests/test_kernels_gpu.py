@@ -479,6 +479,50 @@ def test_gemm_nt_epilogues(M, N, K):
     assert torch.equal(c4, c0)
 
 
+@pytest.mark.parametrize('M,N,K', [(3136, 768, 3072), (512, 768, 3072), (3648, 768, 3072), (300, 200, 1536), (1000, 136, 2048)])
+@pytest.mark.parametrize('splitk,rot', [('0', '1'), ('2', '0'), ('5', '1'), ('8', '1'), ('1', '1')])
+def test_gemm_nt_split_k_and_rotation(M, N, K, splitk, rot, monkeypatch):
+    """Few-tile long-contraction shapes: the contraction cut into K slices (fp32 partial slabs + the reduce kernel that
+    applies the epilogue) and the per-tile rotation of the K walk — every epilogue against fp32 torch and against the
+    one-pass launch (same operands; only the fp32 summation order differs).  splitk '0' = the planner's own choice,
+    'n' = forced n slices, '1' = off."""
+    F_ = torch.nn.functional
+    L = ops()
+    import clover_amd._lib as lib
+    a = rnd(M, K, seed=311).to(BF)
+    w = rnd(N, K, scale=0.05, seed=312).to(BF)
+    bias = rnd(N, scale=0.2, seed=313)
+    ref = a.float() @ w.float().t()
+    scale = ref.abs().max().item()
+    ag, wg, bg = a.to(DEV), w.to(DEV), bias.to(DEV)
+    prein = rnd(M, N, seed=314).to(BF)
+    monkeypatch.setenv('CLV_GEMM_SPLITK', '1')
+    monkeypatch.setenv('CLV_GEMM_ROT', '0')
+    assert lib.lib().clv_gemm_nt_work_bytes(M, N, K) == 0
+    base = dict(none=L.gemm_nt(ag, wg, epilogue=L.GEMM_EPI_NONE), bias=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS),
+                gelu=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS_GELU), gelud=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS_GELU_D),
+                dgelu=L.gemm_nt(ag, wg, aux=prein.to(DEV), epilogue=L.GEMM_EPI_DGELU),
+                mul=L.gemm_nt(ag, wg, aux=prein.to(DEV), epilogue=L.GEMM_EPI_MUL))
+    monkeypatch.setenv('CLV_GEMM_SPLITK', splitk)
+    monkeypatch.setenv('CLV_GEMM_ROT', rot)
+    wb = lib.lib().clv_gemm_nt_work_bytes(M, N, K)
+    if splitk not in ('0', '1'):
+        assert wb == int(splitk) * M * N * 4, (wb, splitk)
+    if splitk == '1':
+        assert wb == 0
+    got = dict(none=L.gemm_nt(ag, wg, epilogue=L.GEMM_EPI_NONE), bias=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS),
+               gelu=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS_GELU), gelud=L.gemm_nt(ag, wg, bg, epilogue=L.GEMM_EPI_BIAS_GELU_D),
+               dgelu=L.gemm_nt(ag, wg, aux=prein.to(DEV), epilogue=L.GEMM_EPI_DGELU),
+               mul=L.gemm_nt(ag, wg, aux=prein.to(DEV), epilogue=L.GEMM_EPI_MUL))
+    assert (got['none'].float().cpu() - ref).abs().max().item() < 6e-3 * scale
+    assert (got['bias'].float().cpu() - (ref + bias)).abs().max().item() < 6e-3 * scale
+    assert (got['gelu'][0].float().cpu() - F_.gelu(ref + bias)).abs().max().item() < 6e-3 * scale
+    for k in base:
+        for x, y in zip(got[k] if isinstance(got[k], tuple) else (got[k],), base[k] if isinstance(base[k], tuple) else (base[k],)):
+            # one bf16 ulp of the largest value: the two launches round the same fp32 sums taken in a different order
+            assert (x.float() - y.float()).abs().max().item() <= 8e-3 * max(1.0, y.float().abs().max().item()), k
+
+
 @pytest.mark.parametrize('M,C,Hd', [(8192, 192, 768), (12544, 384, 1536), (9000, 128, 512)])
 def test_linear_and_mlp_on_the_hip_gemm(M, C, Hd):
     """ops.linear / ops.mlp_gelu on shapes that take clv_gemm_nt (own_gemm_ok): forward, input gradient (through the
