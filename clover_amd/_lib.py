@@ -85,6 +85,8 @@ SIGNATURES = {
     'clv_colsum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p]),
     'clv_focal_ce_fwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
     'clv_focal_ce_bwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
+    'clv_focal_ce_fwd_ld': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i64, _f, _p]),
+    'clv_focal_ce_bwd_ld': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _f, _p]),
     'clv_infonce_work_floats': (C.c_int64, [_i32, _i32]),
     'clv_infonce_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _i32, _f, _f, _p]),
     'clv_infonce_bwd': (C.c_int, [_p] * 10 + [_i32, _i32, _i32, _f, _f, _p]),

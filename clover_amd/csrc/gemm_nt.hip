@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
     };
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) issue_next();
-    if (HAS_BIAS) {
+    const bool bias_lds = N <= GN_MAX_BIAS;                   // wider outputs (the MLM decoder) read their bias from global memory
+    if (HAS_BIAS && bias_lds) {
         // whole bias row -> LDS (bf16, as the GEMM's bf16 bias operand was) UNDER the first stages' DMA round trip (it
         // used to run, with a barrier, before the first DMA went out: ~1 us of serial latency per launch).  The first
         // stage's barrier below publishes it: its LDS writes are waited for here.
@@ -398,10 +399,17 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) gemm_nt_kernel(cons
                 sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
             }
             if (HAS_BIAS) {
-                const uint4 bv = *reinterpret_cast<const uint4*>(bias_s + nh);
-                const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+                if (bias_lds) {
+                    const uint4 bv = *reinterpret_cast<const uint4*>(bias_s + nh);
+                    const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bn[e] = (e & 1) ? gn_hi(bw[e >> 1]) : gn_lo(bw[e >> 1]);
+                    for (int e = 0; e < 8; ++e) bn[e] = (e & 1) ? gn_hi(bw[e >> 1]) : gn_lo(bw[e >> 1]);
+                } else {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias + nh), b1 = *reinterpret_cast<const float4*>(bias + nh + 4);
+                    const float bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bn[e] = bf2f(f2bf(bw[e]));
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1209,7 +1217,7 @@ extern "C" int clv_gemm_nt_fp8(const void* a8, const void* b8, const float* sa, 
 }
 
 extern "C" int clv_gemm_nt_supported(int64_t M, int32_t N, int32_t K) {
-    return M >= 1 && N >= 64 && N % 8 == 0 && N <= GN_MAX_BIAS && K >= 64 && K % GN_BK == 0;
+    return M >= 1 && N >= 64 && N % 8 == 0 && N <= (1 << 20) && K >= 64 && K % GN_BK == 0;
 }
 
 namespace {
@@ -1248,11 +1256,18 @@ GnPlan gn_plan(int64_t M, int N, int K, bool allow_split) {
     const int ws = gn_env_int("CLV_GEMM_WS", 3);                          // bit 0: the 128 x 128 class, bit 1: the few-row class
     const int nst = K / GN_BK;
     p.rot = gn_env_int("CLV_GEMM_ROT", 0) && nst >= 3;                    // measured neutral (hot and cold operands): off
-    if ((ws & 2) && M <= 1024 && K >= 512 && tiles64 <= 256) {
+    if ((ws & 2) && M <= 1024 && K >= 512 && tiles64 <= 256 && N <= GN_MAX_BIAS) {
         p.ws = 2;
         p.BM = 64;
-        if (allow_split && force_s != 1 && K >= 1536 && tiles64 <= 96) p.splitk = 4;
-    } else if ((ws & 1) && tiles128 <= 256 && K >= 1536) {
+        if (allow_split && force_s != 1 && K >= 1536 && tiles64 <= 96) {
+            // enough slices to put ~256 units on the chip, each >= 12 stages deep (measured: 4 slices for the text tower's
+            // 48-tile K = 3 072 layers; the MLM decoder's input gradient contracts over 30 528 vocabulary entries)
+            int sk = (int)((256 + tiles64 / 2) / tiles64);
+            sk = sk < 4 ? 4 : (sk > 16 ? 16 : sk);
+            while (sk > 2 && nst / sk < 12) --sk;
+            p.splitk = sk;
+        }
+    } else if ((ws & 1) && tiles128 <= 256 && K >= 1536 && N <= GN_MAX_BIAS) {
         p.ws = 1;
         p.BM = 128;
     }

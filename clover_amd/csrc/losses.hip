@@ -30,7 +30,7 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
 template <bool BF16>
 __global__ void __launch_bounds__(FC_THREADS) focal_fwd_kernel(
     const void* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ row_ce,
-    float* __restrict__ row_lse, float* __restrict__ sum_acc, float* __restrict__ cnt_acc, int V, float gamma) {
+    float* __restrict__ row_lse, float* __restrict__ sum_acc, float* __restrict__ cnt_acc, int V, int64_t ld, float gamma) {
     __shared__ float sh[8];
     const int64_t row = blockIdx.x;
     const int64_t lab = labels[row];
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(FC_THREADS) focal_fwd_kernel(
         if (threadIdx.x == 0) { row_ce[row] = 0.f; row_lse[row] = 0.f; }
         return;
     }
-    const int64_t base = row * V;
+    const int64_t base = row * ld;
     float m = -INFINITY;
     for (int j = threadIdx.x; j < V; j += FC_THREADS) m = fmaxf(m, ld_logit<BF16>(logits, base + j));
     m = block_reduce(m, sh, true);
@@ -64,10 +64,10 @@ template <bool BF16>
 __global__ void __launch_bounds__(FC_THREADS) focal_bwd_kernel(
     const void* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ row_ce,
     const float* __restrict__ row_lse, const float* __restrict__ count, const float* __restrict__ dloss,
-    void* __restrict__ dlogits, int V, float gamma) {
+    void* __restrict__ dlogits, int V, int64_t ld, float gamma) {
     const int64_t row = blockIdx.x;
     const int64_t lab = labels[row];
-    const int64_t base = row * V;
+    const int64_t base = row * ld;
     float coef = 0.f, lse = 0.f;
     if (lab >= 0) {
         const float ce = row_ce[row], pt = __expf(-ce), om = 1.f - pt;
@@ -76,9 +76,9 @@ __global__ void __launch_bounds__(FC_THREADS) focal_bwd_kernel(
         coef = dloss[0] * dl / count[0];
         lse = row_lse[row];
     }
-    for (int j = threadIdx.x; j < V; j += FC_THREADS) {
+    for (int j = threadIdx.x; j < (int)ld; j += FC_THREADS) {     // columns [V, ld) are padding: zero
         float g = 0.f;
-        if (lab >= 0) {
+        if (lab >= 0 && j < V) {
             const float p = __expf(ld_logit<BF16>(logits, base + j) - lse);
             g = coef * (p - (j == lab ? 1.f : 0.f));
         }
@@ -95,7 +95,7 @@ constexpr int FC_WIDE = 1024;
 
 __global__ void __launch_bounds__(FC_WIDE) focal_fwd_pairs_kernel(
     const unsigned* __restrict__ logits2, const int64_t* __restrict__ labels, float* __restrict__ row_ce,
-    float* __restrict__ row_lse, float* __restrict__ sum_acc, float* __restrict__ cnt_acc, int V, float gamma) {
+    float* __restrict__ row_lse, float* __restrict__ sum_acc, float* __restrict__ cnt_acc, int V, int64_t ld, float gamma) {
     __shared__ float shm[FC_WIDE / 64], shs[FC_WIDE / 64];
     const int64_t row = blockIdx.x;
     const int64_t lab = labels[row];
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(FC_WIDE) focal_fwd_pairs_kernel(
         return;
     }
     const int V2 = V >> 1;
-    const unsigned* r2 = logits2 + row * V2;
+    const unsigned* r2 = logits2 + row * (ld >> 1);
     float m = -INFINITY, sum = 0.f;
     for (int j = threadIdx.x; j < V2; j += FC_WIDE) {
         const unsigned w = r2[j];
@@ -139,19 +139,20 @@ __global__ void __launch_bounds__(FC_WIDE) focal_fwd_pairs_kernel(
 __global__ void __launch_bounds__(FC_WIDE) focal_bwd_pairs_kernel(
     const unsigned* __restrict__ logits2, const int64_t* __restrict__ labels, const float* __restrict__ row_ce,
     const float* __restrict__ row_lse, const float* __restrict__ count, const float* __restrict__ dloss,
-    unsigned* __restrict__ dlogits2, int V, float gamma) {
+    unsigned* __restrict__ dlogits2, int V, int64_t ld, float gamma) {
     const int64_t row = blockIdx.x;
     const int64_t lab = labels[row];
-    const int V2 = V >> 1;
-    unsigned* d2 = dlogits2 + row * V2;
+    const int V2 = V >> 1, L2 = (int)(ld >> 1);
+    unsigned* d2 = dlogits2 + row * L2;
     if (lab < 0) {
-        for (int j = threadIdx.x; j < V2; j += FC_WIDE) d2[j] = 0u;
+        for (int j = threadIdx.x; j < L2; j += FC_WIDE) d2[j] = 0u;
         return;
     }
+    for (int j = V2 + threadIdx.x; j < L2; j += FC_WIDE) d2[j] = 0u;      // padding columns [V, ld)
     const float ce = row_ce[row], pt = __expf(-ce), om = 1.f - pt;
     const float dl = (gamma == 0.f) ? 1.f : gamma * powf(om, gamma - 1.f) * pt * ce + powf(om, gamma);
     const float coef = dloss[0] * dl / count[0], lse = row_lse[row];
-    const unsigned* r2 = logits2 + row * V2;
+    const unsigned* r2 = logits2 + row * L2;
     const int labp = (int)(lab >> 1);
     for (int j = threadIdx.x; j < V2; j += FC_WIDE) {
         const unsigned w = r2[j];
@@ -454,44 +455,71 @@ bool focal_wide() {
 
 }  // namespace
 
-extern "C" int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
-                                float* row_lse, float* loss, float* count, int64_t rows, int32_t V, float gamma,
-                                void* stream) {
-    if (!logits || !labels || !row_ce || !row_lse || !loss || !count || rows <= 0 || V <= 0) return CLV_ERR_ARG;
+static int focal_fwd_impl(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce, float* row_lse,
+                          float* loss, float* count, int64_t rows, int32_t V, int64_t ld, float gamma, void* stream) {
+    if (!logits || !labels || !row_ce || !row_lse || !loss || !count || rows <= 0 || V <= 0 || ld < V) return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     // (loss, count) double as the {sum, count} accumulators (caller zeroes both); normalised in place
     // by the finish kernel
-    if (focal_wide() && is_bf16 && !(V & 1) && !(reinterpret_cast<uintptr_t>(logits) & 3))
+    if (focal_wide() && is_bf16 && !(V & 1) && !(ld & 1) && !(reinterpret_cast<uintptr_t>(logits) & 3))
         hipLaunchKernelGGL(focal_fwd_pairs_kernel, dim3((unsigned)rows), dim3(FC_WIDE), 0, st, (const unsigned*)logits,
-                           labels, row_ce, row_lse, loss, count, (int)V, gamma);
+                           labels, row_ce, row_lse, loss, count, (int)V, ld, gamma);
     else if (is_bf16)
         hipLaunchKernelGGL((focal_fwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
-                           row_ce, row_lse, loss, count, (int)V, gamma);
+                           row_ce, row_lse, loss, count, (int)V, ld, gamma);
     else
         hipLaunchKernelGGL((focal_fwd_kernel<false>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
-                           row_ce, row_lse, loss, count, (int)V, gamma);
+                           row_ce, row_lse, loss, count, (int)V, ld, gamma);
     int rc = clv_check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(1), 0, st, loss, (const float*)count);
     return clv_check_launch();
 }
 
+static int focal_bwd_impl(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
+                          const float* row_lse, const float* count, const float* dloss, void* dlogits, int64_t rows, int32_t V,
+                          int64_t ld, float gamma, void* stream) {
+    if (!logits || !labels || !row_ce || !row_lse || !count || !dloss || !dlogits || rows <= 0 || V <= 0 || ld < V)
+        return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (focal_wide() && is_bf16 && !(V & 1) && !(ld & 1) &&
+        !((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 3))
+        hipLaunchKernelGGL(focal_bwd_pairs_kernel, dim3((unsigned)rows), dim3(FC_WIDE), 0, st, (const unsigned*)logits,
+                           labels, row_ce, row_lse, count, dloss, (unsigned*)dlogits, (int)V, ld, gamma);
+    else if (is_bf16)
+        hipLaunchKernelGGL((focal_bwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, count, dloss, dlogits, (int)V, ld, gamma);
+    else
+        hipLaunchKernelGGL((focal_bwd_kernel<false>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
+                           row_ce, row_lse, count, dloss, dlogits, (int)V, ld, gamma);
+    return clv_check_launch();
+}
+
+extern "C" int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
+                                float* row_lse, float* loss, float* count, int64_t rows, int32_t V, float gamma,
+                                void* stream) {
+    return focal_fwd_impl(logits, is_bf16, labels, row_ce, row_lse, loss, count, rows, V, V, gamma, stream);
+}
+
 extern "C" int clv_focal_ce_bwd(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
                                 const float* row_lse, const float* count, const float* dloss, void* dlogits,
                                 int64_t rows, int32_t V, float gamma, void* stream) {
-    if (!logits || !labels || !row_ce || !row_lse || !count || !dloss || !dlogits || rows <= 0 || V <= 0)
-        return CLV_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (focal_wide() && is_bf16 && !(V & 1) && !((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 3))
-        hipLaunchKernelGGL(focal_bwd_pairs_kernel, dim3((unsigned)rows), dim3(FC_WIDE), 0, st, (const unsigned*)logits,
-                           labels, row_ce, row_lse, count, dloss, (unsigned*)dlogits, (int)V, gamma);
-    else if (is_bf16)
-        hipLaunchKernelGGL((focal_bwd_kernel<true>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
-                           row_ce, row_lse, count, dloss, dlogits, (int)V, gamma);
-    else
-        hipLaunchKernelGGL((focal_bwd_kernel<false>), dim3((unsigned)rows), dim3(FC_THREADS), 0, st, logits, labels,
-                           row_ce, row_lse, count, dloss, dlogits, (int)V, gamma);
-    return clv_check_launch();
+    return focal_bwd_impl(logits, is_bf16, labels, row_ce, row_lse, count, dloss, dlogits, rows, V, V, gamma, stream);
+}
+
+// The same on rows of stride ld >= V elements (logits and dlogits alike): the padded [rows, ld] score buffer the MLM decoder
+// GEMM writes (V = 30522 is not a multiple of 8; ld = 30528 is).  The backward ZEROES the padding columns [V, ld) of dlogits,
+// so that the decoder's input- and weight-gradient GEMMs can contract over ld.
+extern "C" int clv_focal_ce_fwd_ld(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce,
+                                   float* row_lse, float* loss, float* count, int64_t rows, int32_t V, int64_t ld,
+                                   float gamma, void* stream) {
+    return focal_fwd_impl(logits, is_bf16, labels, row_ce, row_lse, loss, count, rows, V, ld, gamma, stream);
+}
+
+extern "C" int clv_focal_ce_bwd_ld(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
+                                   const float* row_lse, const float* count, const float* dloss, void* dlogits,
+                                   int64_t rows, int32_t V, int64_t ld, float gamma, void* stream) {
+    return focal_bwd_impl(logits, is_bf16, labels, row_ce, row_lse, count, dloss, dlogits, rows, V, ld, gamma, stream);
 }
 
 extern "C" int64_t clv_infonce_work_floats(int32_t G, int32_t Dm) { return nce_work_floats(G, Dm); }

@@ -107,7 +107,15 @@ class _Segment:
         self.lr_mult = lr_mult
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
-        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]          # 16-byte aligned slots
+        # 16-byte aligned slots.  A parameter may ask for PHANTOM rows behind its last one (``_clv_pad_rows``: the MLM
+        # decoder's [30522, H] weight and [30522] bias -> 30528, a multiple of 64): the padded [rows + pad, ...] views of the
+        # fp32 data, the gradient and the bf16 shadow are what its GEMMs run on (16-byte row groups, no edge code); the
+        # phantom rows start at zero, receive zero gradients (the loss kernel zeroes the padding columns of d logits) and
+        # so stay zero under AdamW; the module-visible parameter is the unpadded view.
+        def slot_elems(p):
+            pad = int(getattr(p, '_clv_pad_rows', 0) or 0)
+            return p.numel() + pad * (p.numel() // p.shape[0] if p.dim() > 0 and p.shape[0] > 0 else 0)
+        sizes = [(slot_elems(p) + 3) // 4 * 4 for p in self.params]
         self.offsets = [0]
         for s in sizes:
             self.offsets.append(self.offsets[-1] + s)
@@ -124,6 +132,13 @@ class _Segment:
             p.grad = self.flat_g[off:off + p.numel()].view_as(p)
             p._clv_grad = p.grad                                                   # sink for ops.linear
             p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
+            pad = int(getattr(p, '_clv_pad_rows', 0) or 0)
+            if pad:
+                shp = (p.shape[0] + pad,) + tuple(p.shape[1:])
+                n = slot_elems(p)
+                p._clv_pad_weight = self.flat_p[off:off + n].view(shp)
+                p._clv_pad_grad = self.flat_g[off:off + n].view(shp)
+                p._clv_pad_shadow = self.shadow[off:off + n].view(shp)
         self.shadow.copy_(self.flat_p)
         self.shadow_t, self._t_table = None, None
         self._fused = []                     # fused views handed out (fused_view), for build_transposed()
@@ -134,18 +149,26 @@ class _Segment:
         applied as ONE [3H, H] GEMM) gets the transpose of the fused matrix, [H, 3H]; its members then need none of
         their own.  Called once, after the engine has made the fused views."""
         fused_members = {id(m) for f in self._fused if getattr(f, '_clv_want_t', False) for m in f._clv_members}
-        want = [(p, off, tuple(p.shape)) for p, off in zip(self.params, self.offsets)
+        def tshape(p):                       # a phantom-padded weight is transposed with its phantom rows
+            pad = int(getattr(p, '_clv_pad_rows', 0) or 0)
+            return (p.shape[0] + pad, p.shape[1])
+        want = [(p, off, tshape(p)) for p, off in zip(self.params, self.offsets)
                 if getattr(p, '_clv_want_t', False) and p.dim() == 2 and id(p) not in fused_members]
         want += [(f, f._clv_off, tuple(f.shape)) for f in self._fused if getattr(f, '_clv_want_t', False) and f.dim() == 2]
         if not want or not self.flat_p.is_cuda:
             return
         device = self.flat_p.device
-        self.shadow_t = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _, _ in want), device=device, dtype=torch.bfloat16)
+        self.shadow_t = torch.zeros(sum((sh[0] * sh[1] + 7) // 8 * 8 for _, _, sh in want), device=device, dtype=torch.bfloat16)
         entries, toff = [], 0
         for p, off, shape in want:
+            n = shape[0] * shape[1]
             entries.append((off, toff, shape[0], shape[1]))
-            p._clv_shadow_t = self.shadow_t[toff:toff + p.numel()].view(shape[1], shape[0])
-            toff += (p.numel() + 7) // 8 * 8
+            view = self.shadow_t[toff:toff + n].view(shape[1], shape[0])
+            if shape[0] != p.shape[0]:
+                p._clv_pad_shadow_t = view         # [cols, rows + pad]: only the padded kernels may take it
+            else:
+                p._clv_shadow_t = view
+            toff += (n + 7) // 8 * 8
         self._t_table = ops.transpose_table(entries, device)
         self.refresh_transposed()
 
@@ -292,7 +315,9 @@ class CloverEngine:
         sinks = {}                             # data_ptr -> (sink tensor, segment index, slab offset, numel)
         for si, seg in enumerate(self.segments):
             for q, off in zip(seg.params, seg.offsets):
-                sinks[q._clv_grad.data_ptr()] = (q._clv_grad, si, off, q.numel())
+                sk = getattr(q, '_clv_pad_grad', None)         # a phantom-padded parameter's kernels write the padded view
+                sk = sk if sk is not None else q._clv_grad
+                sinks[sk.data_ptr()] = (sk, si, off, sk.numel())
             for f in seg._fused:               # a fused view starts where its first member does: the view is what ops sees
                 sinks[f._clv_grad.data_ptr()] = (f._clv_grad, si, f._clv_off, f.numel())
         cpu_rng, gpu_rng = torch.get_rng_state(), torch.cuda.get_rng_state()

@@ -29,13 +29,24 @@ class BertLMPredictionHead(nn.Module):
         super().__init__()
         self.transform = BertPredictionHeadTransform(hidden_size)
         self.decoder = Linear(hidden_size, vocab_size, bias=True)
+        if vocab_size % 8:
+            # the decoder's GEMMs run on the step's own kernels with the vocabulary padded by phantom rows the engine appends
+            # to the slab slots (engine._Segment) — to a multiple of 64: 16-byte row groups for the scores, whole 64-deep
+            # stages for the input gradient, which contracts over the vocabulary and takes the transposed bf16 shadow
+            pad = -vocab_size % 64
+            self.decoder.weight._clv_pad_rows = pad
+            self.decoder.bias._clv_pad_rows = pad
+            self.decoder.weight._clv_want_t = True
         init_bert_weights(self)
         if os.path.isdir('bert-base-uncased'):
             load_pretrained_dir(self, 'bert-base-uncased', prefix='cls.predictions.')
         self.fp16_enabled = False
 
     def forward(self, hidden_states):
-        return self.decoder(self.transform(hidden_states))
+        h = self.transform(hidden_states)
+        if ops.mlm_decoder_ok(h, self.decoder.weight, self.decoder.bias):
+            return ops.mlm_decoder(h, self.decoder.weight, self.decoder.bias)
+        return self.decoder(h)
 
 
 @HEADS.register_module()

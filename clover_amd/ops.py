@@ -1691,23 +1691,86 @@ def patch_embed_stacked(x, weight, bias, gamma, beta, mask_token, vmask, eps=1e-
     return _PatchEmbed.apply(x, weight, bias, gamma, beta, mask_token, vmask, True, eps, True)[0]
 
 
+# --------------------------------------------------------------------------- MLM decoder (vocabulary projection)
+class _MLMDecoder(torch.autograd.Function):
+    """scores [R, V] = x [R, H] . W[V, H]^T + b — BertLMPredictionHead.decoder (mlm_itm_head.py:38-41; V = 30522) on the
+    step's own GEMM kernels.  V is not a multiple of 8, so every operand is used in its PHANTOM-PADDED form (engine:
+    ``_clv_pad_rows``): Vp = 30528 weight rows / bias entries, the phantom ones zero.  The scores are written into a
+    [R, Vp] buffer and handed out as its [R, V] view; the focal loss reads that view in place and returns its gradient the
+    same way, padding columns zeroed, so that
+        dx  = d scores [R, Vp] . W^T-shadow [H, Vp]^T      (clv_gemm_nt, K slices: the contraction is the vocabulary)
+        dW += d scores^T x                                  (the few-row weight-gradient kernel, into the padded slab view)
+    run over Vp with no edge code and no copy.  Engine-managed parameters only (the caller checks)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        _need_gpu(x2, weight)
+        Wp, bp = weight._clv_pad_shadow, bias._clv_pad_weight
+        Vp, V = Wp.shape[0], weight.shape[0]
+        R = x2.shape[0]
+        xb = _c(x2 if x2.dtype == BF16 else x2.to(BF16))
+        buf = torch.empty(R, Vp, device=x2.device, dtype=BF16)
+        gemm_nt(xb, Wp, bp, epilogue=GEMM_EPI_BIAS, out=buf)
+        ctx.save_for_backward(xb)
+        ctx.refs = (weight, bias)
+        return buf[:, :V]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        weight, bias = ctx.refs
+        Vp, V = weight._clv_pad_shadow.shape[0], weight.shape[0]
+        R = xb.shape[0]
+        if (dy.dtype == BF16 and dy.stride() == (Vp, 1) and dy.storage_offset() == 0 and dy.data_ptr() in PADDED_GRADS):
+            PADDED_GRADS.discard(dy.data_ptr())
+            dyp = dy.as_strided((R, Vp), (Vp, 1))                  # the focal backward's buffer, padding columns zeroed
+        else:
+            dyp = torch.zeros(R, Vp, device=dy.device, dtype=BF16)
+            dyp[:, :V].copy_(dy)
+        dx = gemm_nt(dyp, weight._clv_pad_shadow_t) if ctx.needs_input_grad[0] else None
+        linear_wgrad(dyp, xb, True, weight._clv_pad_grad, bias._clv_pad_grad)
+        weight._clv_ready()
+        bias._clv_ready()
+        return dx, None, None
+
+
+def mlm_decoder_ok(x, weight, bias):
+    """The own-kernel decoder needs the engine's phantom-padded views of both parameters (and is not the parity path)."""
+    return (not parity.enabled() and x.is_cuda and bias is not None
+            and all(hasattr(weight, a) for a in ('_clv_pad_shadow', '_clv_pad_shadow_t', '_clv_pad_grad'))
+            and hasattr(bias, '_clv_pad_weight') and hasattr(bias, '_clv_pad_grad')
+            and os.environ.get('CLOVER_OWN_DECODER', '1') == '1')
+
+
+def mlm_decoder(x, weight, bias):
+    """x [..., H] -> scores [..., V] (a view of a [rows, Vp] buffer)."""
+    y = _MLMDecoder.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+    return y.view(x.shape[:-1] + (weight.shape[0],))
+
+
 # --------------------------------------------------------------------------- focal MLM loss
+PADDED_GRADS = set()        # data_ptr of [rows, ld] gradient buffers whose padding columns the focal backward has zeroed
+
+
 class _FocalCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, gamma):
         _need_gpu(logits, labels)
-        lg = _c(logits)
-        assert lg.dim() == 2 and lg.dtype in (BF16, torch.float32)
+        assert logits.dim() == 2 and logits.dtype in (BF16, torch.float32)
+        # a [rows, V] view of a padded [rows, ld] score buffer (the MLM decoder's, ld = V rounded up to 8) is read in place
+        strided = logits.stride(1) == 1 and logits.stride(0) > logits.shape[1] and logits.stride(0) % 2 == 0
+        lg = logits if strided else _c(logits)
         lab = _c(labels.long())
         rows, V = lg.shape
+        ld = lg.stride(0)
         dev = lg.device
         row_ce = torch.empty(rows, device=dev, dtype=torch.float32)
         row_lse = torch.empty_like(row_ce)
         loss = torch.zeros(1, device=dev, dtype=torch.float32)
         count = torch.zeros(1, device=dev, dtype=torch.float32)
-        check(_lib.lib().clv_focal_ce_fwd(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
-                                          _ptr(loss), _ptr(count), rows, V, float(gamma), _stream()),
-              'clv_focal_ce_fwd')
+        check(_lib.lib().clv_focal_ce_fwd_ld(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
+                                             _ptr(loss), _ptr(count), rows, V, ld, float(gamma), _stream()),
+              'clv_focal_ce_fwd_ld')
         ctx.save_for_backward(lg, lab, row_ce, row_lse, count)
         ctx.gamma = float(gamma)
         return loss[0]
@@ -1716,12 +1779,15 @@ class _FocalCE(torch.autograd.Function):
     def backward(ctx, dloss):
         lg, lab, row_ce, row_lse, count = ctx.saved_tensors
         rows, V = lg.shape
+        ld = lg.stride(0)
         dl = _c(dloss.float().reshape(1))
-        dlogits = torch.empty_like(lg)
-        check(_lib.lib().clv_focal_ce_bwd(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
-                                          _ptr(count), _ptr(dl), _ptr(dlogits), rows, V, ctx.gamma, _stream()),
-              'clv_focal_ce_bwd')
-        return dlogits, None, None
+        buf = torch.empty(rows, ld, device=lg.device, dtype=lg.dtype)         # same row stride as the scores
+        check(_lib.lib().clv_focal_ce_bwd_ld(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
+                                             _ptr(count), _ptr(dl), _ptr(buf), rows, V, ld, ctx.gamma, _stream()),
+              'clv_focal_ce_bwd_ld')
+        if ld != V:
+            PADDED_GRADS.add(buf.data_ptr())           # its columns [V, ld) are zero: the decoder's backward contracts over ld
+        return buf[:, :V], None, None
 
 
 def focal_ce_masked(logits, labels, gamma=2.0):

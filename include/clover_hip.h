@@ -304,6 +304,13 @@ int clv_focal_ce_fwd(const void* logits, int32_t is_bf16, const int64_t* labels,
 int clv_focal_ce_bwd(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
                      const float* row_lse, const float* count, const float* dloss, void* dlogits,
                      int64_t rows, int32_t V, float gamma, void* stream);
+/* The same on rows of stride ld >= V elements (logits and dlogits alike): the padded score buffer of the MLM decoder (V =
+ * 30522 is not a multiple of 8, ld = 30528 is).  The backward zeroes the padding columns [V, ld) of dlogits. (ABI 8) */
+int clv_focal_ce_fwd_ld(const void* logits, int32_t is_bf16, const int64_t* labels, float* row_ce, float* row_lse,
+                        float* loss, float* count, int64_t rows, int32_t V, int64_t ld, float gamma, void* stream);
+int clv_focal_ce_bwd_ld(const void* logits, int32_t is_bf16, const int64_t* labels, const float* row_ce,
+                        const float* row_lse, const float* count, const float* dloss, void* dlogits, int64_t rows,
+                        int32_t V, int64_t ld, float gamma, void* stream);
 
 /* ------------------------------------------------------------------ exclusive InfoNCE + rank
  * ExclusiveNCEwithRankingLoss.forward after the all-gather

@@ -642,3 +642,42 @@ def test_first_touch_slots_across_a_geometry_switch(mode, monkeypatch):
             assert len(eng._captures) == 2
     for n in final['0']:
         assert torch.allclose(final['0'][n], final['1'][n], rtol=0, atol=1e-6), n
+
+
+def test_engine_own_decoder_equals_plain_autograd():
+    """BASELINE config 2's model (vocabulary 30522: not a multiple of 8) under the engine: the MLM decoder runs on the own
+    GEMM kernels over phantom-padded parameters (engine._Segment, ops.mlm_decoder); losses and the decoder / transform /
+    fusion gradients equal those of plain autograd on an identical model (which takes the generic Linear route), and the
+    phantom rows stay zero through optimizer steps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    from clover_amd.engine import CloverEngine
+    torch.manual_seed(21)
+    cfg = bench.model_cfg('T', 8)
+    m1 = clover_amd.build_model(cfg).to(DEV).eval()
+    m2 = clover_amd.build_model(cfg).to(DEV).eval()
+    m2.load_state_dict(m1.state_dict())
+    b = {k: v.to(DEV) for k, v in bench.synthetic_batch(2, 8, 32, seed=9).items()}
+    eng = CloverEngine(m1, b, lr=1e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 9)
+    dec = m1.mlm_head.predictions.decoder
+    assert hasattr(dec.weight, '_clv_pad_shadow') and dec.weight._clv_pad_shadow.shape[0] == 30528
+    o1 = m1.train_step(b, None)
+    o1['loss'].backward()
+    o2 = m2.train_step(b, None)
+    o2['loss'].backward()
+    for k in o2['log_vars']:
+        assert abs(o1['log_vars'][k] - o2['log_vars'][k]) < 2e-2, k
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for n in ['mlm_head.predictions.decoder.weight', 'mlm_head.predictions.decoder.bias',
+              'mlm_head.predictions.transform.dense.weight', 'multimodal_backbone.bert_encoder.layer.2.output.dense.weight']:
+        ref = p2[n].grad.float()
+        err = (p1[n].grad.float() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        assert err < 3e-2, (n, err)
+    assert float(dec.weight._clv_pad_grad[30522:].abs().max()) == 0.0
+    for _ in range(2):
+        eng.step(b)
+    assert float(dec.weight._clv_pad_weight[30522:].abs().max()) == 0.0 and float(dec.bias._clv_pad_weight[30522:].abs().max()) == 0.0
+    assert float(dec.weight._clv_pad_shadow_t[:, 30522:].abs().max()) == 0.0

@@ -994,3 +994,56 @@ def test_gemm_nt_gelu_grad_epilogues():
     out = ops().gemm_nt(dy.to(DEV), wt.to(DEV), aux=dg, epilogue=ops().GEMM_EPI_MUL)
     ref2 = (dy.float() @ wt.float().t()) * dg.float().cpu()
     assert rel(out, ref2) < 1e-2
+
+
+# ----------------------------------------------------------------------------- MLM decoder on the own kernels
+@pytest.mark.parametrize('R,V,H', [(256, 30522, 768), (64, 1003, 128), (40, 2050, 256)])
+def test_mlm_decoder_padded_vocabulary(R, V, H):
+    """ops.mlm_decoder + the strided focal loss (BertLMPredictionHead.decoder + SoftmaxFocalLossMultiClass,
+    mlm_itm_head.py:38-41, focal_loss.py:61-72) with the vocabulary padded to a multiple of 64 by phantom rows, as the
+    engine lays the parameters out: scores, loss, input gradient, weight / bias gradients against fp32 torch; the phantom
+    rows of the gradients stay exactly zero."""
+    F_ = torch.nn.functional
+    L = ops()
+    Vp = (V + 63) // 64 * 64
+    x = rnd(R, H, seed=601).to(BF)
+    w = rnd(V, H, scale=0.05, seed=602)
+    b = rnd(V, scale=0.1, seed=603)
+    labels = torch.full((R,), -100, dtype=torch.long)
+    sel = torch.arange(0, R, 3)
+    labels[sel] = torch.randint(0, V, (len(sel),), generator=torch.Generator().manual_seed(604))
+    # reference (bf16-rounded operands, fp32 math)
+    xr = x.float().requires_grad_()
+    wr = w.to(BF).float().requires_grad_()
+    br = b.to(BF).float().requires_grad_()
+    logits_r = xr @ wr.t() + br
+    ce = F_.cross_entropy(logits_r[sel], labels[sel], reduction='none')
+    loss_r = (((1 - torch.exp(-ce)) ** 2) * ce).mean()
+    loss_r.backward()
+    # engine-style padded views
+    weight = torch.nn.Parameter(w.to(DEV))
+    bias = torch.nn.Parameter(b.to(DEV))
+    wp = torch.zeros(Vp, H, device=DEV)
+    wp[:V] = w.to(DEV)
+    bp = torch.zeros(Vp, device=DEV)
+    bp[:V] = b.to(DEV)
+    weight._clv_pad_shadow = wp.to(BF)
+    weight._clv_pad_shadow_t = wp.to(BF).t().contiguous()
+    weight._clv_pad_grad = torch.zeros(Vp, H, device=DEV)
+    bias._clv_pad_weight = bp
+    bias._clv_pad_grad = torch.zeros(Vp, device=DEV)
+    weight._clv_ready = bias._clv_ready = lambda: None
+    xg = x.to(DEV).requires_grad_()
+    assert L.mlm_decoder_ok(xg, weight, bias)
+    scores = L.mlm_decoder(xg, weight, bias)
+    assert scores.shape == (R, V) and scores.stride() == (Vp, 1)
+    assert rel(scores, logits_r.detach()) < 1e-2
+    loss = L.focal_ce_masked(scores, labels.to(DEV), 2.0)
+    assert abs(loss.item() - loss_r.item()) < 2e-3 * max(1.0, abs(loss_r.item()))
+    loss.backward()
+    assert rel(xg.grad, xr.grad) < 3e-2, rel(xg.grad, xr.grad)
+    assert rel(weight._clv_pad_grad[:V], wr.grad) < 3e-2
+    assert rel(bias._clv_pad_grad[:V], br.grad) < 3e-2
+    if Vp > V:
+        assert float(weight._clv_pad_grad[V:].abs().max()) == 0.0 and float(bias._clv_pad_grad[V:].abs().max()) == 0.0
+    assert not L.PADDED_GRADS
