@@ -119,6 +119,8 @@ SIGNATURES = {
     'clv_sgemm_strided': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _p]),
     'clv_sgemm_nt': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _p]),
     'clv_attn_f32_fwd': (C.c_int, [_p] * 7 + [C.POINTER(ClvAttnGeom), _i32, _p]),
+    'clv_attn_f32_bwd_work_floats': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_f32_bwd': (C.c_int, [_p] * 12 + [C.POINTER(ClvAttnGeom), _p]),
 }
 
 _lib = None

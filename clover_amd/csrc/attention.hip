@@ -939,6 +939,141 @@ __global__ void __launch_bounds__(256) attn_f32_fwd_kernel(const float* __restri
     }
 }
 
+// fp32 backward of the same arithmetic (parity mode: gradients of the step checked against the reference's at fp32
+// tolerances, tests/test_parity_gpu.py).  Two passes over the score matrix, both recomputing it through the forward's index
+// helpers, so that every output element has ONE writer (only the relative-position table is accumulated with atomics):
+//   pass Q (one wave per query row i):  lse_i, delta_i = sum_j p_ij dp_ij with dp_ij = dO_i . v_j;  dS_ij = p_ij (dp_ij - delta_i);
+//                                       dq_i = scale sum_j dS_ij k_j;  d table[row(i, j)] += dS_ij
+//   pass K (one wave per key row j):    p_ij = exp(s_ij - lse_i), dS_ij as above from the stored lse / delta;
+//                                       dk_j = scale sum_i dS_ij q_i;  dv_j = sum_i p_ij dO_i
+template <bool PASS_K>
+__global__ void __launch_bounds__(256) attn_f32_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ dout,
+                                                           const float* __restrict__ table, const int* __restrict__ rid,
+                                                           const float* __restrict__ kmask, float* __restrict__ dq,
+                                                           float* __restrict__ dk, float* __restrict__ dv,
+                                                           float* __restrict__ dtable, float* __restrict__ lse_w,
+                                                           float* __restrict__ delta_w, Geom G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = G.g.N, hd = G.g.hd;
+    int* row_s = reinterpret_cast<int*>(smem);
+    int* lin_s = row_s + N;
+    int* rid_s = lin_s + N;
+    float* kadd_s = reinterpret_cast<float*>(rid_s + N);
+    float* p_s = kadd_s + N;                                    // [4 waves][2][N]: dS (and P in pass K)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gh = blockIdx.x, grp = gh / G.g.nH, h = gh - grp * G.g.nH;
+    const int wloc = (G.g.mode == 1) ? grp % G.nW : 0;
+    for (int n = tid; n < N; n += 256) {
+        row_s[n] = (int)tok_row(G, grp, n);
+        lin_s[n] = (G.g.mode == 1 && table) ? win_lin(G, n) : 0;
+        rid_s[n] = (G.g.mode == 1 && rid) ? rid[wloc * N + n] : 0;
+        kadd_s[n] = (G.g.mode == 0 && kmask) ? kmask[(int64_t)grp * N + n] : 0.f;
+    }
+    __syncthreads();
+    float* ds_w = p_s + wave * 2 * N;
+    float* pp_w = ds_w + N;
+    const int64_t stat0 = (int64_t)gh * N;
+    auto score = [&](int i, int j) {                              // s_ij exactly as the forward builds it
+        const float* qp = q + (int64_t)row_s[i] * G.g.ldq + h * hd;
+        const float* kp = k + (int64_t)row_s[j] * G.g.ldk + h * hd;
+        float dot = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + d);
+            const float4 b = *reinterpret_cast<const float4*>(kp + d);
+            dot = fmaf(a.x, b.x, dot); dot = fmaf(a.y, b.y, dot);
+            dot = fmaf(a.z, b.z, dot); dot = fmaf(a.w, b.w, dot);
+        }
+        float sc = dot * G.g.scale;
+        if (G.g.mode == 1 && table) sc += table[(int64_t)(lin_s[i] + G.tcst + G.tb0 - lin_s[j]) * G.g.nH + h];
+        if (G.g.mode == 1 && rid && rid_s[j] != rid_s[i]) sc += -100.0f;
+        return sc + kadd_s[j];
+    };
+    auto dotrow = [&](const float* a, const float* b) {
+        float dot = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(a + d);
+            const float4 y = *reinterpret_cast<const float4*>(b + d);
+            dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot);
+            dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
+        }
+        return dot;
+    };
+    if (!PASS_K) {
+        for (int qi = blockIdx.y * 4 + wave; qi < N; qi += 4 * gridDim.y) {
+            const float* dop = dout + (int64_t)row_s[qi] * G.g.ldo + h * hd;
+            float s[F32_MAXT], dp[F32_MAXT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < F32_MAXT; ++t) {
+                const int j = t * 64 + lane;
+                s[t] = -INFINITY;
+                dp[t] = 0.f;
+                if (j < N) {
+                    s[t] = score(qi, j);
+                    dp[t] = dotrow(dop, v + (int64_t)row_s[j] * G.g.ldv + h * hd);
+                    m = fmaxf(m, s[t]);
+                }
+            }
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < F32_MAXT; ++t)
+                if (t * 64 + lane < N) { s[t] = expf(s[t] - m); sum += s[t]; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            float delta = 0.f;
+#pragma unroll
+            for (int t = 0; t < F32_MAXT; ++t)
+                if (t * 64 + lane < N) { s[t] *= inv; delta = fmaf(s[t], dp[t], delta); }
+            delta = wave_sum(delta);
+            if (lane == 0) { lse_w[stat0 + qi] = m + logf(sum); delta_w[stat0 + qi] = delta; }
+#pragma unroll
+            for (int t = 0; t < F32_MAXT; ++t) {
+                const int j = t * 64 + lane;
+                if (j < N) {
+                    const float ds = s[t] * (dp[t] - delta);
+                    ds_w[j] = ds;
+                    if (G.g.mode == 1 && table && dtable)
+                        atomicAdd(dtable + (int64_t)(lin_s[qi] + G.tcst + G.tb0 - lin_s[j]) * G.g.nH + h, ds);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < hd) {
+                float acc = 0.f;
+                for (int j = 0; j < N; ++j) acc = fmaf(ds_w[j], k[(int64_t)row_s[j] * G.g.ldk + h * hd + lane], acc);
+                dq[(int64_t)row_s[qi] * G.g.ldq + h * hd + lane] = acc * G.g.scale;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (int kj = blockIdx.y * 4 + wave; kj < N; kj += 4 * gridDim.y) {
+            const float* vp = v + (int64_t)row_s[kj] * G.g.ldv + h * hd;
+#pragma unroll
+            for (int t = 0; t < F32_MAXT; ++t) {
+                const int i = t * 64 + lane;
+                if (i < N) {
+                    const float p = expf(score(i, kj) - lse_w[stat0 + i]);
+                    const float dpv = dotrow(dout + (int64_t)row_s[i] * G.g.ldo + h * hd, vp);
+                    pp_w[i] = p;
+                    ds_w[i] = p * (dpv - delta_w[stat0 + i]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < hd) {
+                float ak = 0.f, av = 0.f;
+                for (int i = 0; i < N; ++i) {
+                    ak = fmaf(ds_w[i], q[(int64_t)row_s[i] * G.g.ldq + h * hd + lane], ak);
+                    av = fmaf(pp_w[i], dout[(int64_t)row_s[i] * G.g.ldo + h * hd + lane], av);
+                }
+                dk[(int64_t)row_s[kj] * G.g.ldk + h * hd + lane] = ak * G.g.scale;
+                dv[(int64_t)row_s[kj] * G.g.ldv + h * hd + lane] = av;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------- long sequences: merging the parts
 // Forward: key part p delivered o_p = softmax over ITS keys . V_p and lse_p; over all keys
 //   lse = log sum_p exp(lse_p),   o = sum_p exp(lse_p - lse) o_p.
@@ -1350,5 +1485,35 @@ extern "C" int clv_attn_f32_fwd(const float* q, const float* k, const float* v, 
     while (pairs * ysplit < 2048 && ysplit * 8 <= G.g.N) ysplit *= 2;
     hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3(pairs, ysplit), dim3(256), lds, (hipStream_t)stream, q, k, v, o, bias, rid,
                        kmask, G, round_p);
+    return clv_check_launch();
+}
+
+extern "C" int64_t clv_attn_f32_bwd_work_floats(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G)) return 0;
+    return (int64_t)2 * G.g.groups * G.g.nH * G.g.N;
+}
+
+extern "C" int clv_attn_f32_bwd(const float* q, const float* k, const float* v, const float* dout, const float* bias,
+                                const int32_t* rid, const float* kmask, float* dq, float* dk, float* dv, float* dbias,
+                                float* work, const ClvAttnGeom* geom, void* stream) {
+    Geom G;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !work || !make_geom(geom, G)) return CLV_ERR_ARG;
+    if (bias && (G.g.mode != 1 || G.tlen == 0)) return CLV_ERR_ARG;
+    if (rid && G.g.mode != 1) return CLV_ERR_ARG;
+    if (G.g.N > F32_MAXT * 64 || G.drop_thresh) return CLV_ERR_UNSUPPORTED;      // eval-mode arithmetic, as the forward
+    const size_t lds = (size_t)G.g.N * (4 * 4 + 8 * 4);
+    const int pairs = G.g.groups * G.g.nH;
+    int ysplit = 1;
+    while (pairs * ysplit < 2048 && ysplit * 8 <= G.g.N) ysplit *= 2;
+    float* lse_w = work;
+    float* delta_w = work + (int64_t)pairs * G.g.N;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((attn_f32_bwd_kernel<false>), dim3(pairs, ysplit), dim3(256), lds, st, q, k, v, dout, bias, rid, kmask,
+                       dq, dk, dv, dbias, lse_w, delta_w, G);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_f32_bwd_kernel<true>), dim3(pairs, ysplit), dim3(256), lds, st, q, k, v, dout, bias, rid, kmask,
+                       dq, dk, dv, dbias, lse_w, delta_w, G);
     return clv_check_launch();
 }

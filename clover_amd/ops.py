@@ -801,7 +801,12 @@ class _FusedMLP(torch.autograd.Function):
             b2b = getattr(b2, '_clv_shadow', None)
             if b2b is None:
                 b2b = b2.to(BF16)
-        out = torch.nn.functional.linear(o1['y'], w2b, b2b)
+        if own_gemm_ok(o1['y'], w2b.shape[0], w2b.shape[1]) and os.environ.get('CLOVER_FC2_OWN', '1') == '1':
+            # fc2 of the stage-0 block (200 704 x 96 x 384): the last library GEMM of the video tower
+            out = gemm_nt(o1['y'], w2b, b2.detach() if b2 is not None else None,
+                          epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
+        else:
+            out = torch.nn.functional.linear(o1['y'], w2b, b2b)
         ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b, o1['xhat'])
         ctx.has_res = r is not None
         ctx.shape = a.shape
@@ -1175,10 +1180,9 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_sca
     f: optional dropout(p = x_dropout_p) then per-sample factor x_scale [B] on x (fused, see _LayerNorm).
     return_sum=True -> (y, f(x) + residual);  fork=True -> y is returned twice (y, y2 share storage; use one
     for each consumer and their gradients meet inside the LayerNorm backward kernel)."""
-    if parity.enabled():                      # fp32 storage: the same kernels in their fp32 instantiation, forward only
-        with torch.no_grad():
-            y, s, _ = _LayerNorm.apply(x.float(), residual.float() if residual is not None else None, weight, bias, eps,
-                                       bool(return_sum), x_scale, float(x_dropout_p), False)
+    if parity.enabled():                      # fp32 storage: the same kernels (forward and backward) in their fp32 instantiation
+        y, s, _ = _LayerNorm.apply(x.float(), residual.float() if residual is not None else None, weight, bias, eps,
+                                   bool(return_sum), x_scale, float(x_dropout_p), False)
         y = parity.rnd('act', y)
         s = parity.rnd('stream', s) if return_sum else None
         out = (y,) + ((s,) if return_sum else ()) + ((y,) if fork else ())
@@ -1293,8 +1297,7 @@ class _Gelu(torch.autograd.Function):
 def gelu(x):
     """erf GELU (nn.GELU / HF 'gelu'), bf16 or fp32 storage."""
     if parity.enabled():
-        with torch.no_grad():
-            return parity.rnd('act', _Gelu.apply(x.float()))
+        return parity.rnd('act', _Gelu.apply(x.float()))
     return _Gelu.apply(x)
 
 

@@ -11,7 +11,9 @@ kernels, but
   * attention is ``clv_attn_f32_fwd`` (fp32 VALU arithmetic through the index helpers the MFMA kernels use),
   * LayerNorm / GELU are the production kernels in their fp32-storage instantiation,
 so that what is compared with the reference at 1e-3 is the path's structure and index logic with the bf16 rounding
-taken out.  Forward only (losses); gradients are checked on the training path.
+taken out.  Forward AND backward: every op above has an fp32 backward on hand-written kernels (clv_sgemm_nt on transposed
+operands, clv_attn_f32_bwd, the LayerNorm / GELU backward kernels in fp32 storage), so the step's gradients are checked
+against the reference's at fp32 tolerances too (tests/test_parity_gpu.py).
 
 Switch: ``CLOVER_PARITY=1`` in the environment or ``with parity.mode():``.  ``round=`` re-injects single bf16 rounding
 sources (error isolation): 'act' (activations written by a kernel), 'stream' (the Swin residual stream),
@@ -92,31 +94,79 @@ def sgemm(a, b, bias=None):
     return c
 
 
+class _LinearP(torch.autograd.Function):
+    """y = x W^T + b on clv_sgemm_nt, forward and backward (dx = dy W, dW = dy^T x, db = sum dy: the same exact-f32 MFMA
+    kernel on transposed copies — parity mode is about values, not speed).  Gradients go back to autograd in fp32."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        w = rnd('weight', weight.detach().float())
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        return sgemm(x2, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx = sgemm(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None           # [M,N] . ([K,N])^T
+        dw = sgemm(dy.t().contiguous(), x2.t().contiguous()) if ctx.needs_input_grad[1] else None   # [N,M] . ([K,M])^T
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 def linear(x, weight, bias):
     K = weight.shape[1]
     x2 = x.float().reshape(-1, K)
-    y = sgemm(x2, rnd('weight', weight.detach().float()), bias)
+    y = _LinearP.apply(x2, weight, bias)
     return rnd('act', y).view(x.shape[:-1] + (weight.shape[0],))
 
 
+class _AttentionP(torch.autograd.Function):
+    """clv_attn_f32_fwd / clv_attn_f32_bwd on a packed fp32 q|k|v tensor; the relative-position table's gradient is returned
+    to autograd (fp32, the table's shape)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, rid, kmask, geom_kw, round_p):
+        g = ClvAttnGeom(**geom_kw)
+        Cdim = g.nH * g.hd
+        g.ldq = g.ldk = g.ldv = 3 * Cdim
+        g.ldo = Cdim
+        tab = table.detach().float().contiguous() if table is not None else None
+        km = kmask.float().contiguous() if kmask is not None else None
+        o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=torch.float32)
+        base = qkv.data_ptr()
+        check(_lib.lib().clv_attn_f32_fwd(C.c_void_p(base), C.c_void_p(base + 4 * Cdim), C.c_void_p(base + 8 * Cdim), _ptr(o),
+                                          _ptr(tab), _ptr(rid), _ptr(km), C.byref(g), int(round_p), _stream()),
+              'clv_attn_f32_fwd')
+        ctx.save_for_backward(qkv, tab, rid, km)
+        ctx.geom, ctx.has_table = g, table is not None
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, tab, rid, km = ctx.saved_tensors
+        g = ctx.geom
+        Cdim = g.nH * g.hd
+        do = do.float().contiguous()
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.zeros_like(tab) if tab is not None else None
+        L = _lib.lib()
+        work = torch.empty(L.clv_attn_f32_bwd_work_floats(C.byref(g)), device=qkv.device, dtype=torch.float32)
+        b, d = qkv.data_ptr(), dqkv.data_ptr()
+        check(L.clv_attn_f32_bwd(C.c_void_p(b), C.c_void_p(b + 4 * Cdim), C.c_void_p(b + 8 * Cdim), _ptr(do), _ptr(tab),
+                                 _ptr(rid), _ptr(km), C.c_void_p(d), C.c_void_p(d + 4 * Cdim), C.c_void_p(d + 8 * Cdim),
+                                 _ptr(dtab), _ptr(work), C.byref(g), _stream()), 'clv_attn_f32_bwd')
+        return dqkv, (dtab if ctx.has_table else None), None, None, None, None
+
+
 def attention(qkv, table, rid, kmask, geom_kw):
-    """clv_attn_f32_fwd on a packed fp32 [..., 3*nH*hd] q|k|v tensor -> o fp32 [..., nH*hd]."""
+    """clv_attn_f32_fwd (+ its fp32 backward) on a packed fp32 [..., 3*nH*hd] q|k|v tensor -> o fp32 [..., nH*hd]."""
     assert qkv.is_cuda
     qkv = qkv.float().contiguous()
-    g = ClvAttnGeom(**geom_kw)
-    if g.dropout_p:
-        raise NotImplementedError('parity mode is an eval-mode forward (no attention dropout)')
-    Cdim = g.nH * g.hd
-    assert qkv.shape[-1] == 3 * Cdim
-    g.ldq = g.ldk = g.ldv = 3 * Cdim
-    g.ldo = Cdim
-    tab = table.detach().float().contiguous() if table is not None else None
-    km = kmask.float().contiguous() if kmask is not None else None
-    o = torch.empty(qkv.shape[:-1] + (Cdim,), device=qkv.device, dtype=torch.float32)
-    base = qkv.data_ptr()
-    check(_lib.lib().clv_attn_f32_fwd(C.c_void_p(base), C.c_void_p(base + 4 * Cdim), C.c_void_p(base + 8 * Cdim), _ptr(o),
-                                      _ptr(tab), _ptr(rid), _ptr(km), C.byref(g), int('prob' in STATE['round']),
-                                      _stream()), 'clv_attn_f32_fwd')
+    if geom_kw.get('dropout_p'):
+        raise NotImplementedError('parity mode is an eval-mode pass (no attention dropout)')
+    o = _AttentionP.apply(qkv, table, rid, kmask, geom_kw, 'prob' in STATE['round'])
     return rnd('act', o)
 
 
@@ -135,7 +185,7 @@ def patch_embed(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps
     # patches [M, 96] in the weight's (c, dt, dh, dw) column order: a pure layout op
     patches = (rnd('input', x.float()).reshape(B, 3, Tp, 2, Hp, 4, Wp, 4).permute(0, 2, 4, 6, 1, 3, 5, 7)
                .reshape(B * Tp * Hp * Wp, 96))
-    z = sgemm(patches, rnd('weight', weight.detach().float().reshape(Cout, 96)), bias)
+    z = _LinearP.apply(patches, weight.reshape(Cout, 96), bias)          # rounds the weight itself when asked to
     if gamma is not None:
         z = ops.layer_norm(z, gamma, beta, eps)            # parity branch of ops.layer_norm: fp32 kernel
     clean = rnd('act', z).view(B, Tp, Hp, Wp, Cout)
@@ -144,7 +194,7 @@ def patch_embed(x, weight, bias, gamma, beta, mask_token, vmask, want_clean, eps
         mh, mw = vmask.shape[-2], vmask.shape[-1]
         w = vmask.reshape(B, 1, mh, 1, mw, 1).expand(B, Tp, mh, Hp // mh, mw, Wp // mw).reshape(B, Tp, Hp, Wp, 1)
         w = w.to(torch.float32)
-        masked = rnd('act', z.view(B, Tp, Hp, Wp, Cout) * (1.0 - w) + mask_token.detach().float().reshape(1, 1, 1, 1, Cout) * w)
+        masked = rnd('act', z.view(B, Tp, Hp, Wp, Cout) * (1.0 - w) + mask_token.float().reshape(1, 1, 1, 1, Cout) * w)
     if stacked:
         return torch.cat([clean, masked], 0)
     return (clean if want_clean else None), masked

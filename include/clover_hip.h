@@ -417,7 +417,7 @@ int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shado
  * The reference's CPU path is fp32 (north_star: "match the reference mmaction CPU path ... losses within 1e-3").  The
  * training path above computes on bf16 MFMA operands; these two entry points let the SAME host graph (registered modules,
  * window geometry, token maps, bias-table indexing, masks, heads, losses) run with fp32 storage and fp32 arithmetic so the
- * step losses can be asserted at 1e-3 against the reference goldens.  Forward only.
+ * step losses can be asserted at 1e-3 against the reference goldens, and the gradients at fp32 tolerances.
  *
  * clv_sgemm_nt: C[M][N] (ldc) = A[M][K] (lda) . B[N][K]^T (ldb) + bias[N] — every nn.Linear of the path
  *   (swin_transformer_3d.py:257-259,361-366,527; transformers BertSelfAttention / BertIntermediate / BertOutput as called
@@ -435,6 +435,14 @@ int clv_sgemm_strided(const float* A, const float* B, const float* bias, float* 
                       int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc, int32_t accumulate, void* stream);
 int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias, const int32_t* rid,
                      const float* kmask, const ClvAttnGeom* geom, int32_t round_p, void* stream);
+/* Backward of clv_attn_f32_fwd in fp32 (ABI 8): dq / dk / dv with the strides of q / k / v, dbias (may be NULL) ACCUMULATED
+ * into the [rows, nH] relative-position table gradient (WindowAttention3D, swin_transformer_3d.py:375-400; HF
+ * BertSelfAttention in mode 0), work = clv_attn_f32_bwd_work_floats(geom) floats (lse and delta per (group, head, query)).
+ * Two recompute passes, one writer per output element: parity mode checks the step's gradients with it. */
+int64_t clv_attn_f32_bwd_work_floats(const ClvAttnGeom* geom);
+int clv_attn_f32_bwd(const float* q, const float* k, const float* v, const float* dout, const float* bias,
+                     const int32_t* rid, const float* kmask, float* dq, float* dk, float* dv, float* dbias, float* work,
+                     const ClvAttnGeom* geom, void* stream);
 
 /* ------------------------------------------------------------------ fp8 forward GEMMs (BASELINE config 5)
  * "fp8 MFMA QKV / patch-proj path": the forward GEMM of a Linear on OCP e4m3 operands with one fp32 scale per row of

@@ -230,3 +230,81 @@ def test_parity_one_frame_image_batch(model):
     for k in LOSS_KEYS:
         assert errs[k] <= PARITY_TOL, (k, lv[k], lv_ref[k])
     assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_parity_step_gradients_vs_reference(model, B):
+    """Parity mode has a backward (fp32 storage + arithmetic on the HIP kernels: clv_sgemm_nt on transposed operands,
+    clv_attn_f32_bwd, the LayerNorm / GELU backward kernels in fp32 storage): the 13 parameter gradients the REFERENCE
+    itself produced for BASELINE config 1 (tests/golden/g_step.npz: both backbones, the fusion encoder, every head, the
+    relative-position table, the mask token) at 1e-4 of each gradient's max — the bf16 training path asserts 3e-2 / 1e-1
+    on the same fixtures — and the same set of statically unused parameters."""
+    from clover_amd import parity
+    g = gutil.load('g_step.npz')
+    batch = {k: v.to(DEV) for k, v in cf.cf_batch(B, tag=f'step{B}').items()}
+    model.zero_grad(set_to_none=True)
+    with parity.mode():
+        out = model.train_step(batch, None)
+        out['loss'].backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for k in [n[len(f'B{B}.grad.'):-4] for n in g.files if n.startswith(f'B{B}.grad.') and n.endswith('.sub')]:
+        sub, stats = gutil.packed(named[k].grad)
+        gsub = g[f'B{B}.grad.{k}.sub'].astype(np.float64)
+        assert g[f'B{B}.grad.{k}.stats'][2] == stats[2]
+        worst[k] = np.abs(sub - gsub).max() / max(np.abs(gsub).max(), 1e-20)
+    print('parity grad rel errors', B, worst)
+    assert len(worst) == 13
+    for k, e in worst.items():
+        assert e < 1e-4, (k, e)
+    unused = sorted(k for k, p in named.items() if p.grad is None)
+    assert unused == gutil.unused_params()
+    model.zero_grad(set_to_none=True)
+
+
+@pytest.mark.parametrize('case', [(2, 4, 14, 14, 48, 3, True), (1, 8, 7, 7, 64, 2, True), (2, 2, 14, 14, 32, 1, False),
+                                  (1, 16, 14, 14, 32, 2, True)])
+def test_window_attention_f32_backward(case):
+    """clv_attn_f32_bwd (mode 1) against fp64 autograd through roll + partition + WindowAttention3D + reverse + un-roll over the
+    oracle's index helpers: d qkv and the relative-position-table gradient."""
+    from test_kernels_gpu import ref_window_attention
+    from clover_amd import ops, parity
+    from clover_amd.backbones.swin_transformer_3d import window_geometry
+    B, D, H, W, C, nH, shifted = case
+    cfg_ws, cfg_ss = (8, 7, 7), ((4, 3, 3) if shifted else (0, 0, 0))
+    qkv = rnd(B, D, H, W, 3 * C, seed=71)
+    table = rnd((2 * 8 - 1) * 13 * 13, nH, scale=0.5, seed=72)
+    dout = rnd(B, D, H, W, C, seed=73)
+    q64, t64 = qkv.double().requires_grad_(), table.double().requires_grad_()
+    o_ref = ref_window_attention(q64, t64, ix.relative_position_index(cfg_ws), cfg_ws, cfg_ss, nH)
+    (o_ref * dout.double()).sum().backward()
+    ws, ss, rid = window_geometry((D, H, W), cfg_ws, cfg_ss, DEV)
+    qg, tg = qkv.to(DEV).requires_grad_(), table.to(DEV).requires_grad_()
+    with parity.mode():
+        o = ops.window_attention(qg, tg, rid, ws, ss, nH, table_window=cfg_ws)
+    o.backward(dout.to(DEV))
+    assert rel(o, o_ref.detach()) < 1e-5
+    assert rel(qg.grad, q64.grad) < 2e-5, rel(qg.grad, q64.grad)
+    assert rel(tg.grad, t64.grad) < 2e-5, rel(tg.grad, t64.grad)
+
+
+@pytest.mark.parametrize('B,S,nH,hd', [(3, 16, 2, 64), (2, 228, 12, 64), (2, 40, 4, 32)])
+def test_seq_attention_f32_backward(B, S, nH, hd):
+    from clover_amd import ops, parity
+    Hd = nH * hd
+    qkv = rnd(B, S, 3 * Hd, seed=74)
+    dout = rnd(B, S, Hd, seed=75)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[0, S - 5:] = 0
+    ext = om.extended_mask(mask)
+    q64 = qkv.double().requires_grad_()
+    q, k, v = q64.view(B, S, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    p = (q @ k.transpose(-1, -2) / hd ** 0.5 + ext.double()).softmax(-1)
+    o_ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, Hd)
+    (o_ref * dout.double()).sum().backward()
+    qg = qkv.to(DEV).requires_grad_()
+    with parity.mode():
+        o = ops.seq_attention(qg, ext.reshape(B, S).to(DEV).contiguous(), nH)
+    o.backward(dout.to(DEV))
+    assert rel(o, o_ref.detach()) < 1e-5
+    assert rel(qg.grad, q64.grad) < 2e-5, rel(qg.grad, q64.grad)
