@@ -107,7 +107,7 @@ class _Segment:
         self.lr_mult = lr_mult
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
-        # 16-byte aligned slots.  A parameter may ask for PHANTOM rows behind its last one (``_clv_pad_rows``: the MLM
+        # 16-byte aligned slots (fp32 AND bf16 views: the GEMM kernels take 16-byte aligned operands).  A parameter may ask for PHANTOM rows behind its last one (``_clv_pad_rows``: the MLM
         # decoder's [30522, H] weight and [30522] bias -> 30528, a multiple of 64): the padded [rows + pad, ...] views of the
         # fp32 data, the gradient and the bf16 shadow are what its GEMMs run on (16-byte row groups, no edge code); the
         # phantom rows start at zero, receive zero gradients (the loss kernel zeroes the padding columns of d logits) and
@@ -115,7 +115,7 @@ class _Segment:
         def slot_elems(p):
             pad = int(getattr(p, '_clv_pad_rows', 0) or 0)
             return p.numel() + pad * (p.numel() // p.shape[0] if p.dim() > 0 and p.shape[0] > 0 else 0)
-        sizes = [(slot_elems(p) + 3) // 4 * 4 for p in self.params]
+        sizes = [(slot_elems(p) + 7) // 8 * 8 for p in self.params]          # 8 elements: the bf16 shadow slots are 16-byte aligned too
         self.offsets = [0]
         for s in sizes:
             self.offsets.append(self.offsets[-1] + s)
@@ -183,7 +183,7 @@ class _Segment:
         module that applies the members as ONE GEMM (BERT Q|K|V) needs no cat / cast / gradient split."""
         idx = [next(i for i, q in enumerate(self.params) if q is m) for m in members]
         assert idx == list(range(idx[0], idx[0] + len(idx))), 'fusion group is not adjacent in the slab'
-        assert all(m.numel() % 4 == 0 and m.shape[1:] == members[0].shape[1:] for m in members)
+        assert all(m.numel() % 8 == 0 and m.shape[1:] == members[0].shape[1:] for m in members)      # slots are 8-element aligned
         off, n = self.offsets[idx[0]], sum(m.numel() for m in members)
         shape = (sum(m.shape[0] for m in members),) + tuple(members[0].shape[1:])
         f = torch.nn.Parameter(self.flat_p[off:off + n].view(shape))
@@ -296,6 +296,7 @@ class CloverEngine:
             seg.build_transposed()
         self._zero_views = None                # None: clear whole slabs
         self._stale_views = []
+        self._prepacked = frozenset()
         self._setup_first_touch(sample_batch)
 
     # ------------------------------------------------------------------ gradient clearing
@@ -467,6 +468,7 @@ class CloverEngine:
                     self.capture(batch)
             out = self._graphed_forward_backward(batch)
         else:
+            self.reducer.prepacked = frozenset()
             self._ft.done.clear()
             out = self.model.train_step(batch, None)
             self._backward(lambda: out['loss'].backward())
@@ -487,7 +489,7 @@ class CloverEngine:
     # ------------------------------------------------------------------ hipGraph mode
     _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
                        '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts', 'graph_loss', '_loss_io',
-                       '_stale_views')
+                       '_stale_views', '_prepacked')
 
     @staticmethod
     def _signature(batch):
@@ -551,6 +553,7 @@ class CloverEngine:
         return lambda q: cl.get(id(q), 'h') in classes
 
     def _replay_backward(self):
+        self.reducer.prepacked = getattr(self, '_prepacked', None) or frozenset()
         self.graph_bwd.replay()
         if self.graph_bwd_video is None:
             return
@@ -647,14 +650,26 @@ class CloverEngine:
             emb, mlm = encode(vcuts, tcuts)
         self._static_demb = torch.zeros_like(emb)
         self._static_dmlm = torch.zeros_like(mlm) if mlm is not None else None
+        # Data-parallel jobs: the bf16 wire copy of every bucket is written INSIDE the backward graph that completes its
+        # gradients (the pack kernels are plain launches; only the RCCL calls stay between the replays)
+        pack = cut_ok and os.environ.get('CLOVER_PACK_IN_GRAPH', '1') == '1'
+        prepacked = set()
         with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode='thread_local'):
             self._backward(lambda: torch.autograd.backward(*roots(emb, mlm, self._static_demb, self._static_dmlm)))
+            if pack:
+                prepacked |= self.reducer.pack_where(self._ready('h'))
         if cut_ok:
             gb2 = []
-            for c in reversed(vcuts):
+            ncut = len(vcuts)
+            for i, c in enumerate(reversed(vcuts)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=gf.pool(), capture_error_mode='thread_local'):
                     bwd_cut([c])
+                    if pack:
+                        # as _replay_backward launches them: the late video stages after the first cut graph, what is
+                        # left of the video encoder (and, without a text cut, of the text encoder) after the last
+                        cls = ('v1',) if i + 1 < ncut else (('v0', 'v1') if text_ok else ('v0', 'v1', 't'))
+                        prepacked |= self.reducer.pack_where(self._ready(*cls), skip=prepacked)
                 gb2.append(g)
         if text_ok:
             # captured LAST and into a pool of its own: it replays concurrently with the video graph, so neither
@@ -662,6 +677,9 @@ class CloverEngine:
             # video graph has been laid out; its own temporaries never alias the video graph's)
             with torch.cuda.graph(gb3, capture_error_mode='thread_local'):
                 bwd_cut(tcuts)
+                if pack:
+                    prepacked |= self.reducer.pack_where(self._ready('t'), skip=prepacked)
+        self._prepacked = frozenset(prepacked)
         self._stale_views = self._stale_sinks()    # first-touch slots this geometry's backward never writes
         for seg in self.segments:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit

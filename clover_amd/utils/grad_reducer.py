@@ -77,12 +77,32 @@ class BucketedGradReducer:
         self.seen = {}
         self._producers = [[] for _ in self.buckets]
 
+    prepacked = frozenset()      # buckets whose bf16 wire copy the replayed backward graphs have already written (engine)
+
+    def pack_where(self, ready, skip=()):
+        """Pack (fp32 slab slice -> bf16 wire slab, no collective) every bucket all of whose parameters satisfy `ready` —
+        called by the engine INSIDE a backward-graph capture, right after the segment that completes those gradients: the
+        pack kernels then replay with the graph instead of being launched one by one, host-paced, between the replays
+        (17 launches, 0.28 ms at config 2).  skip: buckets already packed by an earlier graph.  Returns the set packed."""
+        done = set()
+        if not self.active or self.wire is None:
+            return done
+        from .. import ops
+        for b, ps in enumerate(self._bucket_params):
+            flat, s, e, _ = self.buckets[b]
+            if b not in skip and flat.is_cuda and all(ready(q) for q in ps):
+                ops.pack_bf16(flat[s:e], self.wire[self._bucket_slab[b]][s:e])
+                done.add(b)
+        return done
+
     def _payload(self, b):
         """The tensor bucket b puts on the wire: the fp32 slab slice, or its freshly packed bf16 copy."""
         flat, s, e, _ = self.buckets[b]
         if self.wire is None:
             return flat[s:e]
         w = self.wire[self._bucket_slab[b]][s:e]
+        if b in self.prepacked:
+            return w
         if flat.is_cuda:
             from .. import ops
             ops.pack_bf16(flat[s:e], w)

@@ -362,6 +362,14 @@ def test_rccl_code_path_on_one_gpu(monkeypatch):
         assert {k for _, k, _, ph in log if ph == 'finish'} == {'v0'} and {ph for _, k, _, ph in log if k != 'v0'} == {'where'}
         total, left = sum(b for _, _, b, _ in log), sum(b for _, _, b, ph in log if ph == 'finish')
         assert total == 2 * sum(seg.flat_g.numel() for seg in eng.segments) and left <= 0.05 * total, (left, total)
+        # every bucket's bf16 wire copy is written inside the backward graph that completes it (no eager pack launches),
+        # and the stall of the compute stream on the comm stream is recorded
+        assert eng._prepacked == frozenset(range(len(eng.reducer.buckets))), eng._prepacked
+        eng.reducer.start_timing()
+        eng.step(b)
+        torch.cuda.synchronize()
+        ex = eng.reducer.exposed_ms()
+        assert ex is not None and ex >= 0.0
         g_got, g_ref = grads(eng), grads(eng, graph=False)
     finally:
         dist.destroy_process_group()

@@ -368,7 +368,8 @@ def test_use_checkpoint_recomputes_and_matches():
         out['loss'].backward()
         losses[ck] = {k: float(v) for k, v in out['log_vars'].items()}
         grads[ck] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
-    assert losses[True] == losses[False], (losses[True], losses[False])
+    for k in losses[False]:           # the focal / InfoNCE sums are atomically accumulated: equal up to fp32 summation order
+        assert abs(losses[True][k] - losses[False][k]) <= 1e-5 * max(1.0, abs(losses[False][k])), (k, losses[True], losses[False])
     assert grads[True].keys() == grads[False].keys()
     for n in grads[False]:
         a, b = grads[True][n].float(), grads[False][n].float()
