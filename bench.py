@@ -352,18 +352,18 @@ def main():
                     return None, None
                 d = json.load(open(path))
                 return d.get(kname), f"profiles/{fname}@{(d.get('_meta') or {}).get('commit', 'unknown')}"
-            rec, src = committed('r03_pmc_traffic.json')
+            rec, src = committed('r04_pmc_traffic.json')
             res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
             res['roofline']['traffic_source'] = src if rec else None
-            rec, src = committed('r03_pmc_mfma.json')
+            rec, src = committed('r04_pmc_mfma.json')
             res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
             res['roofline']['mfma_util_source'] = src if rec else None
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
             # (device-side, no event / dispatch overhead) and the roofline fraction it gives
-            stats = os.path.join(prof_dir, 'r03_kernel_stats_bench_default_final.csv')
+            stats = os.path.join(prof_dir, 'r04_kernel_stats_bench_default_final.csv')
             if os.path.exists(stats):
                 import csv
-                meta = os.path.join(prof_dir, 'r03_kernel_stats_bench_default_final.meta.json')
+                meta = os.path.join(prof_dir, 'r04_kernel_stats_bench_default_final.meta.json')
                 sha = json.load(open(meta)).get('commit', 'unknown') if os.path.exists(meta) else 'unknown'
                 for row in csv.DictReader(open(stats)):
                     nm = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
@@ -374,7 +374,7 @@ def main():
                                               else 'algorithmic_flops_per_launch']
                         peak = 8.0e12 if res['roofline']['bound'] == 'hbm' else 2.5e15
                         res['roofline']['frac_rocprof'] = round(per / (us * 1e-6) / peak, 4)
-                        res['roofline']['rocprof_source'] = f'profiles/r03_kernel_stats_bench_default_final.csv@{sha}'
+                        res['roofline']['rocprof_source'] = f'profiles/r04_kernel_stats_bench_default_final.csv@{sha}'
                         break
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)

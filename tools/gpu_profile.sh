@@ -22,6 +22,6 @@ rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mfma g
 python3 - <<PY
 import json
 t=json.load(open('gpurun_out/${TAG}_pmc_traffic.json')); m=json.load(open('gpurun_out/${TAG}_pmc_mfma.json'))
-for k in ['wgrad_dma2_group_kernel','attn_fwd_kernel<32, 13, false, 1>','attn_bwd_dq_kernel<32, 13, false, 1>','adamw_dev_kernel<float>']:
+for k in list(m)[:6]:
     print(k, t.get(k), m.get(k))
 PY

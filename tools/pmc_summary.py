@@ -22,7 +22,7 @@ def load(d, counter):
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
 out = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 1])[0])):
-    if not (k.startswith(('wgrad', 'attn_', 'lnv_', 'rowgemm', 'fold_', 'dbias', 'adamw', 'gelu', 'ln_', 'gemm_nt', 'transpose_', 'patch_', 'sumsq'))):
+    if not (k.startswith(('wgrad', 'attn_', 'lnv_', 'rowgemm', 'fold_', 'dbias', 'adamw', 'gelu', 'ln_', 'gemm_nt', 'gemm_ws', 'splitk_', 'sgemm', 'focal', 'transpose_', 'patch_', 'sumsq'))):
         continue
     f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
     fb = 2.0 * 1024.0 * f[0] / max(f[1], 1)
