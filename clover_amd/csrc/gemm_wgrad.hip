@@ -369,6 +369,72 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
     const int rows = (int)(m_end - m_begin);
     const int nst = (rows + SM - 1) / SM;                   // stages of this slice
     const int nfull = rows / SM;                            // ... of which complete (all 32 rows inside)
+    // Wave-specialised launch (blockDim = 320): a FIFTH wave issues every LDS-DMA piece of the workgroup, the four MFMA
+    // waves only read and multiply.  A wave is blocked ~60 cycles per piece it issues (the CU's vector-memory path takes
+    // 1 KiB per ~16 cycles) and feeds no MFMA meanwhile — tools/probes/gemm_lab.cpp measured issue ~ compute ~ 40 % of a
+    // stage each for this loop structure; on separate waves the two overlap.
+    const bool ws = blockDim.x > WG_THREADS;
+    if (ws && wave == 4) {
+        const int ln = lane;
+        unsigned py[8], px[8];
+        int prow[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                       // q = j * 4 + w: the piece wave w issued as its j-th
+            const int pp = (q >> 2) * 256 + (q & 3) * 64 + ln;
+            const int r = pp >> 4, c = ((pp & 15) ^ ((r & 7) << 1)) * 8;
+            int cy = n0 + c, cx = k0 + c;
+            cy = cy < N ? cy : N - 8;
+            cx = cx < K ? cx : K - 8;
+            prow[q] = r;
+            py[q] = (unsigned)((r * ldy + cy) * 2);
+            px[q] = (unsigned)((r * ldx + cx) * 2);
+        }
+        const bf16_t* pby = dy + m_begin * ldy;
+        const bf16_t* pbx = x + m_begin * ldx;
+        const int64_t sy = (int64_t)SM * ldy, sx = (int64_t)SM * ldx;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)&ring[0][0][0]);
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
+        auto issue_p = [&](int s, int slot) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool in = s * SM + prow[q] < rows;
+                const unsigned dst = lds0 + (unsigned)((q & 3) * 1024 + (q >> 2) * 4096);
+                dma16(in ? reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pby) + py[q]) : zero,
+                      dst + (unsigned)((slot * 2 + 0) * STAGE * 2));
+                dma16(in ? reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pbx) + px[q]) : zero,
+                      dst + (unsigned)((slot * 2 + 1) * STAGE * 2));
+            }
+            pby += sy;
+            pbx += sx;
+        };
+        // complete stages go out in the lean form (SGPR bases + fixed lane offsets, four pieces per asm block), the ragged
+        // last one through the predicated per-piece path
+        auto issue_f = [&](int s, int slot) {
+            if (s < nfull) {
+                const int sc = slot * 2 * STAGE * 2;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) dma4(lds0 + (unsigned)(w * 1024), py[w], py[4 + w], px[w], px[4 + w], pby, pbx, sc);
+                pby += sy;
+                pbx += sx;
+            } else {
+                issue_p(s, slot);
+            }
+        };
+        for (int d = 0; d < RING - 1 && d < nst; ++d) issue_f(d, d);
+        int nslot = (RING - 1) % RING;
+        for (int s = 0; s < nst; ++s) {
+            if (nst - 1 - s >= RING - 2) wait_vm<(RING - 2) * 16>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + RING - 1 < nst) {
+                issue_f(s + RING - 1, nslot);
+                nslot = nslot == RING - 1 ? 0 : nslot + 1;
+            }
+        }
+        wait_vm<0>();
+        return;
+    }
 
     // per-lane source offsets (bytes from the stage's first row), fixed for the whole slice: LDS position
     // p = j*256 + tid -> row p>>4, physical chunk p&15 holds logical chunk (p&15) ^ ((row&7)<<1); columns clamped
@@ -454,6 +520,23 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         }
     };
 
+    if (ws) {                                               // MFMA waves of a wave-specialised workgroup
+        int sw = 0;
+        for (; sw + RING <= nst; sw += RING) {
+            __builtin_amdgcn_s_barrier(); compute(ring[0][0], ring[0][1]);
+            __builtin_amdgcn_s_barrier(); compute(ring[1][0], ring[1][1]);
+            __builtin_amdgcn_s_barrier(); compute(ring[2][0], ring[2][1]);
+#if WG_RING == 4
+            __builtin_amdgcn_s_barrier(); compute(ring[3][0], ring[3][1]);
+#endif
+        }
+        int sl = 0;
+        for (; sw < nst; ++sw) {
+            __builtin_amdgcn_s_barrier();
+            compute(ring[sl][0], ring[sl][1]);
+            sl = sl == RING - 1 ? 0 : sl + 1;
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < RING - 1; ++d) issue_slow(d);       // prologue (also correct for slices shorter than the ring)
     int st = 0;
@@ -495,6 +578,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         slot = slot == RING - 1 ? 0 : slot + 1;
     }
     wait_vm<0>();
+    }
     float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
     float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
     if (ACCUM && RMW) {
@@ -559,7 +643,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
 }
 
 template <bool ACCUM, bool RMW = false>
-__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
+__global__ void __launch_bounds__(WG_THREADS + 64, 2) wgrad_dma2_kernel(const bf16_t* __restrict__ dy,
                                                                    const bf16_t* __restrict__ x,
                                                                    float* __restrict__ out, float* __restrict__ out_b,
                                                                    int64_t M, int N, int K, int ldy, int ldx, int tiles,
@@ -589,7 +673,7 @@ struct WgGroup {
     WgProblem p[WG_GROUP_MAX];
     int n;
 };
-__global__ void __launch_bounds__(WG_THREADS, WG_RING == 3 ? 3 : 2) wgrad_dma2_group_kernel(WgGroup grp) {
+__global__ void __launch_bounds__(WG_THREADS + 64, 2) wgrad_dma2_group_kernel(WgGroup grp) {
     __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];
     int idx = 0;
     for (int i = 1; i < grp.n; ++i)
@@ -973,6 +1057,13 @@ int pick_splits(int64_t M, int tiles) {
 
 }  // namespace
 
+// CLV_WGRAD_WS=1 (probe): 320 threads = four MFMA waves + one LDS-DMA producer wave (wgrad_dma2_body).  Measured and NOT
+// the default: with two workgroups per CU the other workgroup already fills the issue bubbles — 11.89 vs 11.83 ms per step.
+static unsigned wg_threads() {
+    const char* v = getenv("CLV_WGRAD_WS");
+    return (v && atoi(v) == 1) ? WG_THREADS + 64 : WG_THREADS;
+}
+
 extern "C" int64_t clv_linear_wgrad_work_floats(int64_t M, int32_t N, int32_t K) {
     const int tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
     const int splits = pick_splits(M, tiles);
@@ -1017,13 +1108,13 @@ extern "C" int clv_linear_wgrad(const void* dy, const void* x, float* dw, float*
                 hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
                                    M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else if (atomic_acc && splits == 1 && !getenv("CLV_WGRAD_NORMW")) {   // one M-slice: dW += in place, no fold
-            hipLaunchKernelGGL((wgrad_dma2_kernel<true, true>), dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+            hipLaunchKernelGGL((wgrad_dma2_kernel<true, true>), dim3(dma_grid), dim3(wg_threads()), 0, st, dyp, xp, dw, db, M,
                                (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else if (atomic_acc) {           // A/B switches: atomics straight into dW / db
-            hipLaunchKernelGGL(wgrad_dma2_kernel<true>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, dw, db, M,
+            hipLaunchKernelGGL(wgrad_dma2_kernel<true>, dim3(dma_grid), dim3(wg_threads()), 0, st, dyp, xp, dw, db, M,
                                (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(wgrad_dma2_kernel<false>, dim3(dma_grid), dim3(WG_THREADS), 0, st, dyp, xp, work, nullptr,
+            hipLaunchKernelGGL(wgrad_dma2_kernel<false>, dim3(dma_grid), dim3(wg_threads()), 0, st, dyp, xp, work, nullptr,
                                M, (int)N, (int)K, (int)ldy, (int)ldx, tiles, tilesK, nsp, rows, db ? 1 : 0);
         }
         rc = clv_check_launch();
@@ -1194,7 +1285,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
         if (!cnt) continue;
         grp.n = cnt;
         if (cls == 0) {
-            hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(WG_THREADS), 0, (hipStream_t)stream,
+            hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(wg_threads()), 0, (hipStream_t)stream,
                                grp);
         } else if (cls == 1) {
             constexpr int LDS = BIG_RING * 4 * 8192;
