@@ -533,6 +533,10 @@ __global__ void __launch_bounds__(64 * (WAVES_M * WAVES_N + NPROD), 1)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int pr = 8 / pc, xr = xcd / pc, xc = xcd - xr * pc;
+#ifdef GN_TRACE
+    asm volatile("" ::"s"(pr));                               // the first use of a kernel argument: its load has returned
+    const unsigned long long t_args = __builtin_amdgcn_s_memtime();
+#endif
     const int my_mblks = (nmblk - xr + pr - 1) / pr;
     const int my_tns = (tilesN - xc + pc - 1) / pc;
     const int my_units = my_mblks * my_tns * splitk;
@@ -562,6 +566,7 @@ __global__ void __launch_bounds__(64 * (WAVES_M * WAVES_N + NPROD), 1)
             gn_init<BM, NPROD, 0>(A, a + (int64_t)kb * GN_BK, (int64_t)tile_m(t) * BM, M, lda, pw, lane);
             gn_init<BN, NPROD, TN>(B, b + (int64_t)kb * GN_BK, tile_n(t) * BN, N, ldb, pw, lane);
         };
+        GN_T(t_pre);
         init_unit(qn);
         auto issue_next = [&]() {
             if (qn >= my_units) return;
@@ -612,6 +617,7 @@ __global__ void __launch_bounds__(64 * (WAVES_M * WAVES_N + NPROD), 1)
             unsigned long long* o = gn_trace_buf + (size_t)blockIdx.x * 16;
             o[0] = tr_wait; o[2] = tr_issue;
             o[8] = t_init - t_entry; o[9] = t_primed - t_init; o[10] = t_first - t_primed;
+            o[12] = t_args - t_entry; o[13] = t_pre - t_args; o[14] = t_init - t_pre;
         }
 #endif
         return;

@@ -156,9 +156,9 @@ def test_patch_embed_fp8(C, B, T, HW, monkeypatch):
 
 # |loss - oracle| of the fp8-forward step, B = 2, eval mode: ~2x the largest value measured over the three
 # configurations below (printed by the test; round 4 numbers in DESIGN.md section 5)
-FP8_LOSS_TOL = dict(mlm_loss=5e-2, nce_loss=2.5e-1, rank_t_tm_loss=2.5e-1, v_nce_loss=2.5e-1, rank_v_vm_loss=2.5e-1, loss=6e-1)
+FP8_LOSS_TOL = dict(mlm_loss=1e-2, nce_loss=5e-2, rank_t_tm_loss=1.2e-1, v_nce_loss=2.7e-1, rank_v_vm_loss=1.7e-1, loss=4.5e-1)
 # max|grad - oracle| / max|oracle| of gradients that cross every encoder (fp8 forward operands, bf16 backward)
-FP8_GRAD_TOL = 0.25
+FP8_GRAD_TOL = 0.30         # measured <= 17.5 % (e4m3 operands carry 2^-4 relative rounding)
 
 
 @pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16), ('B', 32)])

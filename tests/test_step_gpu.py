@@ -230,7 +230,7 @@ def test_finetune_other_tasks_refuse():
 
 
 # ----------------------------------------------------------------------------- BASELINE configs 2 and 4 at full size
-FULL_GRAD_TOL = 6e-2          # max|grad - oracle| / max|oracle|; measured 0.8-3.5 % (round 3)
+FULL_GRAD_TOL = 8e-2          # max|grad - oracle| / max|oracle|; measured 0.8-4.7 % (round 4, incl. Swin-B 32 frames)
 FULL_GRAD_KEYS = {
     'T': ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.3.attn.relative_position_bias_table',
           'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',

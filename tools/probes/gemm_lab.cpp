@@ -86,9 +86,10 @@ int main(int argc, char** argv) {
         }
         const double stg = sum[5] / std::max(n, 1);
         printf("%-9s %6ldx%5dx%5d: %7.1f us %5.0f TF rc=%d S=%d | WGs %4d stages/WG %5.1f | per stage: wait %5.0f bar %5.0f issue %5.0f comp %5.0f"
-               " | per WG: epi %6.0f total %7.0f (max %7llu) | start: prod init %5.0f prime %5.0f first-land %5.0f; cons B0 at %6.0f\n",
+               " | per WG: epi %6.0f total %7.0f (max %7llu) | start: prod init %5.0f (args %5.0f, index math %5.0f, offsets %5.0f) prime %5.0f first-land %5.0f; cons B0 at %6.0f\n",
                s.name, (long)s.M, s.N, s.K, us, fl / us / 1e6, rc, (int)(work_bytes / (s.M * s.N * 4)), n, stg, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5],
-               sum[3] / sum[5], sum[4] / std::max(n, 1), sum[6] / std::max(n, 1), maxtot, sum[8] / std::max(n, 1), sum[9] / std::max(n, 1),
+               sum[3] / sum[5], sum[4] / std::max(n, 1), sum[6] / std::max(n, 1), maxtot, sum[8] / std::max(n, 1), sum[12] / std::max(n, 1),
+               sum[13] / std::max(n, 1), sum[14] / std::max(n, 1), sum[9] / std::max(n, 1),
                sum[10] / std::max(n, 1), sum[11] / std::max(n, 1));
         hipFree(a); hipFree(b); hipFree(c); hipFree(c2); hipFree(aux); hipFree(bias);
         if (work) hipFree(work);
