@@ -182,6 +182,7 @@ def main():
                     help='fp8: forward GEMMs on e4m3 operands (BASELINE config 5); gradients stay bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--phases', action='store_true', help='after the timed region: GPU time per phase of the graphed step (events at the phase boundaries), as a "phases_ms" field')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of as one hipGraph')
     ap.add_argument('--no-gemm-tuning', action='store_true', help='library GEMMs with default heuristics')
     ap.add_argument('--tune-gemms', metavar='CSV', help='benchmark library GEMM algorithms and write the table')
@@ -288,6 +289,13 @@ def main():
         sync()
         with_copy_ms = (time.perf_counter() - t1) / args.steps * 1e3
         del fresh
+    phases_ms = None
+    if graphed and args.phases:
+        engine.start_phase_timing()
+        for _ in range(args.steps):
+            engine.step(batch)
+        sync()
+        phases_ms = {k: round(v, 3) for k, v in engine.phase_ms().items()}
     if graphed and not args.no_kernel_timing:
         # per-kernel durations: HIP events cannot bracket launches inside a replayed graph, so the same
         # kernels (same shapes, same data) are timed on 3 eager steps right after the timed region
@@ -336,6 +344,7 @@ def main():
             # data-parallel runs: mean per-step stall of the compute stream on the gradient all-reduces (rank 0), and what
             # travels: bf16 gradients in per-class buckets (null at N = 1: no collective is issued)
             'exposed_comm_ms': round(exposed_comm_ms, 3) if exposed_comm_ms is not None else None,
+            'phases_ms': phases_ms,
             'grad_allreduce_dtype': ('bf16' if engine.wire is not None else 'fp32') if engine.reducer.active else None,
         }
         if prof:

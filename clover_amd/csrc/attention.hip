@@ -754,6 +754,317 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
     }
 }
 
+// ------------------------------------------------------------------------- backward, ONE kernel: dQ, dK, dV (+ dS scratch)
+// Window mode (round 4).  The two kernels above each recompute S, P, dP and dS — the exp2 / bias / mask arithmetic that
+// bounds them (VALU issue, not MFMA) runs twice per score.  Here it runs once, in a wave-specialised workgroup:
+//   compute waves (one per PAIR of key tiles) keep their k / v fragments and dK / dV accumulators in registers for the whole
+//     (window, head) and walk the queries in chunks of 32 (two query tiles), read from a double-buffered LDS chunk
+//     (Q', dO, -L, D).  Per chunk and key tile: S, dP (MFMA), P, dS (VALU), dV += dO^T P, dK += Q'^T dS (MFMA) — and the
+//     bf16 dS tile goes to LDS as T[key][query].
+//   the service wave (the last one) stages the chunks (global -> registers one step ahead -> LDS; D = rowsum(dO . O) on the
+//     way) and turns the T tiles of the PREVIOUS chunk into dQ: the transposing LDS read returns dS keyed the way the
+//     contraction over keys wants it (and exactly as the dS scratch of the table gradient stores it), K^T of all key tiles
+//     sits in its registers, so dQ of a chunk is complete in one wave — no partial sums, no second pass over the scores.
+//   One raw barrier per chunk (LDS traffic only: no wave waits for the service wave's global stores).
+#ifndef ONE_MINW
+#define ONE_MINW 4
+#endif
+constexpr int ONE_CWAVES(int nkt) { return (nkt + 1) / 2; }   // compute waves: two key tiles each
+template <int HD, int NKT>
+size_t one_lds(int tls) {
+    return 2 * 2 * 32 * (size_t)(HD + 8) * 2 + 4 * 32 * 4 + 3 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16 +
+           2 * (size_t)ONE_CWAVES(NKT) * 4 * 256 * 2;
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int HD, int NKT>
+__global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd_one_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ bias, const int* __restrict__ rid, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+    bf16_t* __restrict__ dv, bf16_t* __restrict__ ds_out, Geom G) {
+    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16, CH = HD / 8;
+    constexpr int NWC = ONE_CWAVES(NKT), NTHR = (NWC + 1) * 64, NQP = (NKT + 1) / 2;
+    constexpr int TW = 4 * 256;                              // bf16 of one compute wave's T tiles: [half][ti][16][16]
+    static_assert(KS == 1 && CH == 4, "one-kernel backward: HD = 32");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [2][32][LDR]  Q * scale * log2e
+    bf16_t* dOs = Qs + 2 * 32 * LDR;                         // [2][32][LDR]
+    float* L_s = reinterpret_cast<float*>(dOs + 2 * 32 * LDR);   // [2][32]  -lse * log2e (pad queries: -inf)
+    float* D_s = L_s + 64;                                   // [2][32]  rowsum(dO . O)
+    int* row_s = reinterpret_cast<int*>(D_s + 64);           // [NK]
+    int* linb_s = row_s + NK;
+    int* rid_s = linb_s + NK;
+    float* tab_s = reinterpret_cast<float*>(rid_s + NK);
+    int* flag_s = reinterpret_cast<int*>(tab_s + G.tls);
+    bf16_t* T_s = reinterpret_cast<bf16_t*>(flag_s + 4);     // [2][NWC][half][ti][16 keys][16 queries]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
+    const int gh = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = gh / G.g.nH + G.grp0, h = gh % G.g.nH;
+    const int N = G.g.N, nt = (N + 15) >> 4;                 // real tiles (queries and keys alike)
+    const bool tb = bias != nullptr;
+    if (tid == 0) *flag_s = 0;
+    token_rows<NK>(G, grp, row_s, tid, NTHR);                // ends with a barrier
+    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, NTHR, LOG2E);
+    {
+        const int wloc = grp % G.nW;
+        int differs = 0;
+        for (int n = tid; n < NK; n += NTHR) {
+            if (rid) {
+                const int rv = (n < N) ? rid[wloc * N + n] : 0;
+                rid_s[n] = rv;
+                if (n < N) differs |= rv != rid[wloc * N];
+            }
+        }
+        if (differs) *flag_s = 1;
+    }
+
+    // K rows [NK][HD] -> the second T buffer (free until step 1): the service wave's dQ operand, see there
+    static_assert((size_t)NK * HD <= (size_t)NWC * TW, "K rows fit one T buffer");
+    bf16_t* Kst = T_s + NWC * TW;
+    for (int idx = tid; idx < NK * CH; idx += NTHR) {
+        const int n = idx / CH, c = idx - n * CH;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (n < N) val = *reinterpret_cast<const uint4*>(k + (int64_t)row_s[n] * G.g.ldk + h * HD + c * 8);
+        *reinterpret_cast<uint4*>(Kst + n * HD + c * 8) = val;
+    }
+
+    if (wave == NWC) {
+        // ================================================================= service wave
+        // K^T of every key-tile pair: A[hd c*16 + lr][kappa] = K[key(kappa)][hd], kappa = lg*8 + j: j < 4 -> tile 2 jp, key
+        // lg*4 + j; j >= 4 -> tile 2 jp + 1.  Unscaled: dQ = (dS . K) * scale.
+        Frag8 ktf[NWC][NC];
+        // staging: lane -> rows l>>2 and 16 + (l>>2), 16-byte piece l&3 of Q, dO and O; lanes 0..31 one -lse each
+        const int srow = lane >> 2, sseg = lane & 3;
+        const float qmul = G.g.scale * LOG2E;
+        uint4 pq[2], pd[2], po[2];
+        float pl = 0.f;
+        auto chunk_load = [&](int p) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int qn = p * 32 + j * 16 + srow;
+                pq[j] = pd[j] = po[j] = make_uint4(0, 0, 0, 0);
+                if (qn < N) {
+                    const int64_t r = row_s[qn];
+                    pq[j] = *reinterpret_cast<const uint4*>(q + r * G.g.ldq + h * HD + sseg * 8);
+                    pd[j] = *reinterpret_cast<const uint4*>(dout + r * G.g.ldo + h * HD + sseg * 8);
+                    po[j] = *reinterpret_cast<const uint4*>(o + r * G.g.ldo + h * HD + sseg * 8);
+                }
+            }
+            const int ql = p * 32 + lane;
+            pl = (lane < 32 && ql < N) ? -lse[((int64_t)grp * G.g.nH + h) * N + ql] * LOG2E : -INFINITY;
+        };
+        auto chunk_store = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t* w = reinterpret_cast<uint32_t*>(&pq[j]);
+                const uint32_t* a = reinterpret_cast<const uint32_t*>(&pd[j]);
+                const uint32_t* c = reinterpret_cast<const uint32_t*>(&po[j]);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w[e] = pack2bf(__uint_as_float(w[e] << 16) * qmul, __uint_as_float(w[e] & 0xffff0000u) * qmul);
+                    d += __uint_as_float(a[e] << 16) * __uint_as_float(c[e] << 16) +
+                         __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(c[e] & 0xffff0000u);
+                }
+                d += __shfl_xor(d, 1, 64);                   // the 4 pieces of a row sit in adjacent lanes
+                d += __shfl_xor(d, 2, 64);
+                const int r = b * 32 + j * 16 + srow;
+                *reinterpret_cast<uint4*>(Qs + r * LDR + sseg * 8) = pq[j];
+                *reinterpret_cast<uint4*>(dOs + r * LDR + sseg * 8) = pd[j];
+                if (sseg == 0) D_s[r] = d;
+            }
+            if (lane < 32) L_s[b * 32 + lane] = pl;
+        };
+        bf16_t* dsbase = (tb && ds_out) ? ds_out + (((int64_t)(grp - G.grp0) * G.g.nH + h) * nt * NKT * 64 + lane) * 4 : nullptr;
+        // dQ of chunk pc from the T tiles in buffer bt
+        auto dq_chunk = [&](int pc, int bt) {
+            const bf16_t* Tb = T_s + bt * (NWC * TW);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * pc + half;
+                if (qt >= nt) break;
+                f32x4_t qacc[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) qacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jp = 0; jp < NWC; ++jp) {
+                    Frag8 bq;
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti) {
+                        const bool ok = 2 * jp + ti < nt;
+                        bq.u2[ti] = ok ? tr4(Tb + jp * TW + (half * 2 + ti) * 256, 16, lg * 4, 0, lr) : make_uint2(0u, 0u);
+                        if (dsbase && ok)
+                            *reinterpret_cast<uint2*>(dsbase + ((int64_t)qt * NKT + 2 * jp + ti) * 256) = bq.u2[ti];
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) qacc[c] = mfma16(ktf[jp][c], bq, qacc[c]);   // dQ^T[hd c*16+lg*4+r][query lr]
+                    __builtin_amdgcn_sched_barrier(0);       // pair by pair: keeps the T reads from piling up in registers
+                }
+                const int qn = qt * 16 + lr;
+                if (qn < N) {
+                    bf16_t* drow = dq + (int64_t)row_s[qn] * G.lddq + h * HD + lg * 4;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        uint2 w2;
+                        w2.x = pack2bf(qacc[c][0] * G.g.scale, qacc[c][1] * G.g.scale);
+                        w2.y = pack2bf(qacc[c][2] * G.g.scale, qacc[c][3] * G.g.scale);
+                        *reinterpret_cast<uint2*>(drow + c * 16) = w2;
+                    }
+                }
+            }
+        };
+        chunk_load(0);
+        chunk_store(0);
+        if (NQP > 1) chunk_load(1);
+        lds_barrier();                                       // B0: tables, masks, chunk 0, K rows
+        // the rows of K sit (unpadded) in the T buffer the compute waves first write in step 1: transposed reads now
+#pragma unroll
+        for (int jp = 0; jp < NWC; ++jp)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                ktf[jp][c].u2[0] = tr4(Kst, HD, (2 * jp) * 16 + lg * 4, c * 16, lr);
+                ktf[jp][c].u2[1] = (2 * jp + 1 < NKT) ? tr4(Kst, HD, (2 * jp + 1) * 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
+            }
+#pragma unroll 1
+        for (int p = 0; p < NQP; ++p) {
+            if (p + 1 < NQP) {
+                chunk_store((p + 1) & 1);                    // loaded one step ago
+                if (p + 2 < NQP) chunk_load(p + 2);
+            }
+            if (p > 0) dq_chunk(p - 1, (p - 1) & 1);
+            lds_barrier();
+        }
+        dq_chunk(NQP - 1, (NQP - 1) & 1);
+        return;
+    }
+
+    // ===================================================================== compute waves: key tiles 2 wave, 2 wave + 1
+    Frag8 kf[2], vf[2];
+    bool tv[2];
+    int ko[2], rk[2];
+    float kmv[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int kt = wave * 2 + ti, nk = kt * 16 + lr;
+        tv[ti] = kt < nt;
+        const bool kv = nk < N;
+        const int64_t krow = row_s[kv ? nk : 0];
+        Frag8 t1[KS], t2[KS];
+        load_frags<HD>(t1, k + krow * G.g.ldk + h * HD, kv, lane);
+        load_frags<HD>(t2, v + krow * G.g.ldv + h * HD, kv, lane);
+        kf[ti] = t1[0];
+        vf[ti] = t2[0];
+        kmv[ti] = kv ? 0.f : -INFINITY;                      // pad keys: P = dS = 0 (they would enter dQ otherwise)
+    }
+    f32x4_t dvacc[2][NC], dkacc[2][NC];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            dvacc[ti][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dkacc[ti][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    lds_barrier();                                           // B0
+    const bool masked = rid && *flag_s != 0;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int nk = (wave * 2 + ti) * 16 + lr;
+        rk[ti] = (rid && nk < N) ? rid_s[nk] : 0;
+        ko[ti] = tb ? linb_s[nk < N ? nk : 0] - 4 * G.tcst : 0;     // slot(q, key) = lin(q) - (lin(key) - tcst)
+    }
+
+#pragma unroll 1
+    for (int p = 0; p < NQP; ++p) {
+        const int b = p & 1;
+        const bf16_t* Qb = Qs + b * 32 * LDR;
+        const bf16_t* dOb = dOs + b * 32 * LDR;
+        bf16_t* Tw = T_s + (b * NWC + wave) * TW;
+        const int nh = nt - 2 * p;                           // query tiles of this chunk that exist: <= 0, 1, >= 2
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            if (!tv[ti]) continue;                           // wave-uniform
+            Frag8 pf, dsf;
+            pf.u[2] = pf.u[3] = dsf.u[2] = dsf.u[3] = 0u;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half >= nh) break;
+                const int qn0 = (2 * p + half) * 16 + lg * 4;   // this lane's 4 queries (window token ids)
+                float4 bv = make_float4(kmv[ti], kmv[ti], kmv[ti], kmv[ti]);
+                if (tb) {
+                    const int4 qb = *reinterpret_cast<const int4*>(linb_s + qn0);
+                    const char* tp = reinterpret_cast<const char*>(tab_s) - ko[ti];
+                    bv.x += *reinterpret_cast<const float*>(tp + qb.x);
+                    bv.y += *reinterpret_cast<const float*>(tp + qb.y);
+                    bv.z += *reinterpret_cast<const float*>(tp + qb.z);
+                    bv.w += *reinterpret_cast<const float*>(tp + qb.w);
+                }
+                f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
+                if (masked) {
+                    const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
+                    sacc[0] += (rq4.x != rk[ti]) ? -100.0f * LOG2E : 0.0f;
+                    sacc[1] += (rq4.y != rk[ti]) ? -100.0f * LOG2E : 0.0f;
+                    sacc[2] += (rq4.z != rk[ti]) ? -100.0f * LOG2E : 0.0f;
+                    sacc[3] += (rq4.w != rk[ti]) ? -100.0f * LOG2E : 0.0f;
+                }
+                Frag8 qf, dof;
+                qf.u4 = *reinterpret_cast<const uint4*>(Qb + (half * 16 + lr) * LDR + lg * 8);
+                dof.u4 = *reinterpret_cast<const uint4*>(dOb + (half * 16 + lr) * LDR + lg * 8);
+                sacc = mfma16(qf, kf[ti], sacc);             // S[query lg*4+r][key lr], log2 units
+                pacc = mfma16(dof, vf[ti], pacc);            // dP, same layout
+                const float4 L4 = *reinterpret_cast<const float4*>(L_s + b * 32 + half * 16 + lg * 4);
+                const float4 D4 = *reinterpret_cast<const float4*>(D_s + b * 32 + half * 16 + lg * 4);
+                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(sacc[r] + Lr[r]);     // pad keys / pad queries: exp2(-inf) = 0
+                    dsv[r] = pv[r] * (pacc[r] - Dr[r]);
+                }
+                pf.u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
+                pf.u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
+                dsf.u[half * 2 + 0] = pack2bf(dsv[0], dsv[1]);
+                dsf.u[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+                // dS tile as T[key lr][query lg*4 .. +3]: the service wave's transposing read returns it keyed the other way
+                *reinterpret_cast<uint2*>(Tw + (half * 2 + ti) * 256 + lr * 16 + lg * 4) =
+                    make_uint2(dsf.u[half * 2 + 0], dsf.u[half * 2 + 1]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                Frag8 a;   // A[hd c*16+lr][kappa] = dO[query(kappa)][hd]
+                a.u2[0] = tr4(dOb, LDR, lg * 4, c * 16, lr);
+                a.u2[1] = tr4(dOb, LDR, 16 + lg * 4, c * 16, lr);       // second tile absent: zero rows, zero P
+                dvacc[ti][c] = mfma16(a, pf, dvacc[ti][c]);  // dV^T[hd (lg*4+r)][key lr]
+                a.u2[0] = tr4(Qb, LDR, lg * 4, c * 16, lr);
+                a.u2[1] = tr4(Qb, LDR, 16 + lg * 4, c * 16, lr);
+                dkacc[ti][c] = mfma16(a, dsf, dkacc[ti][c]);
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int nk = (wave * 2 + ti) * 16 + lr;
+        if (nk < N) {
+            const int64_t krow = row_s[nk];
+            bf16_t* dvrow = dv + krow * G.lddv + h * HD + lg * 4;
+            bf16_t* dkrow = dk + krow * G.lddk + h * HD + lg * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint2 w;
+                w.x = pack2bf(dvacc[ti][c][0], dvacc[ti][c][1]);
+                w.y = pack2bf(dvacc[ti][c][2], dvacc[ti][c][3]);
+                *reinterpret_cast<uint2*>(dvrow + c * 16) = w;
+                w.x = pack2bf(dkacc[ti][c][0] * (1.0f / LOG2E), dkacc[ti][c][1] * (1.0f / LOG2E));
+                w.y = pack2bf(dkacc[ti][c][2] * (1.0f / LOG2E), dkacc[ti][c][3] * (1.0f / LOG2E));
+                *reinterpret_cast<uint2*>(dkrow + c * 16) = w;
+            }
+        }
+    }
+}
+
 // d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key], in two kernels and without atomics:
 //   sum     partial[s][h][q tile][key tile][lane][4] (fp32) = sum over group slice s of the dQ kernel's bf16 scratch
 //           (same fragment order; one thread = 4 scores; streaming, HBM-bound)
@@ -1247,6 +1558,7 @@ void set_attrs() {
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 1>));
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 0>));
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, true, 0>));
+    if constexpr (HD == 32 && NKT == 13) CLV_ATTR((attn_bwd_one_kernel<HD, NKT>));
 #undef CLV_ATTR
 }
 
@@ -1308,6 +1620,21 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         dk_out = dq_out + tc;
         dv_out = dq_out + 2 * tc;
     }
+    // Window mode, head dim 32, the two Swin window sizes: ONE kernel for dQ / dK / dV (+ the dS scratch), see
+    // attn_bwd_one_kernel.  CLV_ATTN_BWD_ONE: 0 = the two-kernel path, 1 (default) = when the (group, head) pairs alone
+    // fill the chip (tsplit == 1), 2 = whenever the shapes allow (tests).
+    const char* one_env = getenv("CLV_ATTN_BWD_ONE");     // read per call: the tests switch it
+    const int one_mode = one_env ? atoi(one_env) : 1;
+    bool one = false;
+    if constexpr (HD == 32 && NKT == 13)
+        one = one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && stages == 7 && (G.tsplit == 1 || one_mode > 1) &&
+              one_lds<HD, NKT>(bl) <= MAX_LDS;
+    auto launch_one = [&](const Geom& Gx, int groups) {
+        if constexpr (HD == 32 && NKT == 13)
+            attn_bwd_one_kernel<HD, NKT><<<dim3(groups * G.g.nH), dim3((ONE_CWAVES(NKT) + 1) * 64), one_lds<HD, NKT>(bl), st>>>(
+                (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
+                dq_out, dk_out, dv_out, (bf16_t*)(bias ? work : nullptr), Gx);
+    };
     const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
     float* partial = bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT)) : nullptr;
     // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
@@ -1332,12 +1659,18 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
             Geom Cg = G;
             Cg.grp0 = cix * cg;
             const int nb = cg * G.g.nH * G.tsplit;
+            if (one) launch_one(Cg, cg);
+            else
             CLV_PICK(attn_bwd_dq_kernel, <<<dim3(nb), dim3(DKV_THREADS(NKT)), lds_a, st>>>((const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid, kmask, dq_out,
                      (bf16_t*)work, dsum, seed, Cg));
             hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), spc), dim3(256), 0, st,
                                (const bf16_t*)work, reinterpret_cast<float4*>(partial + (int64_t)cix * spc * E * 4), cg, E / 2);
         }
+        rc = clv_check_launch();
+        if (rc) return rc;
+    } else if (one) {
+        launch_one(G, G.g.groups);
         rc = clv_check_launch();
         if (rc) return rc;
     } else if (stages & 1) {
@@ -1363,7 +1696,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         rc = clv_check_launch();
         if (rc) return rc;
     }
-    if (stages & 4) {
+    if ((stages & 4) && !one) {
         CLV_PICK_N(attn_bwd_dkv_kernel, NKE, <<<dim3(nblk), dim3(DKV_THREADS(NKE)), lds_b, st>>>((const bf16_t*)q, (const bf16_t*)k,
                  (const bf16_t*)v, (const bf16_t*)dout, lse, dsum, bias, rid, kmask, dk_out, dv_out, seed, G));
         rc = clv_check_launch();

@@ -474,6 +474,7 @@ class CloverEngine:
             self._backward(lambda: out['loss'].backward())
         self.reducer.finish()
         self.optimizer_step()
+        self._mark('optimizer')
         return out
 
     def _backward(self, run):
@@ -516,7 +517,9 @@ class CloverEngine:
         for k, v in self._static_batch.items():
             if batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
+        self._mark('start')
         self.graph.replay()
+        self._mark('forward')
         if getattr(self, 'graph_loss', None) is not None:
             # the loss section as a graph of its own: only the feature all-gather (and the all-reduce of the logged
             # scalars) stay eager — ~60 launch-bound kernels otherwise paced by the host
@@ -545,8 +548,34 @@ class CloverEngine:
             self._static_demb.copy_(emb.grad)
             if mlm is not None:
                 self._static_dmlm.copy_(mlm.grad)
+        self._mark('loss')
         self._replay_backward()
+        self._mark('backward')
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=len(next(iter(batch.values()))))
+
+    # Phase clock of the graphed step (bench.py --phases): events on the main stream at the phase boundaries — the
+    # forward graph, the eager loss section, the backward graphs, reducer.finish() + optimizer.  GPU time between
+    # consecutive marks, averaged by phase_ms(); off (None) unless start_phase_timing() was called.
+    _phase_ev = None
+
+    def start_phase_timing(self):
+        self._phase_ev = []
+
+    def _mark(self, name):
+        if self._phase_ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._phase_ev.append((name, e))
+
+    def phase_ms(self):
+        """Mean GPU milliseconds per phase since start_phase_timing() (call after a device sync); stops the clock."""
+        ev, self._phase_ev = self._phase_ev, None
+        tot, cnt = {}, {}
+        for (_, a), (n, b) in zip(ev, ev[1:]):
+            if n != 'start':
+                tot[n] = tot.get(n, 0.0) + a.elapsed_time(b)
+                cnt[n] = cnt.get(n, 0) + 1
+        return {n: tot[n] / cnt[n] for n in tot}
 
     def _ready(self, *classes):
         cl = self._pclass

@@ -119,11 +119,13 @@ WIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize('bwd_one', ['2', '0'])           # backward: the one-kernel form wherever it exists / dQ + dK/dV kernels
 @pytest.mark.parametrize('dbias_index', ['1', '0'])       # table gradient: precomputed offset table / index arithmetic
 @pytest.mark.parametrize('case', WIN_CASES)
-def test_window_attention(case, dbias_index, monkeypatch):
+def test_window_attention(case, dbias_index, bwd_one, monkeypatch):
     from clover_amd.backbones.swin_transformer_3d import window_geometry
     monkeypatch.setenv('CLOVER_DBIAS_INDEX', dbias_index)
+    monkeypatch.setenv('CLV_ATTN_BWD_ONE', bwd_one)
     B, D, H, W, C, nH, shifted = case
     cfg_ws, cfg_ss = (8, 7, 7), ((4, 3, 3) if shifted else (0, 0, 0))
     qkv = rnd(B, D, H, W, 3 * C, seed=11).to(BF)
