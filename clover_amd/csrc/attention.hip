@@ -14,6 +14,7 @@
 // {2s*16 + (lane>>4)*4 + (j&3), j<4} ∪ {(2s+1)*16 + ...} and Vᵀ is read with the
 // same enumeration.
 #include "common.hpp"
+#include <type_traits>
 #include "../../include/clover_hip.h"
 
 namespace {
@@ -755,24 +756,27 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
 }
 
 // ------------------------------------------------------------------------- backward, ONE kernel: dQ, dK, dV (+ dS scratch)
-// Window mode (round 4).  The two kernels above each recompute S, P, dP and dS — the exp2 / bias / mask arithmetic that
-// bounds them (VALU issue, not MFMA) runs twice per score.  Here it runs once, in a wave-specialised workgroup:
-//   compute waves (one per PAIR of key tiles) keep their k / v fragments and dK / dV accumulators in registers for the whole
-//     (window, head) and walk the queries in chunks of 32 (two query tiles), read from a double-buffered LDS chunk
-//     (Q', dO, -L, D).  Per chunk and key tile: S, dP (MFMA), P, dS (VALU), dV += dO^T P, dK += Q'^T dS (MFMA) — and the
-//     bf16 dS tile goes to LDS as T[key][query].
-//   the service wave (the last one) stages the chunks (global -> registers one step ahead -> LDS; D = rowsum(dO . O) on the
-//     way) and turns the T tiles of the PREVIOUS chunk into dQ: the transposing LDS read returns dS keyed the way the
-//     contraction over keys wants it (and exactly as the dS scratch of the table gradient stores it), K^T of all key tiles
-//     sits in its registers, so dQ of a chunk is complete in one wave — no partial sums, no second pass over the scores.
-//   One raw barrier per chunk (LDS traffic only: no wave waits for the service wave's global stores).
+// Window mode (round 4).  The two kernels above each recompute S, P, dP and dS.  Here that runs once, in a wave-specialised
+// workgroup over one (window, head) whose Q' (= Q * scale * log2e), dO, -L and D = rowsum(dO . O) are staged in LDS up front:
+//   compute waves (one per PAIR of key tiles) keep their k / v fragments and dK / dV accumulators in registers and walk the
+//     queries in chunks of 32 (two query tiles).  Per chunk and key tile: S, dP (MFMA), P, dS (VALU), dV += dO^T P,
+//     dK += Q'^T dS (MFMA) — and the bf16 dS tile goes to LDS as T[key][query] (double-buffered per chunk).
+//   the service wave (the last one) turns the T tiles of the PREVIOUS chunk into dQ: the transposing LDS read returns dS keyed
+//     the way the contraction over keys wants it (and exactly as the dS scratch of the table gradient stores it), K^T of all
+//     key tiles sits in its registers, so dQ of a chunk is complete in one wave — no partial sums, no second pass over the
+//     scores.  One raw barrier per chunk (LDS traffic only: nobody waits for the service wave's global stores).
+// (A first version staged the chunks inside the loop, one step ahead, from the service wave: every step then waited for a
+// global round trip — 223 us per stage-0 launch against 239 us for the two kernels it replaces.)
 #ifndef ONE_MINW
 #define ONE_MINW 4
+#endif
+#ifndef ONE_ABL            // ablation builds (tools/probes/attn_one_abl.sh): 1 no dS scratch stores, 2 no dQ work, 4 no T writes,
+#define ONE_ABL 0          // 8 no dV / dK MFMAs, 16 no bias gathers, 32 no exp2
 #endif
 constexpr int ONE_CWAVES(int nkt) { return (nkt + 1) / 2; }   // compute waves: two key tiles each
 template <int HD, int NKT>
 size_t one_lds(int tls) {
-    return 2 * 2 * 32 * (size_t)(HD + 8) * 2 + 4 * 32 * 4 + 3 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16 +
+    return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16 +
            2 * (size_t)ONE_CWAVES(NKT) * 4 * 256 * 2;
 }
 
@@ -783,17 +787,28 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
-    bf16_t* __restrict__ dv, bf16_t* __restrict__ ds_out, Geom G) {
+    bf16_t* __restrict__ dv, bf16_t* __restrict__ ds_out, float* __restrict__ trace, Geom G) {
     constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16, CH = HD / 8;
     constexpr int NWC = ONE_CWAVES(NKT), NTHR = (NWC + 1) * 64, NQP = (NKT + 1) / 2;
+#ifdef ONE_TRACE           // probe build: s_memtime deltas of wave 0 (and the service wave's loop) into the unused dsum array
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#define ONE_T(i) if (trace && (threadIdx.x & 63) == 0) trace[(int64_t)blockIdx.x * 16 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start)
+#define ONE_TV(i, v) if (trace && (threadIdx.x & 63) == 0) trace[(int64_t)blockIdx.x * 16 + (i)] = (float)(v)
+    unsigned long long bw_s = 0, bw_c = 0;       // cycles spent waiting at the per-chunk barrier (service / compute wave)
+#define ONE_BAR(acc) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); lds_barrier(); acc += __builtin_amdgcn_s_memtime() - t0_; }
+#else
+#define ONE_T(i)
+#define ONE_TV(i, v)
+#define ONE_BAR(acc) lds_barrier()
+#endif
     constexpr int TW = 4 * 256;                              // bf16 of one compute wave's T tiles: [half][ti][16][16]
     static_assert(KS == 1 && CH == 4, "one-kernel backward: HD = 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [2][32][LDR]  Q * scale * log2e
-    bf16_t* dOs = Qs + 2 * 32 * LDR;                         // [2][32][LDR]
-    float* L_s = reinterpret_cast<float*>(dOs + 2 * 32 * LDR);   // [2][32]  -lse * log2e (pad queries: -inf)
-    float* D_s = L_s + 64;                                   // [2][32]  rowsum(dO . O)
-    int* row_s = reinterpret_cast<int*>(D_s + 64);           // [NK]
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [NK][LDR]  Q * scale * log2e
+    bf16_t* dOs = Qs + NK * LDR;                             // [NK][LDR]
+    float* L_s = reinterpret_cast<float*>(dOs + NK * LDR);   // [NK]  -lse * log2e (pad queries: -inf)
+    float* D_s = L_s + NK;                                   // [NK]  rowsum(dO . O)
+    int* row_s = reinterpret_cast<int*>(D_s + NK);           // [NK]
     int* linb_s = row_s + NK;
     int* rid_s = linb_s + NK;
     float* tab_s = reinterpret_cast<float*>(rid_s + NK);
@@ -803,106 +818,138 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     const int gh = xcd_remap(blockIdx.x, gridDim.x);
     const int grp = gh / G.g.nH + G.grp0, h = gh % G.g.nH;
-    const int N = G.g.N, nt = (N + 15) >> 4;                 // real tiles (queries and keys alike)
+    const int N = G.g.N;
+    constexpr int nt = NKT;                                  // the launcher guarantees (N + 15) / 16 == NKT: no padding-only tile
     const bool tb = bias != nullptr;
     if (tid == 0) *flag_s = 0;
     token_rows<NK>(G, grp, row_s, tid, NTHR);                // ends with a barrier
-    if (tb) load_bias_table<NK>(G, bias, h, tab_s, linb_s, tid, NTHR, LOG2E);
-    {
-        const int wloc = grp % G.nW;
-        int differs = 0;
-        for (int n = tid; n < NK; n += NTHR) {
-            if (rid) {
-                const int rv = (n < N) ? rid[wloc * N + n] : 0;
-                rid_s[n] = rv;
-                if (n < N) differs |= rv != rid[wloc * N];
-            }
-        }
-        if (differs) *flag_s = 1;
-    }
+    if (wave == 0) { ONE_T(0); }
 
-    // K rows [NK][HD] -> the second T buffer (free until step 1): the service wave's dQ operand, see there
+    // ---- compute waves: the k / v fragments of their key tiles go out first (as in the dK / dV kernel)
+    Frag8 kf[2], vf[2];
+    float kmv[2];
+    if (wave < NWC) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int nk = (wave * 2 + ti) * 16 + lr;
+            const bool kv = nk < N;
+            const int64_t krow = row_s[kv ? nk : 0];
+            Frag8 t1[KS], t2[KS];
+            load_frags<HD>(t1, k + krow * G.g.ldk + h * HD, kv, lane);
+            load_frags<HD>(t2, v + krow * G.g.ldv + h * HD, kv, lane);
+            kf[ti] = t1[0];
+            vf[ti] = t2[0];
+            kmv[ti] = kv ? 0.f : -INFINITY;                  // pad keys: P = dS = 0 (they would enter dQ otherwise)
+        }
+    }
+    // ---- staging, all threads: Q' and dO rows, D = rowsum(dO . O), -L; K rows (unpadded) into the second T buffer, which the
+    // compute waves first write in step 1 — the service wave takes its K^T fragments from there right after the barrier
     static_assert((size_t)NK * HD <= (size_t)NWC * TW, "K rows fit one T buffer");
     bf16_t* Kst = T_s + NWC * TW;
-    for (int idx = tid; idx < NK * CH; idx += NTHR) {
-        const int n = idx / CH, c = idx - n * CH;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (n < N) val = *reinterpret_cast<const uint4*>(k + (int64_t)row_s[n] * G.g.ldk + h * HD + c * 8);
-        *reinterpret_cast<uint4*>(Kst + n * HD + c * 8) = val;
+    {
+        // every global load of the prologue goes out before the first result is used: ONE round trip instead of five
+        // (two staging passes, -L, the region ids, the bias table: 20 000 of a workgroup's 46 000 cycles)
+        const float qmul = G.g.scale * LOG2E;
+        constexpr int NP = (NK * CH + NTHR - 1) / NTHR;      // 16-byte pieces per thread and matrix
+        constexpr int NTAB = 3;                              // table rows per thread: the band of a 4-frame window = 1 183 rows
+        uint4 vq[NP], vd[NP], vo[NP], vk[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = tid + j * NTHR, n = idx / CH, c = idx - n * CH;
+            vq[j] = vd[j] = vo[j] = vk[j] = make_uint4(0, 0, 0, 0);
+            if (idx < NK * CH && n < N) {
+                const int64_t r = row_s[n];
+                vq[j] = *reinterpret_cast<const uint4*>(q + r * G.g.ldq + h * HD + c * 8);
+                vd[j] = *reinterpret_cast<const uint4*>(dout + r * G.g.ldo + h * HD + c * 8);
+                vo[j] = *reinterpret_cast<const uint4*>(o + r * G.g.ldo + h * HD + c * 8);
+                vk[j] = *reinterpret_cast<const uint4*>(k + r * G.g.ldk + h * HD + c * 8);
+            }
+        }
+        static_assert(NK <= NTHR, "one token per thread");
+        const int wloc = grp % G.nW;
+        const float lv = (tid < N) ? lse[((int64_t)grp * G.g.nH + h) * N + tid] : 0.f;
+        const int rv = (rid && tid < N) ? rid[wloc * N + tid] : 0, rv0 = rid ? rid[wloc * N] : 0;
+        float tv[NTAB];
+#pragma unroll
+        for (int j = 0; j < NTAB; ++j) {
+            const int i = tid + j * NTHR;
+            tv[j] = i < G.tbn ? bias[(int64_t)(G.tb0 + i) * G.g.nH + h] : 0.f;      // [tlen][nH] parameter layout
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = tid + j * NTHR, n = idx / CH, c = idx - n * CH;
+            auto sc2 = [&](uint32_t w) { return pack2bf(__uint_as_float(w << 16) * qmul, __uint_as_float(w & 0xffff0000u) * qmul); };
+            auto dot2 = [](uint32_t a, uint32_t b) {
+                return __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+            };
+            float d = (dot2(vd[j].x, vo[j].x) + dot2(vd[j].y, vo[j].y)) + (dot2(vd[j].z, vo[j].z) + dot2(vd[j].w, vo[j].w));
+            d += __shfl_xor(d, 1, 64);                       // the CH = 4 pieces of a row sit in adjacent lanes
+            d += __shfl_xor(d, 2, 64);
+            if (idx < NK * CH) {
+                *reinterpret_cast<uint4*>(Qs + n * LDR + c * 8) = make_uint4(sc2(vq[j].x), sc2(vq[j].y), sc2(vq[j].z), sc2(vq[j].w));
+                *reinterpret_cast<uint4*>(dOs + n * LDR + c * 8) = vd[j];
+                *reinterpret_cast<uint4*>(Kst + n * HD + c * 8) = vk[j];
+                if (c == 0) D_s[n] = d;
+            }
+        }
+        if (tid < NK) {
+            L_s[tid] = (tid < N) ? -lv * LOG2E : -INFINITY;
+            linb_s[tid] = (tid < N) ? 4 * win_lin(G, tid) : 0;
+            if (rid) {
+                rid_s[tid] = rv;
+                if (tid < N && rv != rv0) *flag_s = 1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NTAB; ++j) {
+            const int i = tid + j * NTHR;
+            if (i < G.tbn) tab_s[i] = tv[j] * LOG2E;
+        }
     }
+    if (wave == 0) { ONE_T(1); }
+    lds_barrier();                                           // B0
+    if (wave == 0) { ONE_T(2); }
 
     if (wave == NWC) {
         // ================================================================= service wave
         // K^T of every key-tile pair: A[hd c*16 + lr][kappa] = K[key(kappa)][hd], kappa = lg*8 + j: j < 4 -> tile 2 jp, key
         // lg*4 + j; j >= 4 -> tile 2 jp + 1.  Unscaled: dQ = (dS . K) * scale.
         Frag8 ktf[NWC][NC];
-        // staging: lane -> rows l>>2 and 16 + (l>>2), 16-byte piece l&3 of Q, dO and O; lanes 0..31 one -lse each
-        const int srow = lane >> 2, sseg = lane & 3;
-        const float qmul = G.g.scale * LOG2E;
-        uint4 pq[2], pd[2], po[2];
-        float pl = 0.f;
-        auto chunk_load = [&](int p) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int qn = p * 32 + j * 16 + srow;
-                pq[j] = pd[j] = po[j] = make_uint4(0, 0, 0, 0);
-                if (qn < N) {
-                    const int64_t r = row_s[qn];
-                    pq[j] = *reinterpret_cast<const uint4*>(q + r * G.g.ldq + h * HD + sseg * 8);
-                    pd[j] = *reinterpret_cast<const uint4*>(dout + r * G.g.ldo + h * HD + sseg * 8);
-                    po[j] = *reinterpret_cast<const uint4*>(o + r * G.g.ldo + h * HD + sseg * 8);
-                }
+        for (int jp = 0; jp < NWC; ++jp)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                ktf[jp][c].u2[0] = tr4(Kst, HD, (2 * jp) * 16 + lg * 4, c * 16, lr);
+                ktf[jp][c].u2[1] = (2 * jp + 1 < NKT) ? tr4(Kst, HD, (2 * jp + 1) * 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
             }
-            const int ql = p * 32 + lane;
-            pl = (lane < 32 && ql < N) ? -lse[((int64_t)grp * G.g.nH + h) * N + ql] * LOG2E : -INFINITY;
-        };
-        auto chunk_store = [&](int b) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                uint32_t* w = reinterpret_cast<uint32_t*>(&pq[j]);
-                const uint32_t* a = reinterpret_cast<const uint32_t*>(&pd[j]);
-                const uint32_t* c = reinterpret_cast<const uint32_t*>(&po[j]);
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    w[e] = pack2bf(__uint_as_float(w[e] << 16) * qmul, __uint_as_float(w[e] & 0xffff0000u) * qmul);
-                    d += __uint_as_float(a[e] << 16) * __uint_as_float(c[e] << 16) +
-                         __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(c[e] & 0xffff0000u);
-                }
-                d += __shfl_xor(d, 1, 64);                   // the 4 pieces of a row sit in adjacent lanes
-                d += __shfl_xor(d, 2, 64);
-                const int r = b * 32 + j * 16 + srow;
-                *reinterpret_cast<uint4*>(Qs + r * LDR + sseg * 8) = pq[j];
-                *reinterpret_cast<uint4*>(dOs + r * LDR + sseg * 8) = pd[j];
-                if (sseg == 0) D_s[r] = d;
-            }
-            if (lane < 32) L_s[b * 32 + lane] = pl;
-        };
         bf16_t* dsbase = (tb && ds_out) ? ds_out + (((int64_t)(grp - G.grp0) * G.g.nH + h) * nt * NKT * 64 + lane) * 4 : nullptr;
-        // dQ of chunk pc from the T tiles in buffer bt
+        // dQ of chunk pc from the T tiles in buffer bt.  All transposing reads of a query tile go out first, then the scratch
+        // stores, then the MFMAs: with a read / wait / store per tile the wave spent 5 200 cycles per chunk and every compute
+        // wave waited for it at the barrier.
         auto dq_chunk = [&](int pc, int bt) {
             const bf16_t* Tb = T_s + bt * (NWC * TW);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * pc + half;
-                if (qt >= nt) break;
+                if (qt >= NKT) break;
+                Frag8 bq[NWC];
+#pragma unroll
+                for (int jp = 0; jp < NWC; ++jp) {
+                    bq[jp].u2[0] = tr4(Tb + jp * TW + (half * 2 + 0) * 256, 16, lg * 4, 0, lr);
+                    bq[jp].u2[1] = (2 * jp + 1 < NKT) ? tr4(Tb + jp * TW + (half * 2 + 1) * 256, 16, lg * 4, 0, lr) : make_uint2(0u, 0u);
+                }
+                if (!(ONE_ABL & 1) && dsbase) {
+                    bf16_t* dsq = dsbase + (int64_t)qt * NKT * 256;
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) *reinterpret_cast<uint2*>(dsq + kt * 256) = bq[kt >> 1].u2[kt & 1];
+                }
                 f32x4_t qacc[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) qacc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jp = 0; jp < NWC; ++jp) {
-                    Frag8 bq;
+                for (int jp = 0; jp < NWC; ++jp)
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
-                        const bool ok = 2 * jp + ti < nt;
-                        bq.u2[ti] = ok ? tr4(Tb + jp * TW + (half * 2 + ti) * 256, 16, lg * 4, 0, lr) : make_uint2(0u, 0u);
-                        if (dsbase && ok)
-                            *reinterpret_cast<uint2*>(dsbase + ((int64_t)qt * NKT + 2 * jp + ti) * 256) = bq.u2[ti];
-                    }
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) qacc[c] = mfma16(ktf[jp][c], bq, qacc[c]);   // dQ^T[hd c*16+lg*4+r][query lr]
-                    __builtin_amdgcn_sched_barrier(0);       // pair by pair: keeps the T reads from piling up in registers
-                }
+                    for (int c = 0; c < NC; ++c) qacc[c] = mfma16(ktf[jp][c], bq[jp], qacc[c]);   // dQ^T[hd c*16+lg*4+r][query lr]
                 const int qn = qt * 16 + lr;
                 if (qn < N) {
                     bf16_t* drow = dq + (int64_t)row_s[qn] * G.lddq + h * HD + lg * 4;
@@ -916,134 +963,123 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
                 }
             }
         };
-        chunk_load(0);
-        chunk_store(0);
-        if (NQP > 1) chunk_load(1);
-        lds_barrier();                                       // B0: tables, masks, chunk 0, K rows
-        // the rows of K sit (unpadded) in the T buffer the compute waves first write in step 1: transposed reads now
-#pragma unroll
-        for (int jp = 0; jp < NWC; ++jp)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                ktf[jp][c].u2[0] = tr4(Kst, HD, (2 * jp) * 16 + lg * 4, c * 16, lr);
-                ktf[jp][c].u2[1] = (2 * jp + 1 < NKT) ? tr4(Kst, HD, (2 * jp + 1) * 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
-            }
 #pragma unroll 1
         for (int p = 0; p < NQP; ++p) {
-            if (p + 1 < NQP) {
-                chunk_store((p + 1) & 1);                    // loaded one step ago
-                if (p + 2 < NQP) chunk_load(p + 2);
-            }
-            if (p > 0) dq_chunk(p - 1, (p - 1) & 1);
-            lds_barrier();
+            if (!(ONE_ABL & 2) && p > 0) dq_chunk(p - 1, (p - 1) & 1);
+            ONE_BAR(bw_s);
         }
-        dq_chunk(NQP - 1, (NQP - 1) & 1);
+        ONE_T(5);
+        ONE_TV(8, bw_s);
+        if (!(ONE_ABL & 2)) dq_chunk(NQP - 1, (NQP - 1) & 1);
+        ONE_T(6);
         return;
     }
 
     // ===================================================================== compute waves: key tiles 2 wave, 2 wave + 1
-    Frag8 kf[2], vf[2];
-    bool tv[2];
     int ko[2], rk[2];
-    float kmv[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int kt = wave * 2 + ti, nk = kt * 16 + lr;
-        tv[ti] = kt < nt;
-        const bool kv = nk < N;
-        const int64_t krow = row_s[kv ? nk : 0];
-        Frag8 t1[KS], t2[KS];
-        load_frags<HD>(t1, k + krow * G.g.ldk + h * HD, kv, lane);
-        load_frags<HD>(t2, v + krow * G.g.ldv + h * HD, kv, lane);
-        kf[ti] = t1[0];
-        vf[ti] = t2[0];
-        kmv[ti] = kv ? 0.f : -INFINITY;                      // pad keys: P = dS = 0 (they would enter dQ otherwise)
-    }
     f32x4_t dvacc[2][NC], dkacc[2][NC];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             dvacc[ti][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             dkacc[ti][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
-    lds_barrier();                                           // B0
-    const bool masked = rid && *flag_s != 0;
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
         const int nk = (wave * 2 + ti) * 16 + lr;
         rk[ti] = (rid && nk < N) ? rid_s[nk] : 0;
-        ko[ti] = tb ? linb_s[nk < N ? nk : 0] - 4 * G.tcst : 0;     // slot(q, key) = lin(q) - (lin(key) - tcst)
+        ko[ti] = linb_s[nk < N ? nk : 0] - 4 * G.tcst;              // slot(q, key) = lin(q) - (lin(key) - tcst)
     }
+    const bool masked = rid && *flag_s != 0;
 
-#pragma unroll 1
-    for (int p = 0; p < NQP; ++p) {
-        const int b = p & 1;
-        const bf16_t* Qb = Qs + b * 32 * LDR;
-        const bf16_t* dOb = dOs + b * 32 * LDR;
-        bf16_t* Tw = T_s + (b * NWC + wave) * TW;
-        const int nh = nt - 2 * p;                           // query tiles of this chunk that exist: <= 0, 1, >= 2
+    // One chunk of 32 queries (NH = 2) or the odd last tile (NH = 1), with / without the shift mask — four straight-line
+    // bodies picked outside the loop: no branch inside, so the scheduler overlaps the LDS latencies of the four (query tile,
+    // key tile) units of a chunk (a wave whose second key tile is padding computes it anyway: k = 0, P = 0).
+    auto chunk = [&](int p, auto nh_c, auto masked_c) {
+        constexpr int NH = decltype(nh_c)::value;
+        constexpr bool MASKED = decltype(masked_c)::value;
+        const bf16_t* Qb = Qs + p * 32 * LDR;
+        const bf16_t* dOb = dOs + p * 32 * LDR;
+        bf16_t* Tw = T_s + ((p & 1) * NWC + wave) * TW;
+        Frag8 pf[2], dsf[2];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            if (!tv[ti]) continue;                           // wave-uniform
-            Frag8 pf, dsf;
-            pf.u[2] = pf.u[3] = dsf.u[2] = dsf.u[3] = 0u;
+        for (int ti = 0; ti < 2; ++ti) pf[ti].u4 = dsf[ti].u4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half >= nh) break;
-                const int qn0 = (2 * p + half) * 16 + lg * 4;   // this lane's 4 queries (window token ids)
-                float4 bv = make_float4(kmv[ti], kmv[ti], kmv[ti], kmv[ti]);
-                if (tb) {
-                    const int4 qb = *reinterpret_cast<const int4*>(linb_s + qn0);
+        for (int half = 0; half < NH; ++half) {
+            const int qn0 = (2 * p + half) * 16 + lg * 4;    // this lane's 4 queries (window token ids)
+            Frag8 qf, dof;
+            qf.u4 = *reinterpret_cast<const uint4*>(Qb + (half * 16 + lr) * LDR + lg * 8);
+            dof.u4 = *reinterpret_cast<const uint4*>(dOb + (half * 16 + lr) * LDR + lg * 8);
+            const float4 L4 = *reinterpret_cast<const float4*>(L_s + qn0);
+            const float4 D4 = *reinterpret_cast<const float4*>(D_s + qn0);
+            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+            const int4 qb = *reinterpret_cast<const int4*>(linb_s + qn0);
+            int4 rq4 = make_int4(0, 0, 0, 0);
+            if (MASKED) rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x4_t sacc, pacc = {0.f, 0.f, 0.f, 0.f};
+                if (!(ONE_ABL & 16)) {
                     const char* tp = reinterpret_cast<const char*>(tab_s) - ko[ti];
-                    bv.x += *reinterpret_cast<const float*>(tp + qb.x);
-                    bv.y += *reinterpret_cast<const float*>(tp + qb.y);
-                    bv.z += *reinterpret_cast<const float*>(tp + qb.z);
-                    bv.w += *reinterpret_cast<const float*>(tp + qb.w);
+                    sacc[0] = kmv[ti] + *reinterpret_cast<const float*>(tp + qb.x);
+                    sacc[1] = kmv[ti] + *reinterpret_cast<const float*>(tp + qb.y);
+                    sacc[2] = kmv[ti] + *reinterpret_cast<const float*>(tp + qb.z);
+                    sacc[3] = kmv[ti] + *reinterpret_cast<const float*>(tp + qb.w);
+                } else {
+                    sacc = (f32x4_t){kmv[ti], kmv[ti], kmv[ti], kmv[ti]};
                 }
-                f32x4_t sacc = {bv.x, bv.y, bv.z, bv.w}, pacc = {0.f, 0.f, 0.f, 0.f};
-                if (masked) {
-                    const int4 rq4 = *reinterpret_cast<const int4*>(rid_s + qn0);
+                if (MASKED) {
                     sacc[0] += (rq4.x != rk[ti]) ? -100.0f * LOG2E : 0.0f;
                     sacc[1] += (rq4.y != rk[ti]) ? -100.0f * LOG2E : 0.0f;
                     sacc[2] += (rq4.z != rk[ti]) ? -100.0f * LOG2E : 0.0f;
                     sacc[3] += (rq4.w != rk[ti]) ? -100.0f * LOG2E : 0.0f;
                 }
-                Frag8 qf, dof;
-                qf.u4 = *reinterpret_cast<const uint4*>(Qb + (half * 16 + lr) * LDR + lg * 8);
-                dof.u4 = *reinterpret_cast<const uint4*>(dOb + (half * 16 + lr) * LDR + lg * 8);
                 sacc = mfma16(qf, kf[ti], sacc);             // S[query lg*4+r][key lr], log2 units
                 pacc = mfma16(dof, vf[ti], pacc);            // dP, same layout
-                const float4 L4 = *reinterpret_cast<const float4*>(L_s + b * 32 + half * 16 + lg * 4);
-                const float4 D4 = *reinterpret_cast<const float4*>(D_s + b * 32 + half * 16 + lg * 4);
-                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
                 float pv[4], dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(sacc[r] + Lr[r]);     // pad keys / pad queries: exp2(-inf) = 0
+                    pv[r] = (ONE_ABL & 32) ? sacc[r] + Lr[r] : __builtin_amdgcn_exp2f(sacc[r] + Lr[r]);     // pad keys / pad queries: exp2(-inf) = 0
                     dsv[r] = pv[r] * (pacc[r] - Dr[r]);
                 }
-                pf.u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
-                pf.u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
-                dsf.u[half * 2 + 0] = pack2bf(dsv[0], dsv[1]);
-                dsf.u[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+                pf[ti].u[half * 2 + 0] = pack2bf(pv[0], pv[1]);
+                pf[ti].u[half * 2 + 1] = pack2bf(pv[2], pv[3]);
+                dsf[ti].u[half * 2 + 0] = pack2bf(dsv[0], dsv[1]);
+                dsf[ti].u[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
                 // dS tile as T[key lr][query lg*4 .. +3]: the service wave's transposing read returns it keyed the other way
+                if (!(ONE_ABL & 4))
                 *reinterpret_cast<uint2*>(Tw + (half * 2 + ti) * 256 + lr * 16 + lg * 4) =
-                    make_uint2(dsf.u[half * 2 + 0], dsf.u[half * 2 + 1]);
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                Frag8 a;   // A[hd c*16+lr][kappa] = dO[query(kappa)][hd]
-                a.u2[0] = tr4(dOb, LDR, lg * 4, c * 16, lr);
-                a.u2[1] = tr4(dOb, LDR, 16 + lg * 4, c * 16, lr);       // second tile absent: zero rows, zero P
-                dvacc[ti][c] = mfma16(a, pf, dvacc[ti][c]);  // dV^T[hd (lg*4+r)][key lr]
-                a.u2[0] = tr4(Qb, LDR, lg * 4, c * 16, lr);
-                a.u2[1] = tr4(Qb, LDR, 16 + lg * 4, c * 16, lr);
-                dkacc[ti][c] = mfma16(a, dsf, dkacc[ti][c]);
+                    make_uint2(dsf[ti].u[half * 2 + 0], dsf[ti].u[half * 2 + 1]);
             }
         }
-        lds_barrier();
-    }
+#pragma unroll
+        for (int c = 0; c < ((ONE_ABL & 8) ? 0 : NC); ++c) {
+            Frag8 ad, aq;   // A[hd c*16+lr][kappa] = dO (Q')[query(kappa)][hd]
+            ad.u2[0] = tr4(dOb, LDR, lg * 4, c * 16, lr);
+            ad.u2[1] = NH == 2 ? tr4(dOb, LDR, 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);   // odd tile count: nothing staged there
+            aq.u2[0] = tr4(Qb, LDR, lg * 4, c * 16, lr);
+            aq.u2[1] = NH == 2 ? tr4(Qb, LDR, 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                dvacc[ti][c] = mfma16(ad, pf[ti], dvacc[ti][c]);      // dV^T[hd (lg*4+r)][key lr]
+                dkacc[ti][c] = mfma16(aq, dsf[ti], dkacc[ti][c]);
+            }
+        }
+    };
+    auto loop = [&](auto masked_c) {
+#pragma unroll 1
+        for (int p = 0; p < NKT / 2; ++p) {
+            chunk(p, std::integral_constant<int, 2>{}, masked_c);
+            ONE_BAR(bw_c);
+        }
+        if (NKT & 1) {
+            chunk(NKT / 2, std::integral_constant<int, 1>{}, masked_c);
+            ONE_BAR(bw_c);
+        }
+    };
+    if (masked) loop(std::true_type{});
+    else loop(std::false_type{});
+    if (wave == 0) { ONE_T(3); ONE_TV(7, bw_c); }
+    if (wave == NWC - 1) { ONE_TV(9, bw_c); }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int nk = (wave * 2 + ti) * 16 + lr;
@@ -1063,6 +1099,7 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
             }
         }
     }
+    if (wave == 0) { ONE_T(4); }
 }
 
 // d table[slot(q, key)][h] += sum over groups of dS[g][h][q][key], in two kernels and without atomics:
@@ -1628,12 +1665,13 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     bool one = false;
     if constexpr (HD == 32 && NKT == 13)
         one = one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && stages == 7 && (G.tsplit == 1 || one_mode > 1) &&
+              (G.g.N + 15) / 16 == NKT && bias != nullptr && G.tbn <= 3 * (ONE_CWAVES(NKT) + 1) * 64 &&
               one_lds<HD, NKT>(bl) <= MAX_LDS;
     auto launch_one = [&](const Geom& Gx, int groups) {
         if constexpr (HD == 32 && NKT == 13)
             attn_bwd_one_kernel<HD, NKT><<<dim3(groups * G.g.nH), dim3((ONE_CWAVES(NKT) + 1) * 64), one_lds<HD, NKT>(bl), st>>>(
                 (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
-                dq_out, dk_out, dv_out, (bf16_t*)(bias ? work : nullptr), Gx);
+                dq_out, dk_out, dv_out, (bf16_t*)(bias ? work : nullptr), dsum, Gx);
     };
     const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
     float* partial = bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT)) : nullptr;
