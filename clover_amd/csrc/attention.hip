@@ -774,22 +774,28 @@ __global__ void __launch_bounds__(DKV_THREADS(NKT)) attn_bwd_dkv_kernel(
 #define ONE_ABL 0          // 8 no dV / dK MFMAs, 16 no bias gathers, 32 no exp2
 #endif
 constexpr int ONE_CWAVES(int nkt) { return (nkt + 1) / 2; }   // compute waves: two key tiles each
+// 196-token windows: one service wave with K^T in its registers, two 8-wave workgroups per CU.  392-token windows (25 key
+// tiles, 13 compute waves): K^T of 13 tile pairs does not fit a wave's registers next to the dS fragments — it stays in LDS
+// (rows unpadded to make room) — and TWO service waves take one query tile of the chunk each; one 15-wave workgroup per CU.
+constexpr int ONE_SWAVES(int nkt) { return nkt > 16 ? 2 : 1; }
+constexpr int ONE_LDR(int hd, int nkt) { return nkt > 16 ? hd : hd + 8; }
 template <int HD, int NKT>
 size_t one_lds(int tls) {
-    return 2 * (size_t)(NKT * 16) * (HD + 8) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16 +
-           2 * (size_t)ONE_CWAVES(NKT) * 4 * 256 * 2;
+    return 2 * (size_t)(NKT * 16) * ONE_LDR(HD, NKT) * 2 + 5 * (size_t)NKT * 16 * 4 + (size_t)tls * 4 + 16 +
+           2 * (size_t)ONE_CWAVES(NKT) * 4 * 256 * 2 + (NKT > 16 ? (size_t)NKT * 16 * HD * 2 : 0);
 }
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int HD, int NKT>
-__global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd_one_kernel(
+__global__ void __launch_bounds__((ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64, ONE_MINW) attn_bwd_one_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ bias, const int* __restrict__ rid, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
     bf16_t* __restrict__ dv, bf16_t* __restrict__ ds_out, float* __restrict__ trace, Geom G) {
-    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = HD + 8, NC = HD / 16, CH = HD / 8;
-    constexpr int NWC = ONE_CWAVES(NKT), NTHR = (NWC + 1) * 64, NQP = (NKT + 1) / 2;
+    constexpr int NK = NKT * 16, KS = (HD + 31) / 32, LDR = ONE_LDR(HD, NKT), NC = HD / 16, CH = HD / 8;
+    constexpr int NWC = ONE_CWAVES(NKT), NS = ONE_SWAVES(NKT), NTHR = (NWC + NS) * 64, NQP = (NKT + 1) / 2;
+    constexpr bool KREG = NKT <= 16;                         // K^T in the service wave's registers (else read from LDS per use)
 #ifdef ONE_TRACE           // probe build: s_memtime deltas of wave 0 (and the service wave's loop) into the unused dsum array
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #define ONE_T(i) if (trace && (threadIdx.x & 63) == 0) trace[(int64_t)blockIdx.x * 16 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start)
@@ -844,8 +850,8 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
     }
     // ---- staging, all threads: Q' and dO rows, D = rowsum(dO . O), -L; K rows (unpadded) into the second T buffer, which the
     // compute waves first write in step 1 — the service wave takes its K^T fragments from there right after the barrier
-    static_assert((size_t)NK * HD <= (size_t)NWC * TW, "K rows fit one T buffer");
-    bf16_t* Kst = T_s + NWC * TW;
+    static_assert(!KREG || (size_t)NK * HD <= (size_t)NWC * TW, "K rows fit one T buffer");
+    bf16_t* Kst = T_s + (KREG ? 1 : 2) * NWC * TW;           // kept for the whole kernel: its own region behind the T buffers
     {
         // every global load of the prologue goes out before the first result is used: ONE round trip instead of five
         // (two staging passes, -L, the region ids, the bias table: 20 000 of a workgroup's 46 000 cycles)
@@ -910,18 +916,24 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
     lds_barrier();                                           // B0
     if (wave == 0) { ONE_T(2); }
 
-    if (wave == NWC) {
-        // ================================================================= service wave
+    if (wave >= NWC) {
+        // ================================================================= service wave(s)
         // K^T of every key-tile pair: A[hd c*16 + lr][kappa] = K[key(kappa)][hd], kappa = lg*8 + j: j < 4 -> tile 2 jp, key
         // lg*4 + j; j >= 4 -> tile 2 jp + 1.  Unscaled: dQ = (dS . K) * scale.
-        Frag8 ktf[NWC][NC];
+        auto kt_frag = [&](int jp, int c) {
+            Frag8 f;
+            f.u2[0] = tr4(Kst, HD, (2 * jp) * 16 + lg * 4, c * 16, lr);
+            f.u2[1] = (2 * jp + 1 < NKT) ? tr4(Kst, HD, (2 * jp + 1) * 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
+            return f;
+        };
+        Frag8 ktf[KREG ? NWC : 1][NC];
+        if (KREG) {
 #pragma unroll
-        for (int jp = 0; jp < NWC; ++jp)
+            for (int jp = 0; jp < NWC; ++jp)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                ktf[jp][c].u2[0] = tr4(Kst, HD, (2 * jp) * 16 + lg * 4, c * 16, lr);
-                ktf[jp][c].u2[1] = (2 * jp + 1 < NKT) ? tr4(Kst, HD, (2 * jp + 1) * 16 + lg * 4, c * 16, lr) : make_uint2(0u, 0u);
-            }
+                for (int c = 0; c < NC; ++c) ktf[KREG ? jp : 0][c] = kt_frag(jp, c);
+        }
+        const int sw = wave - NWC;                           // two service waves: query tile `sw` of every chunk
         bf16_t* dsbase = (tb && ds_out) ? ds_out + (((int64_t)(grp - G.grp0) * G.g.nH + h) * nt * NKT * 64 + lane) * 4 : nullptr;
         // dQ of chunk pc from the T tiles in buffer bt.  All transposing reads of a query tile go out first, then the scratch
         // stores, then the MFMAs: with a read / wait / store per tile the wave spent 5 200 cycles per chunk and every compute
@@ -932,6 +944,7 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * pc + half;
                 if (qt >= NKT) break;
+                if (NS == 2 && half != sw) continue;
                 Frag8 bq[NWC];
 #pragma unroll
                 for (int jp = 0; jp < NWC; ++jp) {
@@ -949,7 +962,8 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + 1) * 64, ONE_MINW) attn_bwd
 #pragma unroll
                 for (int jp = 0; jp < NWC; ++jp)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) qacc[c] = mfma16(ktf[jp][c], bq[jp], qacc[c]);   // dQ^T[hd c*16+lg*4+r][query lr]
+                    for (int c = 0; c < NC; ++c)             // dQ^T[hd c*16+lg*4+r][query lr]
+                        qacc[c] = mfma16(KREG ? ktf[KREG ? jp : 0][c] : kt_frag(jp, c), bq[jp], qacc[c]);
                 const int qn = qt * 16 + lr;
                 if (qn < N) {
                     bf16_t* drow = dq + (int64_t)row_s[qn] * G.lddq + h * HD + lg * 4;
@@ -1595,7 +1609,7 @@ void set_attrs() {
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 1>));
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, false, 0>));
     CLV_ATTR((attn_bwd_dkv_kernel<HD, NKE, true, 0>));
-    if constexpr (HD == 32 && NKT == 13) CLV_ATTR((attn_bwd_one_kernel<HD, NKT>));
+    if constexpr (HD == 32 && (NKT == 13 || NKT == 25)) CLV_ATTR((attn_bwd_one_kernel<HD, NKT>));
 #undef CLV_ATTR
 }
 
@@ -1658,18 +1672,18 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         dv_out = dq_out + 2 * tc;
     }
     // Window mode, head dim 32, the two Swin window sizes: ONE kernel for dQ / dK / dV (+ the dS scratch), see
-    // attn_bwd_one_kernel.  CLV_ATTN_BWD_ONE: 0 = the two-kernel path, 1 (default) = when the (group, head) pairs alone
-    // fill the chip (tsplit == 1), 2 = whenever the shapes allow (tests).
+    // attn_bwd_one_kernel.  CLV_ATTN_BWD_ONE: 0 = the two-kernel path, 1 (default) = when there are (group, head) pairs for
+    // most of the chip (>= 192: Swin-B stage 3 at 8 clips, 256 pairs, 143 -> 101 us), 2 = whenever the shapes allow (tests).
     const char* one_env = getenv("CLV_ATTN_BWD_ONE");     // read per call: the tests switch it
     const int one_mode = one_env ? atoi(one_env) : 1;
     bool one = false;
-    if constexpr (HD == 32 && NKT == 13)
-        one = one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && stages == 7 && (G.tsplit == 1 || one_mode > 1) &&
-              (G.g.N + 15) / 16 == NKT && bias != nullptr && G.tbn <= 3 * (ONE_CWAVES(NKT) + 1) * 64 &&
+    if constexpr (HD == 32 && (NKT == 13 || NKT == 25))
+        one = one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && stages == 7 && (G.tsplit == 1 || G.g.groups * G.g.nH >= 192 || one_mode > 1) &&
+              (G.g.N + 15) / 16 == NKT && bias != nullptr && G.tbn <= 3 * (ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64 &&
               one_lds<HD, NKT>(bl) <= MAX_LDS;
     auto launch_one = [&](const Geom& Gx, int groups) {
-        if constexpr (HD == 32 && NKT == 13)
-            attn_bwd_one_kernel<HD, NKT><<<dim3(groups * G.g.nH), dim3((ONE_CWAVES(NKT) + 1) * 64), one_lds<HD, NKT>(bl), st>>>(
+        if constexpr (HD == 32 && (NKT == 13 || NKT == 25))
+            attn_bwd_one_kernel<HD, NKT><<<dim3(groups * G.g.nH), dim3((ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64), one_lds<HD, NKT>(bl), st>>>(
                 (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, lse, bias, rid,
                 dq_out, dk_out, dv_out, (bf16_t*)(bias ? work : nullptr), dsum, Gx);
     };

@@ -615,7 +615,11 @@ inline bool lnv_config(int C, LnvCfg& cfg) {
 }
 inline int lnv_blocks(int64_t rows, int group, bool fwd = false) {
     const int rpb = LN_WAVES * (64 / group);           // rows per block per pass
-    static const int cap_b = env_cap("CLV_LNV_GRID", 2048), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);   // forward: one pass per wave (-0.08 ms); backward: bounded (dgamma / dbeta partials)
+    // forward: one pass per wave (-0.08 ms); backward: bounded (dgamma / dbeta partials) — at 1 280 = 256 CUs x the 5 workgroups
+    // a CU holds (one 16-byte chunk per lane: 96 VGPRs, LNV_BWD_WAVES), so that every workgroup is resident and walks the same
+    // number of rows: 2 048 ran as one full round plus a 60 % one (round 4, same box: 11.99 -> 11.84 ms per step; 1 024, 1 536,
+    // 2 560: 11.98, 12.14, 12.08)
+    static const int cap_b = env_cap("CLV_LNV_GRID", 1280), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
     const int cap = fwd ? cap_f : cap_b;
     int64_t b = (rows + rpb - 1) / rpb;
     if (b > cap) b = cap;

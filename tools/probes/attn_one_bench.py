@@ -27,7 +27,10 @@ def graph_time(fn, n=10):
 
 
 out = []
-for (B, D, H, W, Cc, nH) in [(16, 4, 56, 56, 96, 3), (16, 4, 28, 28, 192, 6), (16, 4, 14, 14, 384, 12), (16, 4, 7, 7, 768, 24)]:
+SHAPES = {'T8': ([(16, 4, 56, 56, 96, 3), (16, 4, 28, 28, 192, 6), (16, 4, 14, 14, 384, 12), (16, 4, 7, 7, 768, 24)], (2, 2, 6, 2)),
+          'B16': ([(8, 8, 56, 56, 128, 4), (8, 8, 28, 28, 256, 8), (8, 8, 14, 14, 512, 16), (8, 8, 7, 7, 1024, 32)], (2, 2, 18, 2))}
+shapes, depths = SHAPES[os.environ.get('SHAPES', 'T8')]       # Swin-T 8 frames x 16 clips (196-token windows) / Swin-B 16 frames x 8 clips (392)
+for (B, D, H, W, Cc, nH) in shapes:
     ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), (4, 3, 3), 'cuda')
     N = ws[0] * ws[1] * ws[2]
     nW = (D // ws[0]) * (H // ws[1]) * (W // ws[2])
@@ -68,4 +71,4 @@ for (B, D, H, W, Cc, nH) in [(16, 4, 56, 56, 96, 3), (16, 4, 28, 28, 192, 6), (1
               f'stores issued {m[4]:.0f} || service: loop end {m[5]:.0f}, last dQ {m[6]:.0f} || cycles waiting at the chunk barriers: '
               f'wave 0 {m[7]:.0f}, last compute wave {m[9]:.0f}, service wave {m[8]:.0f}')
 print(os.environ.get('CLOVER_LIB_PATH', 'default').split('/')[-1], 'ONE=' + os.environ.get('CLV_ATTN_BWD_ONE', '1'),
-      ' '.join(f'{t:7.1f}' for t in out), f'| step total {2 * out[0] + 2 * out[1] + 6 * out[2] + 2 * out[3]:7.1f} us')
+      ' '.join(f'{t:7.1f}' for t in out), f'| step total {sum(d * t for d, t in zip(depths, out)):7.1f} us')
