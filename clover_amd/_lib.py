@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -62,6 +62,7 @@ SIGNATURES = {
     'clv_attn_seq_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_seq_max_keys': (C.c_int, []),
     'clv_attn_bwd_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
+    'clv_attn_bwd_one_kernel': (C.c_int, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index_count': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),

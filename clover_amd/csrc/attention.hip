@@ -1643,6 +1643,23 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     return clv_check_launch();
 }
 
+// Window mode, head dim 32, the two Swin window sizes: ONE kernel for dQ / dK / dV (+ the dS scratch), see
+// attn_bwd_one_kernel.  CLV_ATTN_BWD_ONE: 0 = the two-kernel path, 1 (default) = when there are (group, head) pairs for
+// most of the chip (>= 192: Swin-B stage 3 at 8 clips, 256 pairs, 143 -> 101 us), 2 = whenever the shapes allow (tests).
+template <int HD, int NKT>
+bool one_eligible(const Geom& G, bool has_bias) {
+    if constexpr (HD == 32 && (NKT == 13 || NKT == 25)) {
+        const char* one_env = getenv("CLV_ATTN_BWD_ONE");     // read per call: the tests switch it
+        const int one_mode = one_env ? atoi(one_env) : 1;
+        return one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && !G.drop_thresh &&
+               (G.tsplit == 1 || G.g.groups * G.g.nH >= 192 || one_mode > 1) && (G.g.N + 15) / 16 == NKT && has_bias &&
+               G.tbn <= 3 * (ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64 && one_lds<HD, NKT>(G.tls) <= MAX_LDS;
+    }
+    return false;
+}
+template <int HD, int NKT>
+int query_one(const Geom& G) { return one_eligible<HD, NKT>(G, true) ? 1 : 0; }
+
 template <int HD, int NKT>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                const float* lse, const float* bias, const int32_t* rid, const float* kmask, void* dq,
@@ -1671,16 +1688,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         dk_out = dq_out + tc;
         dv_out = dq_out + 2 * tc;
     }
-    // Window mode, head dim 32, the two Swin window sizes: ONE kernel for dQ / dK / dV (+ the dS scratch), see
-    // attn_bwd_one_kernel.  CLV_ATTN_BWD_ONE: 0 = the two-kernel path, 1 (default) = when there are (group, head) pairs for
-    // most of the chip (>= 192: Swin-B stage 3 at 8 clips, 256 pairs, 143 -> 101 us), 2 = whenever the shapes allow (tests).
-    const char* one_env = getenv("CLV_ATTN_BWD_ONE");     // read per call: the tests switch it
-    const int one_mode = one_env ? atoi(one_env) : 1;
-    bool one = false;
-    if constexpr (HD == 32 && (NKT == 13 || NKT == 25))
-        one = one_mode > 0 && G.g.mode == 1 && G.nparts == 1 && stages == 7 && (G.tsplit == 1 || G.g.groups * G.g.nH >= 192 || one_mode > 1) &&
-              (G.g.N + 15) / 16 == NKT && bias != nullptr && G.tbn <= 3 * (ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64 &&
-              one_lds<HD, NKT>(bl) <= MAX_LDS;
+    // stage masks of the one-kernel form: 5 = the kernel alone (dQ + dK / dV + dS scratch), 2 = the table gradient, 7 = both
+    const bool one = one_eligible<HD, NKT>(G, bias != nullptr) && (stages & 5) == 5;
     auto launch_one = [&](const Geom& Gx, int groups) {
         if constexpr (HD == 32 && (NKT == 13 || NKT == 25))
             attn_bwd_one_kernel<HD, NKT><<<dim3(groups * G.g.nH), dim3((ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64), one_lds<HD, NKT>(bl), st>>>(
@@ -1809,6 +1818,13 @@ extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
     const int nkt = pick_nkt(G.g.N);
     if (nkt < 0) return 0;
     return ds_scratch_bytes(G, nkt) + (int64_t)(DBIAS_SPLITS + 1) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;   // + fp32 partials, dense
+}
+
+extern "C" int clv_attn_bwd_one_kernel(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0 || G.g.hd != 32) return 0;
+    const int nkt = pick_nkt(G.g.N);
+    DISPATCH_NKT(32, query_one, G)
 }
 
 extern "C" int64_t clv_attn_seq_work_bytes(const ClvAttnGeom* geom) {

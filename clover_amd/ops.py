@@ -1397,6 +1397,11 @@ class _Attention(torch.autograd.Function):
                 C.c_void_p(d + 4 * Cdim), _ptr(dtab), _ptr(dsum), _ptr(work), _ptr(seed))
         if PROF is None:
             check(L.clv_attn_bwd(*args, 0, C.byref(g), _stream()), 'clv_attn_bwd')
+        elif tab is not None and L.clv_attn_bwd_one_kernel(C.byref(g)) == 1:
+            fl, by = _attn_work(g, True)           # dQ / dK / dV as one kernel (stage mask 5), then the table gradient (2)
+            with _Timed(f'attn_bwd_one_kernel<{g.hd}, {(g.N + 15) // 16}>', fl, by):
+                check(L.clv_attn_bwd(*args, 5, C.byref(g), _stream()), 'clv_attn_bwd')
+            check(L.clv_attn_bwd(*args, 2, C.byref(g), _stream()), 'clv_attn_bwd')
         else:                                  # one event pair per device kernel (work split 2:3 of the 5 matmuls)
             fl, by = _attn_work(g, True)
             with _Timed(_kname('attn_bwd_dq_kernel', g), fl * 0.4, by * 0.5):

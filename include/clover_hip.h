@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 8
+#define CLV_ABI_VERSION 9
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -87,6 +87,9 @@ int clv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * work: scratch of clv_attn_bwd_work_bytes() bytes (the bf16 dS of every (group, head), summed over the groups
  * and scattered into dbias by a second kernel), required iff bias != NULL. */
 int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom_host);
+/* 1 if clv_attn_bwd runs this geometry (with a bias table) as ONE kernel for dQ / dK / dV (round 4: window mode, head dim 32,
+ * 196- / 392-token windows) — `stages` then knows the masks 5 (that kernel) and 2 (the table gradient) instead of 1 / 2 / 4. */
+int clv_attn_bwd_one_kernel(const ClvAttnGeom* geom_host);
 /* int32 [clv_attn_dbias_index_count()]: fragment offset of the (query, key) pair of every (bias-table row, key), -1 = none;
  * depends on (N, bwd, bwh, bww) only — build once, pass in ClvAttnGeom.dbias_index of every backward call. */
 int64_t clv_attn_dbias_index_count(const ClvAttnGeom* geom_host);

@@ -186,6 +186,58 @@ def test_merge_layer_norm(B, D, H, W, C, with_res, with_scale):
         assert xg.grad[0].abs().max().item() == 0.0          # dropped path: no gradient into the branch
 
 
+@pytest.mark.parametrize('D,N', [(4, 196), (16, 392)])
+def test_window_attention_one_kernel_stage_masks(D, N, monkeypatch):
+    """clv_attn_bwd on the one-kernel geometries: `clv_attn_bwd_one_kernel` reports them, the stage masks 5 (dQ / dK / dV
+    kernel) + 2 (table gradient) together give what one call with stages = 0 gives, and both agree with the two-kernel path."""
+    import ctypes as C
+    from clover_amd import _lib
+    from clover_amd._lib import ClvAttnGeom
+    from clover_amd.backbones.swin_transformer_3d import window_geometry
+    L = _lib.lib()
+    B, H, W, Cc, nH = 2, 14, 14, 64, 2
+    ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), (4, 3, 3), DEV)
+    assert ws[0] * ws[1] * ws[2] == N
+    nW = (D // ws[0]) * (H // ws[1]) * (W // ws[2])
+    hd = Cc // nH
+    g = ClvAttnGeom(mode=1, groups=B * nW, N=N, nH=nH, hd=hd, D=D, H=H, W=W, wd=ws[0], wh=ws[1], ww=ws[2], sd=ss[0], sh=ss[1],
+                    sw=ss[2], ldq=3 * Cc, ldk=3 * Cc, ldv=3 * Cc, ldo=Cc, bwd=8, bwh=7, bww=7, scale=hd ** -0.5, dropout_p=0.0)
+    qkv = rnd(B, D, H, W, 3 * Cc, seed=31).to(BF).to(DEV)
+    table = rnd(15 * 13 * 13, nH, scale=0.5, seed=32).to(DEV)
+    do = rnd(B, D, H, W, Cc, seed=33).to(BF).to(DEV)
+    o = torch.empty(B, D, H, W, Cc, device=DEV, dtype=BF)
+    lse = torch.empty(g.groups * nH * N, device=DEV)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = qkv.data_ptr()
+    assert L.clv_attn_fwd(C.c_void_p(p), C.c_void_p(p + 2 * Cc), C.c_void_p(p + 4 * Cc), P(o), P(lse), P(table), P(rid), None, None,
+                          C.byref(g), st) == 0
+    g.dbias_index = ops()._dbias_index(g, qkv.device)
+    work = torch.empty(L.clv_attn_bwd_work_bytes(C.byref(g)), device=DEV, dtype=torch.uint8)
+    dsum = torch.empty_like(lse)
+
+    def run(masks):
+        dqkv = torch.zeros_like(qkv)
+        dtab = torch.zeros_like(table)
+        d = dqkv.data_ptr()
+        for m in masks:
+            rc = L.clv_attn_bwd(C.c_void_p(p), C.c_void_p(p + 2 * Cc), C.c_void_p(p + 4 * Cc), P(o), P(do), P(lse), P(table), P(rid),
+                                None, C.c_void_p(d), C.c_void_p(d + 2 * Cc), C.c_void_p(d + 4 * Cc), P(dtab), P(dsum), P(work), None, m,
+                                C.byref(g), st)
+            assert rc == 0, (m, rc)
+        torch.cuda.synchronize()
+        return dqkv.float().cpu(), dtab.cpu()
+    monkeypatch.setenv('CLV_ATTN_BWD_ONE', '2')
+    assert L.clv_attn_bwd_one_kernel(C.byref(g)) == 1
+    a_q, a_t = run([0])
+    b_q, b_t = run([5, 2])
+    assert torch.equal(a_q, b_q) and rel(a_t, b_t) < 1e-6
+    monkeypatch.setenv('CLV_ATTN_BWD_ONE', '0')
+    assert L.clv_attn_bwd_one_kernel(C.byref(g)) == 0
+    c_q, c_t = run([0])
+    assert rel(a_q, c_q) < 2e-2 and rel(a_t, c_t) < 2e-2, (rel(a_q, c_q), rel(a_t, c_t))
+
+
 # ----------------------------------------------------------------------------- sequence attention
 @pytest.mark.parametrize('B,S,nH,hd', [(3, 16, 2, 64), (2, 32, 12, 64), (2, 228, 12, 64), (2, 40, 4, 32), (1, 408, 2, 64)])
 def test_seq_attention(B, S, nH, hd):
