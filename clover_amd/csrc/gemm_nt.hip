@@ -90,6 +90,19 @@ __device__ __forceinline__ void gn_dma_block<1>(unsigned lds, const unsigned (&v
         : "memory", "scc");
 }
 template <>
+__device__ __forceinline__ void gn_dma_block<3>(unsigned lds, const unsigned (&v)[3], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [b] "s"(base)
+        : "memory", "scc");
+}
+template <>
 __device__ __forceinline__ void gn_dma_block<2>(unsigned lds, const unsigned (&v)[2], const bf16_t* base) {
     unsigned keep;
     asm volatile(
@@ -1277,6 +1290,18 @@ GnPlan gn_plan(int64_t M, int N, int K, bool allow_split) {
         p.ws = 1;
         p.BM = 128;
     }
+    // Outputs of 192 / 384 / 576 columns (every width of Swin-T's stages 1-2) on many rows: 128 x 192 tiles — 128-column
+    // tiles leave a quarter of the MFMAs of N = 192 on clamped columns, and 98 x 3 tiles of N = 384 run as two rounds on 256
+    // CUs where 98 x 2 run as one (cold weights, us: fc2 s1 30.3 -> 26.1, dqkv s1 25.4 -> 21.5, fc2 s2 28.9 -> 23.1, dqkv s2
+    // 22.9 -> 18.8, merge s2 17.5 -> 14.9, proj s1 / s2 14.1 -> 12.7 / 11.1 -> 10.3; library 23.1 / 20.6 / 21.8 / 17.8 / 13.0 /
+    // 13.4 / 12.8).  N = 1 152 and the M ~ 3 000 shapes lose on it (qkv s2 20.6 -> 23.9, fc2 s3 28.0 -> 39.0).
+    if (!p.ws && gn_env_int("CLV_GEMM_T192", 1) && N % 192 == 0 && N <= 576 && M >= 8192) {
+        p.BM = 128;
+        p.BN = 192;
+        p.W = 8;
+        p.r2 = false;
+        return p;
+    }
     if (allow_split && force_s > 1 && nst / force_s >= 2 && K >= 1536 && tiles128 <= 256) p.splitk = force_s;
     if (p.splitk > 1 && !p.ws) p.BM = 128;
     if (p.BM == 128 && w8 && !p.ws) { p.W = 8; p.r2 = true; }
@@ -1375,6 +1400,7 @@ int gn_run(const void* a, const void* b, const float* bias, const void* aux, voi
     if (BM == 64 && BN == 128 && W == 4) return gn_launch<64, 128, 2, 2, 3>(GN_ARGS);     // 24 KiB stages x 3, two WGs per CU
     if (BM == 64 && BN == 128 && W == 8) return gn_launch<64, 128, 2, 4, 3>(GN_ARGS);     // the same ring on eight waves of 32 x 32
     if (BM == 64 && BN == 64 && W == 2) return gn_launch<64, 64, 1, 2, 3>(GN_ARGS);       // 16 KiB stages x 3, three WGs per CU
+    if (BM == 128 && BN == 192 && W == 8) return gn_launch<128, 192, 4, 2, 3>(GN_ARGS);   // 40 KiB stages x 3, eight waves of 32 x 96
 #undef GN_ARGS
     return CLV_ERR_UNSUPPORTED;
 }
