@@ -861,10 +861,22 @@ def fused_block_supported(C_, hidden):
             and hidden % 32 == 0)
 
 
+def _fp8_side(x):
+    """(q8, scale) the producing LayerNorm left on x, if x has not been written since."""
+    side = getattr(x, '_clv_fp8', None) if FP8 else None
+    if side is None:
+        return None
+    if len(side) == 3:
+        if side[2] != x._version:
+            return None
+        side = side[:2]
+    return side
+
+
 def linear(x, weight, bias=None):
     if parity.enabled():
         return parity.linear(x, weight, bias)
-    return _Linear.apply(x, weight, bias, getattr(x, '_clv_fp8', None) if FP8 else None)
+    return _Linear.apply(x, weight, bias, _fp8_side(x))
 
 
 def _param_grads(dy2, x2, weight, bias):
@@ -941,7 +953,7 @@ def mlp_gelu_ok(x, hidden):
 
 
 def mlp_gelu(x, w1, b1, w2, b2):
-    return _MlpGelu.apply(x, w1, b1, w2, b2, getattr(x, '_clv_fp8', None) if FP8 else None)
+    return _MlpGelu.apply(x, w1, b1, w2, b2, _fp8_side(x))
 
 
 # --------------------------------------------------------------------------- LDS-tiled GEMM with fused epilogues
@@ -1193,9 +1205,11 @@ def layer_norm(x, weight, bias, eps=1e-5, residual=None, return_sum=False, x_sca
     _LN_FP8_OUT = None
     y, s, y2 = _LayerNorm.apply(x, residual, weight, bias, eps, bool(return_sum), x_scale, float(x_dropout_p), bool(fork))
     if _LN_FP8_OUT is not None:               # the consumer GEMM (ops.linear / ops.mlp_gelu) picks the operand up from here
-        y._clv_fp8 = _LN_FP8_OUT
+        # ... bound to the tensor's VERSION: an in-place write to y between the LayerNorm and its Linear (dropout_, add_, a
+        # mask) bumps it, and _fp8_side() then drops the quantised copy instead of multiplying stale data
+        y._clv_fp8 = _LN_FP8_OUT + (y._version,)
         if y2 is not None:
-            y2._clv_fp8 = _LN_FP8_OUT
+            y2._clv_fp8 = _LN_FP8_OUT + (y2._version,)
         _LN_FP8_OUT = None
     out = (y,) + ((s,) if return_sum else ()) + ((y2,) if fork else ())
     return out if len(out) > 1 else y

@@ -116,7 +116,7 @@ def test_layernorm_emits_fp8_operand(rows, C, monkeypatch):
     g, b = (1 + 0.1 * rnd(C, seed=33)).to(DEV), (0.1 * rnd(C, seed=34)).to(DEV)
     y, ssum = ops.layer_norm(x, g, b, 1e-5, residual=r, return_sum=True)
     assert hasattr(y, '_clv_fp8')
-    q, sc = y._clv_fp8
+    q, sc = ops._fp8_side(y)
     assert q.shape == (rows, C) and q.dtype == torch.uint8
     amax = y.float().abs().amax(1)
     assert torch.allclose(sc, amax / 448.0, rtol=2 ** -7)                       # y is the bf16 rounding of what was scaled
@@ -126,6 +126,11 @@ def test_layernorm_emits_fp8_operand(rows, C, monkeypatch):
     c_fused = ops.gemm_nt_fp8(y, w, None, aq8=(q, sc))
     c_pass = ops.gemm_nt_fp8(y, w, None)
     assert rel(c_fused, c_pass) < 4e-2            # fp32 y vs its bf16 rounding as the quantised value: e4m3 ties flip
+    # the pair is bound to y's version: an in-place write between the LayerNorm and its Linear drops it
+    yw = ops.layer_norm(x, g, b, 1e-5, residual=r)
+    assert ops._fp8_side(yw) is not None
+    yw.mul_(2.0)
+    assert ops._fp8_side(yw) is None
     monkeypatch.setattr(ops, 'FP8', False)
     y2 = ops.layer_norm(x, g, b, 1e-5, residual=r)
     assert not hasattr(y2, '_clv_fp8') and torch.equal(y2, y)
