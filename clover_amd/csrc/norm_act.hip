@@ -613,14 +613,18 @@ inline bool lnv_config(int C, LnvCfg& cfg) {
     }
     return true;
 }
-inline int lnv_blocks(int64_t rows, int group, bool fwd = false) {
+inline int lnv_blocks(int64_t rows, int group, bool fwd = false, int iters = 1) {
     const int rpb = LN_WAVES * (64 / group);           // rows per block per pass
     // forward: one pass per wave (-0.08 ms); backward: bounded (dgamma / dbeta partials) — at 1 280 = 256 CUs x the 5 workgroups
     // a CU holds (one 16-byte chunk per lane: 96 VGPRs, LNV_BWD_WAVES), so that every workgroup is resident and walks the same
     // number of rows: 2 048 ran as one full round plus a 60 % one (round 4, same box: 11.99 -> 11.84 ms per step; 1 024, 1 536,
     // 2 560: 11.98, 12.14, 12.08)
     static const int cap_b = env_cap("CLV_LNV_GRID", 1280), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
-    const int cap = fwd ? cap_f : cap_b;
+    // rows wider than 512 elements (two+ chunks per lane: C = 768 of stage 3 / the fusion encoder, 3 136-3 648 rows): 512
+    // blocks of ~2 rows per wave write half the dgamma / dbeta partial rows of 912 one-row-per-wave blocks (5.6 MB beside 22 MB
+    // of operands): 11.39 -> 11.36 ms per step, twice; 256: 11.47
+    static const int cap_b2 = env_cap("CLV_LNV_GRID2", 512);
+    const int cap = fwd ? cap_f : (iters > 1 ? cap_b2 : cap_b);
     int64_t b = (rows + rpb - 1) / rpb;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -757,7 +761,7 @@ extern "C" int clv_layernorm_fwd(const void* x, const void* res, const float* ga
 
 extern "C" int clv_layernorm_bwd_blocks(int64_t rows, int32_t C) {
     LnvCfg cfg;
-    if (lnv_config(C, cfg)) return lnv_blocks(rows, cfg.group);
+    if (lnv_config(C, cfg)) return lnv_blocks(rows, cfg.group, false, cfg.iters);
     int64_t b = (rows + LN_WAVES - 1) / LN_WAVES;      // one row per wave until the chip is full
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
