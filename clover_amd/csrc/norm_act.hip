@@ -467,8 +467,11 @@ __global__ void __launch_bounds__(LN_THREADS) lnv_fwd_kernel(
     }
 }
 
+#ifndef LNV_BWD_RG2
+#define LNV_BWD_RG2 3       // row groups in flight per trip (one-chunk-per-lane bf16 kernels); 1 = the plain loop
+#endif
 #ifndef LNV_BWD_WAVES
-#define LNV_BWD_WAVES 5
+#define LNV_BWD_WAVES (LNV_BWD_RG2 >= 3 ? 3 : LNV_BWD_RG2 == 2 ? 4 : 5)
 #endif
 // dx = d t * (x multiplier) [-> dx], d t itself [-> dres, when given];  d t = LN-backward(dy (+ dy2)) (+ dsum)
 template <int GROUP, int ITERS, typename T, bool XF>
@@ -490,6 +493,103 @@ __global__ void __launch_bounds__(LN_THREADS, ITERS == 1 ? LNV_BWD_WAVES : 1) ln
     for (int i = 0; i < ITERS; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = 0.f;
+    // One chunk per lane, bf16 storage (Swin stages 0-2: C = 96 / 192 / 384): RG row groups per trip, the raw 16-byte loads of
+    // all of them issued before anything is converted — a wave keeps RG times the bytes in flight.  These kernels run at the
+    // rate their waves' loads are outstanding, not at the HBM's (the plain loop at 4 instead of 5 waves per SIMD: +25 %,
+    // 11.24 -> 11.37 ms per step).  The groups are then worked off one at a time.  Same box, ms per step: plain loop, 5 waves
+    // 11.41; RG = 2, 4 waves 11.45; RG = 3, 3 waves (<= 168 VGPRs) 11.33.
+    if (LNV_BWD_RG2 > 1 && ITERS == 1 && sizeof(T) == 2 && rows * C < (1ll << 31)) {      // 32-bit element offsets below
+        constexpr int RG = LNV_BWD_RG2 > 1 ? LNV_BWD_RG2 : 2;
+        const int c = gl * 8;
+        const bool cv = c < C;
+        float gm[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[e] = 0.f;
+        if (cv) ld8f(gamma + c, gm);
+        for (int64_t row0 = wave * RPW; row0 < rows; row0 += RG * stride) {
+            int64_t row[RG];
+            unsigned off[RG], offd[RG];
+            bool live[RG];
+            uint4 rx[RG], rr[RG], rd[RG], rd2[RG], ra[RG];
+            float mu[RG], rs[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                row[g] = row0 + g * stride + sub;
+                live[g] = row[g] < rows && cv;
+                rx[g] = rr[g] = rd[g] = rd2[g] = ra[g] = make_uint4(0, 0, 0, 0);
+                mu[g] = rs[g] = 0.f;
+                off[g] = offd[g] = 0;
+                if (live[g]) {
+                    // wave-uniform bases + 32-bit lane offsets: a 64-bit address pair per load is what does not fit
+                    offd[g] = (unsigned)(row[g] * C + c);
+                    off[g] = XF ? (unsigned)ln_src_off(xf, row[g], c, C) : offd[g];
+                    rx[g] = *reinterpret_cast<const uint4*>(x + off[g]);
+                    if (res) rr[g] = *reinterpret_cast<const uint4*>(res + off[g]);
+                    rd[g] = *reinterpret_cast<const uint4*>(dy + offd[g]);
+                    if (dy2) rd2[g] = *reinterpret_cast<const uint4*>(dy2 + offd[g]);
+                    if (dsum) ra[g] = *reinterpret_cast<const uint4*>(dsum + offd[g]);
+                    mu[g] = mean[row[g]];
+                    rs[g] = rstd[row[g]];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+                auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+                const uint32_t* wx = reinterpret_cast<const uint32_t*>(&rx[g]);      // (register views: these are values)
+                float tt[8], dd[8];
+                const uint32_t ux[4] = {rx[g].x, rx[g].y, rx[g].z, rx[g].w}, ur[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};
+                const uint32_t ud[4] = {rd[g].x, rd[g].y, rd[g].z, rd[g].w}, ud2[4] = {rd2[g].x, rd2[g].y, rd2[g].z, rd2[g].w};
+                const uint32_t ua[4] = {ra[g].x, ra[g].y, ra[g].z, ra[g].w};
+                (void)wx;
+                float xs = 1.f;
+                unsigned long long sd = 0;
+                if (XF && live[g]) {
+                    if (xf.xscale) xs = xf.xscale[row[g] / xf.rows_per_sample];
+                    if (xf.thresh) sd = *xf.seed;
+                }
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = (e & 1) ? hi(ux[e >> 1]) : lo(ux[e >> 1]);
+                    const float rv = (e & 1) ? hi(ur[e >> 1]) : lo(ur[e >> 1]);
+                    float k = 1.f;
+                    if (XF) {
+                        k = xs;
+                        if (xf.thresh) k *= ln_keep(sd, (unsigned)row[g], (unsigned)(c + e), xf.thresh, xf.inv_keep);
+                    }
+                    const float tv = ((XF && xf.on_load != 0) ? xv * k : xv) + rv;
+                    const float dv = ((e & 1) ? hi(ud[e >> 1]) : lo(ud[e >> 1])) + ((e & 1) ? hi(ud2[e >> 1]) : lo(ud2[e >> 1]));
+                    const float xh = live[g] ? (tv - mu[g]) * rs[g] : 0.f;
+                    tt[e] = xh;
+                    dg[0][e] += dv * xh;
+                    db[0][e] += dv;
+                    dd[e] = dv * gm[e];
+                    s1 += dd[e];
+                    s2 += dd[e] * xh;
+                }
+                s1 = group_sum<GROUP>(s1) * invC;
+                s2 = group_sum<GROUP>(s2) * invC;
+                if (live[g]) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        o[e] = rs[g] * (dd[e] - s1 - tt[e] * s2) + ((e & 1) ? hi(ua[e >> 1]) : lo(ua[e >> 1]));
+                    if (dres) IO8<T>::st(dres + off[g], o);
+                    if (XF) {                                // the x multiplier again (DropPath scale; dropout keep re-hashed)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float k = xs;
+                            if (xf.thresh) k *= ln_keep(sd, (unsigned)row[g], (unsigned)(c + e), xf.thresh, xf.inv_keep);
+                            o[e] *= k;
+                        }
+                    }
+                    IO8<T>::st(dx + off[g], o);
+                }
+                __builtin_amdgcn_sched_barrier(0);           // one group's fp32 expansion at a time
+            }
+        }
+    } else
     for (int64_t row0 = wave * RPW; row0 < rows; row0 += stride) {
         const int64_t row = row0 + sub;
         const bool live = row < rows;
@@ -619,7 +719,8 @@ inline int lnv_blocks(int64_t rows, int group, bool fwd = false, int iters = 1) 
     // a CU holds (one 16-byte chunk per lane: 96 VGPRs, LNV_BWD_WAVES), so that every workgroup is resident and walks the same
     // number of rows: 2 048 ran as one full round plus a 60 % one (round 4, same box: 11.99 -> 11.84 ms per step; 1 024, 1 536,
     // 2 560: 11.98, 12.14, 12.08)
-    static const int cap_b = env_cap("CLV_LNV_GRID", 1280), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
+    // (since the one-chunk kernels keep three row groups in flight at 3 waves per SIMD: 768 resident workgroups)
+    static const int cap_b = env_cap("CLV_LNV_GRID", LNV_BWD_WAVES * 256), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
     // rows wider than 512 elements (two+ chunks per lane: C = 768 of stage 3 / the fusion encoder, 3 136-3 648 rows): 512
     // blocks of ~2 rows per wave write half the dgamma / dbeta partial rows of 912 one-row-per-wave blocks (5.6 MB beside 22 MB
     // of operands): 11.39 -> 11.36 ms per step, twice; 256: 11.47
