@@ -473,10 +473,15 @@ __global__ void __launch_bounds__(LN_THREADS) lnv_fwd_kernel(
 #ifndef LNV_BWD_WAVES
 #define LNV_BWD_WAVES (LNV_BWD_RG2 >= 3 ? 3 : LNV_BWD_RG2 == 2 ? 4 : 5)
 #endif
+// ... for rows of <= 32 chunks (C <= 256: Swin stages 0-1, 50 000-200 000 rows = 3-5 full trips per wave).  One row per wave
+// (C = 384, 12 544 rows: 4 rows per wave) stays on the plain loop at 5 waves: three-at-a-time leaves it a ragged second trip
+// and the transform variants spill there (19.6 vs 17 us per launch).
+#define LNV_RG_ON(GROUP, ITERS, T) (LNV_BWD_RG2 > 1 && (ITERS) == 1 && sizeof(T) == 2 && (GROUP) <= 32)
+#define LNV_BWD_MINW(GROUP, ITERS, T) ((ITERS) != 1 ? 1 : (LNV_RG_ON(GROUP, ITERS, T) ? LNV_BWD_WAVES : 5))
 // dx = d t * (x multiplier) [-> dx], d t itself [-> dres, when given];  d t = LN-backward(dy (+ dy2)) (+ dsum)
 template <int GROUP, int ITERS, typename T, bool XF>
 // one 16-byte chunk per lane (ITERS == 1): 96 VGPRs = 5 waves per SIMD (the transform variants wanted 98-112: 4)
-__global__ void __launch_bounds__(LN_THREADS, ITERS == 1 ? LNV_BWD_WAVES : 1) lnv_bwd_kernel(
+__global__ void __launch_bounds__(LN_THREADS, LNV_BWD_MINW(GROUP, ITERS, T)) lnv_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x, const T* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     const T* __restrict__ dsum, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial,
@@ -498,7 +503,7 @@ __global__ void __launch_bounds__(LN_THREADS, ITERS == 1 ? LNV_BWD_WAVES : 1) ln
     // rate their waves' loads are outstanding, not at the HBM's (the plain loop at 4 instead of 5 waves per SIMD: +25 %,
     // 11.24 -> 11.37 ms per step).  The groups are then worked off one at a time.  Same box, ms per step: plain loop, 5 waves
     // 11.41; RG = 2, 4 waves 11.45; RG = 3, 3 waves (<= 168 VGPRs) 11.33.
-    if (LNV_BWD_RG2 > 1 && ITERS == 1 && sizeof(T) == 2 && rows * C < (1ll << 31)) {      // 32-bit element offsets below
+    if (LNV_RG_ON(GROUP, ITERS, T) && rows * C < (1ll << 31)) {      // 32-bit element offsets below
         constexpr int RG = LNV_BWD_RG2 > 1 ? LNV_BWD_RG2 : 2;
         const int c = gl * 8;
         const bool cv = c < C;
@@ -720,12 +725,13 @@ inline int lnv_blocks(int64_t rows, int group, bool fwd = false, int iters = 1) 
     // number of rows: 2 048 ran as one full round plus a 60 % one (round 4, same box: 11.99 -> 11.84 ms per step; 1 024, 1 536,
     // 2 560: 11.98, 12.14, 12.08)
     // (since the one-chunk kernels keep three row groups in flight at 3 waves per SIMD: 768 resident workgroups)
-    static const int cap_b = env_cap("CLV_LNV_GRID", LNV_BWD_WAVES * 256), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
+    static const int cap_b = env_cap("CLV_LNV_GRID", 0), cap_f = env_cap("CLV_LNV_FWD_GRID", 1 << 20);
     // rows wider than 512 elements (two+ chunks per lane: C = 768 of stage 3 / the fusion encoder, 3 136-3 648 rows): 512
     // blocks of ~2 rows per wave write half the dgamma / dbeta partial rows of 912 one-row-per-wave blocks (5.6 MB beside 22 MB
     // of operands): 11.39 -> 11.36 ms per step, twice; 256: 11.47
     static const int cap_b2 = env_cap("CLV_LNV_GRID2", 512);
-    const int cap = fwd ? cap_f : (iters > 1 ? cap_b2 : cap_b);
+    // one chunk per lane: every workgroup resident — 3 per CU where three row groups are in flight, else 5
+    const int cap = fwd ? cap_f : (iters > 1 ? cap_b2 : (cap_b > 0 ? cap_b : (group <= 32 && LNV_BWD_RG2 > 1 ? LNV_BWD_WAVES : 5) * 256));
     int64_t b = (rows + rpb - 1) / rpb;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
