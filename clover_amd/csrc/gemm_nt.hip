@@ -90,6 +90,22 @@ __device__ __forceinline__ void gn_dma_block<1>(unsigned lds, const unsigned (&v
         : "memory", "scc");
 }
 template <>
+__device__ __forceinline__ void gn_dma_block<6>(unsigned lds, const unsigned (&v)[6], const bf16_t* base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b]\n\t"
+        "s_add_u32 m0, %[lds], 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[b]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(lds), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [b] "s"(base)
+        : "memory", "scc");
+}
+template <>
 __device__ __forceinline__ void gn_dma_block<3>(unsigned lds, const unsigned (&v)[3], const bf16_t* base) {
     unsigned keep;
     asm volatile(
@@ -1295,10 +1311,13 @@ GnPlan gn_plan(int64_t M, int N, int K, bool allow_split) {
     // CUs where 98 x 2 run as one (cold weights, us: fc2 s1 30.3 -> 26.1, dqkv s1 25.4 -> 21.5, fc2 s2 28.9 -> 23.1, dqkv s2
     // 22.9 -> 18.8, merge s2 17.5 -> 14.9, proj s1 / s2 14.1 -> 12.7 / 11.1 -> 10.3; library 23.1 / 20.6 / 21.8 / 17.8 / 13.0 /
     // 13.4 / 12.8).  N = 1 152 and the M ~ 3 000 shapes lose on it (qkv s2 20.6 -> 23.9, fc2 s3 28.0 -> 39.0).
+    // Where the 128 x 192 tiles do not fill the chip once (12 544 rows x 384 columns: 196 tiles), 64 x 192 tiles on four waves,
+    // two workgroups per CU: fc2 s2 23.0 -> 21.9, dqkv s2 18.6 -> 17.7, merge s2 14.7 -> 13.5, proj s2 10.2 -> 9.6.
     if (!p.ws && gn_env_int("CLV_GEMM_T192", 1) && N % 192 == 0 && N <= 576 && M >= 8192) {
-        p.BM = 128;
+        const bool small = ((M + 127) / 128) * (N / 192) <= 256;
+        p.BM = small ? 64 : 128;
         p.BN = 192;
-        p.W = 8;
+        p.W = small ? 4 : 8;
         p.r2 = false;
         return p;
     }
@@ -1386,7 +1405,7 @@ int gn_run(const void* a, const void* b, const float* bias, const void* aux, voi
 #undef GN_WARGS
     }
     // persistent workgroups: per_cu per CU, 32 * per_cu slots per XCD, never more than the fullest XCD's units
-    const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 3 : (BM == 128 && W == 8 && r2) ? 2 : 1;
+    const int per_cu = (BM == 128 && W == 4) ? 2 : (BM == 64 && (BN == 128 || BN == 192)) ? 2 : (BM == 64 && BN == 64) ? 3 : (BM == 128 && W == 8 && r2) ? 2 : 1;
     const int pc = gn_pick_pc((int64_t)M * K * 2, (int64_t)N * K * 2, tilesN);
     const int max_units_xcd = ((nmblk + 8 / pc - 1) / (8 / pc)) * ((tilesN + pc - 1) / pc) * pl.splitk;
     const unsigned grid = (unsigned)(8 * (max_units_xcd < 32 * per_cu ? max_units_xcd : 32 * per_cu));
@@ -1401,6 +1420,7 @@ int gn_run(const void* a, const void* b, const float* bias, const void* aux, voi
     if (BM == 64 && BN == 128 && W == 8) return gn_launch<64, 128, 2, 4, 3>(GN_ARGS);     // the same ring on eight waves of 32 x 32
     if (BM == 64 && BN == 64 && W == 2) return gn_launch<64, 64, 1, 2, 3>(GN_ARGS);       // 16 KiB stages x 3, three WGs per CU
     if (BM == 128 && BN == 192 && W == 8) return gn_launch<128, 192, 4, 2, 3>(GN_ARGS);   // 40 KiB stages x 3, eight waves of 32 x 96
+    if (BM == 64 && BN == 192 && W == 4) return gn_launch<64, 192, 2, 2, 2>(GN_ARGS);     // 32 KiB stages x 2, four waves of 32 x 96, two WGs per CU
 #undef GN_ARGS
     return CLV_ERR_UNSUPPORTED;
 }

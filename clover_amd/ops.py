@@ -972,6 +972,8 @@ def _gemm_kname(M, N, K, epi, fp8, split=False):
     if (ws & 1) and t128 <= 256 and K >= 1536:
         return f"gemm_ws_kernel<128, 128, 2, 4, 2, 4, {6 if split else epi}>"
     if not fp8 and os.environ.get('CLV_GEMM_T192', '1') != '0' and N % 192 == 0 and N <= 576 and M >= 8192:
+        if ((M + 127) // 128) * (N // 192) <= 256:
+            return f"gemm_nt_kernel<64, 192, 2, 2, 2, {epi}, false>"                     # 4 waves of 32 x 96, ring of 2
         return f"gemm_nt_kernel<128, 192, 4, 2, 3, {epi}, false>"                        # 8 waves of 32 x 96, ring of 3
     if K >= 512 and t128 <= 384:
         return f"gemm_nt_kernel<64, 128, 2, 2, 3, {epi}, {'true' if fp8 else 'false'}>"

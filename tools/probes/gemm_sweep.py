@@ -51,7 +51,7 @@ VARIANTS = [('base', dict(CLV_GEMM_ROT='0', CLV_GEMM_SPLITK='1')),
             ('rot 128w8r4', dict(CLV_GEMM_ROT='1', CLV_GEMM_SPLITK='1', CLV_GEMM_TILE='128x128w8'))]
 KEYS = ('CLV_GEMM_ROT', 'CLV_GEMM_SPLITK', 'CLV_GEMM_TILE')
 if 't192' in sys.argv:     # the default planner against the 128 x 192 tile class (N = 192 / 384 / 576 / 1152 layers)
-    VARIANTS = [('planner', dict()), ('128x192w8', dict(CLV_GEMM_TILE='128x192w8'))]
+    VARIANTS = [('planner', dict()), ('128x192w8', dict(CLV_GEMM_TILE='128x192w8')), ('64x192w4', dict(CLV_GEMM_TILE='64x192w4'))]
 if 'quick' in sys.argv:
     VARIANTS = [VARIANTS[0], VARIANTS[1], VARIANTS[6], VARIANTS[7], VARIANTS[8]]
 print('shape'.ljust(34) + 'lib'.rjust(7) + ''.join(v[0].rjust(12) for v in VARIANTS), flush=True)
