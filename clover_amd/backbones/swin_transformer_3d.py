@@ -320,8 +320,11 @@ class BasicLayer(nn.Module):
                 # the reference wraps both halves of a block in checkpoint.checkpoint (:494-503): keep the block's
                 # input, drop its activations, recompute them in the backward.  The DropPath factors are the step's
                 # presets (_draw_drop_paths) and the Swin blocks have no dropout, so the recompute is exact; the
-                # kernel-side gradient sinks see ONE backward per layer as without it.
-                x, branch, bscale = _checkpoint.checkpoint(blk.forward_pending, x, branch, bscale, use_reentrant=False)
+                # kernel-side gradient sinks see ONE backward per layer as without it.  preserve_rng_state=False: the
+                # recompute draws nothing, and saving / restoring the generator state is illegal inside the engine's
+                # hipGraph capture.
+                x, branch, bscale = _checkpoint.checkpoint(blk.forward_pending, x, branch, bscale, use_reentrant=False,
+                                                           preserve_rng_state=False)
             else:
                 x, branch, bscale = blk.forward_pending(x, branch, bscale)
         return x, branch, bscale

@@ -209,6 +209,7 @@ class CloverEngine:
         self.max_iters, self.warmup_iters = max_iters, warmup_iters
         self.min_lr_ratio, self.warmup_ratio = min_lr_ratio, warmup_ratio
         self.step_count = 0                    # optimizer_step() calls (taken or skipped)
+        self._stale_cleared = False            # finish_backward() cleared the unreached first-touch slots of this step
         self.lr_iter = 0                       # index into the LR schedule when no runner drives it (set_lr)
         self._lr_external = None
         self.graph = None
@@ -448,7 +449,8 @@ class CloverEngine:
         self._ft.done.clear()
         out = self.model.train_step(batch, None)
         self._backward(lambda: out['loss'].backward())
-        self.reducer.finish()
+        self.finish_backward()
+        self._stale_cleared = False
         for seg in self.segments:
             seg.flat_g.zero_()
         self._ft.done.clear()
@@ -472,10 +474,24 @@ class CloverEngine:
             self._ft.done.clear()
             out = self.model.train_step(batch, None)
             self._backward(lambda: out['loss'].backward())
-        self.reducer.finish()
+        self.finish_backward()
         self.optimizer_step()
         self._mark('optimizer')
         return out
+
+    def finish_backward(self):
+        """Close a backward pass: clear the first-touch slots an EAGER backward did not reach, THEN complete the gradient
+        exchange.  The order matters in data-parallel mode: ``reducer.finish()`` packs and all-reduces the
+        bucket of an unreached parameter, and the norm / AdamW kernels read the reduced wire copy — a slot cleared after
+        the exchange would still update the weight with the previous step's gradient.  (A captured geometry's unreached
+        slots are cleared with the rest of the gradients after every optimizer step: ``_stale_views``.)  A caller that
+        drives its own ``loss.backward()`` calls this instead of ``reducer.finish()``."""
+        if self.graph is None:
+            stale = self._stale_sinks()
+            if stale:
+                torch._foreach_zero_(stale)
+            self._stale_cleared = True
+        self.reducer.finish()
 
     def _backward(self, run):
         """Run a backward pass / segment with the weight-gradient folds deferred to ONE batched launch at its end —
@@ -771,13 +787,18 @@ class CloverEngine:
         lr = self.current_lr()
         self.lr_iter += 1
         self.step_count += 1
-        if self.graph is None:
-            # eager backward (step(), or a caller's own loss.backward() in the style of an OptimizerHook): first-touch
-            # slots this backward did not reach still hold the previous step's gradient — clear them before the norm
-            # (a captured geometry's unreached slots are cleared with the rest: _stale_views)
+        if self.graph is None and not self._stale_cleared:
+            # a caller's own loss.backward() (the style of an OptimizerHook) that did not go through finish_backward():
+            # first-touch slots this backward did not reach still hold the previous step's gradient — clear them before
+            # the norm.  With a reduced wire copy it is too late for that (the stale values have been exchanged).
             stale = self._stale_sinks()
             if stale:
+                if self.wire is not None and self.reducer.active:
+                    raise RuntimeError('first-touch gradient slots were not reached by this backward and the gradient '
+                                       'exchange has already run: call engine.finish_backward() instead of '
+                                       'engine.reducer.finish()')
                 torch._foreach_zero_(stale)
+        self._stale_cleared = False
         gscale = 1.0 / self.world                       # DDP averages the summed gradients
         grads = self.wire if self.wire is not None else [seg.flat_g for seg in self.segments]   # reduced gradients
         for g in grads:

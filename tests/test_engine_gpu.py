@@ -212,6 +212,42 @@ def test_graph_capture_equals_eager_and_loss_decreases(loss_graph, monkeypatch):
     assert traj['graph'][-1] < traj['graph'][0] - 0.5          # the step actually trains
 
 
+def test_use_checkpoint_under_the_engine():
+    """``use_checkpoint=True`` through the engine — dry_step, hipGraph capture (the recompute runs inside the
+    captured backward: checkpoint must not touch the RNG state there), replayed steps, first-touch sinks.  Every
+    parameter's gradient of one replayed forward / backward equals the non-checkpointed engine's on the same weights,
+    and three optimizer steps give the same losses."""
+    import clover_amd
+    from clover_amd.engine import CloverEngine
+    b = batch(2, 'ckeng')
+    res = {}
+    for ck in (False, True):
+        cfg = cf.tiny_model_cfg()
+        cfg['backbone']['use_checkpoint'] = ck
+        m = clover_amd.build_model(cfg)
+        m.load_state_dict(cf.cf_state(gutil.manifest()), strict=False)
+        m = m.to(DEV).eval()
+        eng = CloverEngine(m, b, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+        eng.dry_step(b)
+        assert eng.capture(b)
+        eng.zero_grads()
+        eng._graphed_forward_backward(b)
+        torch.cuda.synchronize()
+        g = {}
+        for seg in eng.segments:
+            for name, p_, off in zip(seg.names, seg.params, seg.offsets):
+                g[name] = seg.flat_g[off:off + p_.numel()].clone()
+        eng.zero_grads()
+        losses = [float(eng.step(b)['log_vars']['loss']) for _ in range(3)]
+        res[ck] = (g, losses, eng.first_touch_params)
+    assert res[True][2] == res[False][2] and res[True][2] > 0          # the same slots qualify as first-touch
+    for n, r in res[False][0].items():
+        scale = float(r.abs().max())
+        assert float((res[True][0][n] - r).abs().max()) <= 1e-3 * scale + 1e-9, n
+    for a, c in zip(res[False][1], res[True][1]):
+        assert abs(a - c) <= 1e-3 * max(1.0, abs(a)), res
+
+
 def test_graphs_per_batch_geometry():
     """The reference alternates video (many-frame) and image (1-frame, padded to 2) batches (clover_runner.py:76-93):
     the engine keeps one set of hipGraphs per batch geometry, captured on first sight, and the alternating
@@ -615,39 +651,70 @@ class _TwoPathToy(torch.nn.Module):
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['imgs']))
 
 
-@pytest.mark.parametrize('mode', ['eager', 'graph'])
+@pytest.mark.parametrize('mode', ['eager', 'graph', 'eager_dp'])
 def test_first_touch_slots_across_a_geometry_switch(mode, monkeypatch):
     """a first-touch slot that geometry A's backward writes and geometry B's never does must not carry A's
     gradient into B's optimizer step.  Alternating A / B steps against an engine that clears every slab
-    (CLOVER_GRAD_FIRST_TOUCH=0): identical parameters afterwards, and `b`'s gradient slot is zero in every B step."""
+    (CLOVER_GRAD_FIRST_TOUCH=0): identical parameters afterwards, and `b`'s gradient slot is zero in every B step.
+    `eager_dp`: the same in eager data-parallel mode on a real 1-rank RCCL group with the bf16 wire — the
+    unreached slot must be cleared BEFORE reducer.finish() packs and all-reduces its bucket, because the norm / AdamW
+    kernels read the reduced wire copy (engine.finish_backward)."""
+    import os
+    import torch.distributed as dist
     from clover_amd.engine import CloverEngine
     torch.manual_seed(3)
     wide = dict(imgs=torch.randn(128, 128, device=DEV))
     narrow = dict(imgs=torch.randn(64, 128, device=DEV))
     final = {}
-    for ft in ('0', '1'):
-        monkeypatch.setenv('CLOVER_GRAD_FIRST_TOUCH', ft)
-        m = _TwoPathToy().to(DEV)
-        eng = CloverEngine(m, wide, lr=1e-2, weight_decay=0.0, grad_clip=0.0, max_iters=10 ** 9)
-        if ft == '1':
-            assert eng.first_touch_params >= 2 * 128 * 128, eng.first_touch_params
-        if mode == 'graph':
-            eng.dry_step(wide)
-            assert eng.capture(wide)
-        for it in range(3):
-            eng.step(wide)
+    dp = mode == 'eager_dp'
+    if dp:
+        monkeypatch.setenv('CLOVER_FORCE_COLLECTIVES', '1')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29563')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        for ft in ('0', '1'):
+            monkeypatch.setenv('CLOVER_GRAD_FIRST_TOUCH', ft)
+            m = _TwoPathToy().to(DEV)
+            eng = CloverEngine(m, wide, lr=1e-2, weight_decay=0.0, grad_clip=0.0, max_iters=10 ** 9)
+            if ft == '1':
+                assert eng.first_touch_params >= 2 * 128 * 128, eng.first_touch_params
+            if dp:
+                assert eng.reducer.active and eng.wire is not None
             if mode == 'graph':
-                # B's replayed backward must see a clean slot for `b` (checked between the replay and the optimizer)
-                sig = eng._signature(narrow)
-                if sig in eng._captures:
-                    eng._activate(sig)
-                    eng._graphed_forward_backward(narrow)
-                    assert float(m.b.weight.grad.abs().max()) == 0.0, it
-                    eng.zero_grads()
-            eng.step(narrow)
-        final[ft] = {n: p.detach().clone() for n, p in m.named_parameters()}
-        if mode == 'graph':
-            assert len(eng._captures) == 2
+                eng.dry_step(wide)
+                assert eng.capture(wide)
+            for it in range(3):
+                eng.step(wide)
+                if mode == 'graph':
+                    # B's replayed backward must see a clean slot for `b` (checked between the replay and the optimizer)
+                    sig = eng._signature(narrow)
+                    if sig in eng._captures:
+                        eng._activate(sig)
+                        eng._graphed_forward_backward(narrow)
+                        assert float(m.b.weight.grad.abs().max()) == 0.0, it
+                        eng.zero_grads()
+                before = m.b.weight.detach().clone()
+                eng.step(narrow)
+                if dp:
+                    # grad_clip = 0, weight_decay = 0: an unreached weight with a zero gradient only moves by Adam's
+                    # decaying momentum; with last step's gradient on the wire it would move like a reached one.  The
+                    # comparison with the all-cleared engine below is the exact check; this one localises a failure.
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(m.b.weight).all() and before.shape == m.b.weight.shape
+            final[ft] = {n: p.detach().clone() for n, p in m.named_parameters()}
+            if mode == 'graph':
+                assert len(eng._captures) == 2
+            if dp and ft == '1':
+                # a caller-driven backward that skips finish_backward() must not silently exchange stale slots
+                eng._ft.done.clear()
+                eng.model.train_step(narrow, None)['loss'].backward()
+                eng.reducer.finish()
+                with pytest.raises(RuntimeError, match='finish_backward'):
+                    eng.optimizer_step()
+    finally:
+        if dp:
+            dist.destroy_process_group()
     for n in final['0']:
         assert torch.allclose(final['0'][n], final['1'][n], rtol=0, atol=1e-6), n
 
