@@ -184,8 +184,6 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--phases', action='store_true', help='after the timed region: GPU time per phase of the graphed step (events at the phase boundaries), as a "phases_ms" field')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of as one hipGraph')
-    ap.add_argument('--no-gemm-tuning', action='store_true', help='library GEMMs with default heuristics')
-    ap.add_argument('--tune-gemms', metavar='CSV', help='benchmark library GEMM algorithms and write the table')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -218,11 +216,6 @@ def main():
     from clover_amd.engine import CloverEngine
     if args.dtype == 'fp8':
         ops.FP8 = True
-
-    tuned = 0
-    if not args.no_gemm_tuning:
-        from clover_amd.utils.gemm_tuning import enable_tuned_gemms
-        tuned = enable_tuned_gemms(tune_missing=bool(args.tune_gemms), out_path=args.tune_gemms)
 
     torch.manual_seed(1234)                              # identical init on every rank (== DDP broadcast)
     cfg = model_cfg(args.variant, args.frames)
@@ -331,7 +324,7 @@ def main():
             'metric': f'video-text pairs/sec ({args.frames}f x 224^2, {args.tokens}-tok), full pre-training step',
             'value': round(pairs_s, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'hip_graph': graphed, 'tuned_gemm_shapes': tuned,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'hip_graph': graphed,
             'config': {'workload': f'VideoSwin-{args.variant} + BERT-base + 3-layer fusion, MLM + tri-modal '
                                    f'exclusive InfoNCE + rank losses, {args.frames}f x 224^2, {args.tokens}-tok',
                        'per_gpu_batch': args.batch, 'global_batch': gb, 'parallelism': f'dp{world}',
@@ -354,27 +347,47 @@ def main():
             # was taken at; the *_source fields say which file and commit, so a reader can tell a fresh counter from a stale one.
             prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
             kname = res['roofline']['kernel']
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from csrc_hash import csrc_sha16
+            cur_sha = csrc_sha16(ROOT)
 
-            def committed(fname):
-                path = os.path.join(prof_dir, fname)
-                if not os.path.exists(path):
+            def newest(suffix):
+                """profiles/rNN_<suffix> of the highest round NN present"""
+                import re
+                best = None
+                for f in os.listdir(prof_dir) if os.path.isdir(prof_dir) else []:
+                    m = re.match(r'r(\d\d)_' + re.escape(suffix) + '$', f)
+                    if m and (best is None or int(m.group(1)) > best[0]):
+                        best = (int(m.group(1)), f)
+                return best[1] if best else None
+
+            stale = []
+
+            def committed(suffix):
+                fname = newest(suffix)
+                if fname is None:
                     return None, None
-                d = json.load(open(path))
-                return d.get(kname), f"profiles/{fname}@{(d.get('_meta') or {}).get('commit', 'unknown')}"
-            rec, src = committed('r04_pmc_traffic.json')
+                d = json.load(open(os.path.join(prof_dir, fname)))
+                meta = d.get('_meta') or {}
+                if meta.get('csrc_sha16') != cur_sha:
+                    stale.append(fname)                      # taken from other kernel sources than this tree's
+                return d.get(kname), f"profiles/{fname}@{meta.get('commit', 'unknown')}"
+            rec, src = committed('pmc_traffic.json')
             res['roofline']['traffic'] = rec['hbm_bytes_per_launch'] if rec else None
             res['roofline']['traffic_source'] = src if rec else None
-            rec, src = committed('r04_pmc_mfma.json')
+            rec, src = committed('pmc_mfma.json')
             res['roofline']['mfma_util'] = rec['mfma_util'] if rec else None
             res['roofline']['mfma_util_source'] = src if rec else None
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
             # (device-side, no event / dispatch overhead) and the roofline fraction it gives
-            stats = os.path.join(prof_dir, 'r04_kernel_stats_bench_default_final.csv')
-            if os.path.exists(stats):
+            sname = newest('kernel_stats_bench_default_final.csv')
+            if sname:
                 import csv
-                meta = os.path.join(prof_dir, 'r04_kernel_stats_bench_default_final.meta.json')
-                sha = json.load(open(meta)).get('commit', 'unknown') if os.path.exists(meta) else 'unknown'
-                for row in csv.DictReader(open(stats)):
+                meta = os.path.join(prof_dir, sname.replace('.csv', '.meta.json'))
+                md = json.load(open(meta)) if os.path.exists(meta) else {}
+                if md.get('csrc_sha16') != cur_sha:
+                    stale.append(sname)
+                for row in csv.DictReader(open(os.path.join(prof_dir, sname))):
                     nm = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
                     if nm.startswith(kname):
                         us = float(row['AverageNs']) / 1e3
@@ -383,8 +396,14 @@ def main():
                                               else 'algorithmic_flops_per_launch']
                         peak = 8.0e12 if res['roofline']['bound'] == 'hbm' else 2.5e15
                         res['roofline']['frac_rocprof'] = round(per / (us * 1e-6) / peak, 4)
-                        res['roofline']['rocprof_source'] = f'profiles/r04_kernel_stats_bench_default_final.csv@{sha}'
+                        res['roofline']['rocprof_source'] = f"profiles/{sname}@{md.get('commit', 'unknown')}"
                         break
+            # stale: a committed counter file was taken from kernel sources other than this tree's (csrc hash mismatch): its
+            # numbers describe an older build of the kernels — the live HIP-event fields above do not depend on it
+            res['roofline']['stale'] = bool(stale)
+            res['roofline']['stale_files'] = stale
+            res['roofline']['csrc_sha16'] = cur_sha
+        res['library_gemm_calls'] = {f'{k[0]} {list(k[1])}': v for k, v in ops.LIBRARY_GEMM_CALLS.items()}
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_subprocess(args.variant, args.frames, args.tokens)
             ref = res['cpu_baseline'].pop('losses', None)
@@ -401,9 +420,6 @@ def main():
                                                          '(structure / index-logic check, not the bf16 kernels)')
         if with_copy_ms is not None:
             res['ms_per_step_with_input_copy'] = round(with_copy_ms, 3)
-    if args.tune_gemms and rank == 0:
-        from clover_amd.utils.gemm_tuning import save_results
-        save_results(args.tune_gemms)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

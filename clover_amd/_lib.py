@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -73,6 +73,8 @@ SIGNATURES = {
     'clv_layernorm_bwd': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, C.POINTER(ClvLnExtra), _p]),
     'clv_ln_fold_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _p]),
     'clv_ln_fold_bwd': (C.c_int, [_p] * 9 + [_i32, _i32, _p]),
+    'clv_batchnorm1d_fwd': (C.c_int, [_p] * 8 + [_i32, _i32, _f, _f, _i32, _p]),
+    'clv_batchnorm1d_bwd': (C.c_int, [_p] * 8 + [_i32, _i32, _i32, _p]),
     'clv_gelu_fwd': (C.c_int, [_p, _p, _i64, _i32, _p]),
     'clv_gelu_bwd': (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'clv_patch_embed_fwd': (C.c_int, [_p] * 12 + [_i32] * 7 + [_f, _p]),

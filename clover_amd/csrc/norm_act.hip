@@ -1067,6 +1067,69 @@ __global__ void __launch_bounds__(128) ln_fold_bwd_kernel(const float* __restric
     if (db && threadIdx.x < LNF_ROWS && n0 + threadIdx.x < N) db[n0 + threadIdx.x] += dbf[n0 + threadIdx.x];
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// nn.BatchNorm1d over [B][D] fp32 — the ln=False / text_bn=True variants of the contrastive projection heads
+// (ssl_head.py:50-66,175-186,252-262): B = clips of one rank (8 .. a few hundred), D = 768 .. 1536.  One thread owns a
+// column and walks the rows (adjacent threads read adjacent columns: coalesced); two-pass variance as torch computes it.
+__global__ void __launch_bounds__(256) bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float* __restrict__ y,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, int B,
+                                                       int D, float eps, float momentum, int training) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D) return;
+    float mean, rstd;
+    if (training) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += x[(int64_t)b * D + j];
+        mean = s / (float)B;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float d = x[(int64_t)b * D + j] - mean;
+            v += d * d;
+        }
+        const float var = v / (float)B;                      // biased: what normalises the batch
+        rstd = rsqrtf(var + eps);
+        if (running_mean) {                                  // running statistics take the UNBIASED variance (torch)
+            running_mean[j] = (1.f - momentum) * running_mean[j] + momentum * mean;
+            running_var[j] = (1.f - momentum) * running_var[j] + momentum * (B > 1 ? v / (float)(B - 1) : var);
+        }
+    } else {
+        mean = running_mean[j];
+        rstd = rsqrtf(running_var[j] + eps);
+    }
+    save_mean[j] = mean;
+    save_rstd[j] = rstd;
+    const float g = gamma ? gamma[j] : 1.f, bt = beta ? beta[j] : 0.f;
+    for (int b = 0; b < B; ++b) y[(int64_t)b * D + j] = (x[(int64_t)b * D + j] - mean) * rstd * g + bt;
+}
+
+__global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int D,
+                                                       int training) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D) return;
+    const float mean = save_mean[j], rstd = save_rstd[j], g = gamma ? gamma[j] : 1.f;
+    float sdy = 0.f, sdyx = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = dy[(int64_t)b * D + j];
+        sdy += d;
+        sdyx += d * (x[(int64_t)b * D + j] - mean) * rstd;
+    }
+    if (dgamma) dgamma[j] = sdyx;
+    if (dbeta) dbeta[j] = sdy;
+    if (!dx) return;
+    const float inv = 1.f / (float)B;
+    for (int b = 0; b < B; ++b) {
+        const float d = dy[(int64_t)b * D + j];
+        // eval mode: the statistics are constants; training mode: they depend on every row of the column
+        dx[(int64_t)b * D + j] = training ? g * rstd * (d - inv * sdy - (x[(int64_t)b * D + j] - mean) * rstd * inv * sdyx) : g * rstd * d;
+    }
+}
+
 }  // namespace
 
 extern "C" int clv_ln_fold_fwd(const float* w, const float* b, const float* gamma, const float* beta, void* wf,
@@ -1084,5 +1147,25 @@ extern "C" int clv_ln_fold_bwd(const float* dwf, const float* dbf, const float* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3((N + LNF_ROWS - 1) / LNF_ROWS), dim3(128), 0, st, dwf, dbf, w, gamma, beta, dw,
                        db, dgamma, dbeta, (int)N, (int)K);
+    return clv_check_launch();
+}
+
+extern "C" int clv_batchnorm1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* y, float* save_mean, float* save_rstd, int32_t B, int32_t D,
+                                   float eps, float momentum, int32_t training, void* stream) {
+    if (!x || !y || !save_mean || !save_rstd || B <= 0 || D <= 0) return CLV_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return CLV_ERR_ARG;
+    if (!training && !running_mean) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean,
+                       running_var, y, save_mean, save_rstd, (int)B, (int)D, eps, momentum, (int)training);
+    return clv_check_launch();
+}
+
+extern "C" int clv_batchnorm1d_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                   const float* save_rstd, float* dx, float* dgamma, float* dbeta, int32_t B, int32_t D,
+                                   int32_t training, void* stream) {
+    if (!dy || !x || !save_mean || !save_rstd || B <= 0 || D <= 0) return CLV_ERR_ARG;
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
+                       save_rstd, dx, dgamma, dbeta, (int)B, (int)D, (int)training);
     return clv_check_launch();
 }

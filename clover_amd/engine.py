@@ -834,8 +834,23 @@ class CloverEngine:
                 if key in st and abs(float(st[key]) - float(getattr(sg, key))) > 1e-12:
                     raise ValueError(f'optimizer state was saved with {key}={st[key]} for the slab of {sg.names[0]} ... '
                                      f'but the current paramwise_cfg gives {getattr(sg, key)}')
-            sg.exp_avg.copy_(st['exp_avg'])
-            sg.exp_avg_sq.copy_(st['exp_avg_sq'])
+            if 'offsets' not in st or list(st['offsets']) == list(sg.offsets):
+                sg.exp_avg.copy_(st['exp_avg'])
+                sg.exp_avg_sq.copy_(st['exp_avg_sq'])
+            else:
+                # a checkpoint written under another slab layout (slot alignment / phantom padding rows changed between
+                # rounds): same parameters, other offsets — re-scatter the moments per parameter by name instead of copying
+                # the flat buffers (which would fail on the size, or silently misalign the moments)
+                old_off = list(st['offsets'])
+                sg.exp_avg.zero_()
+                sg.exp_avg_sq.zero_()
+                for i, (name, p_) in enumerate(zip(sg.names, sg.params)):
+                    n = p_.numel()
+                    if old_off[i] + n > st['exp_avg'].numel() or (i + 1 < len(old_off) and old_off[i + 1] - old_off[i] < n):
+                        raise ValueError(f'optimizer state: the saved slot of {name} holds fewer than {n} elements '
+                                         f'(checkpoint from a different model?)')
+                    for dst, key in ((sg.exp_avg, 'exp_avg'), (sg.exp_avg_sq, 'exp_avg_sq')):
+                        dst[sg.offsets[i]:sg.offsets[i] + n].copy_(st[key][old_off[i]:old_off[i] + n])
         self.refresh_shadow()
 
     def refresh_shadow(self):

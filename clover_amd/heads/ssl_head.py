@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from ..builder import HEADS
-from ..nn import GELU, LayerNorm
+from ..nn import GELU, BatchNorm1d, LayerNorm
 from ..nn import LinearFP32 as Linear
 
 
@@ -21,10 +21,20 @@ def _init_head(module):
             m.bias.data.zero_()
 
 
-def _no_bn(flag, what):
-    if flag:
-        raise NotImplementedError(f'{what}: BatchNorm variants are outside the pre-training path '
-                                  '(configs use ln=True / text_bn=False)')
+def _norm(dim, ln):
+    """nn.LayerNorm (ln=True, every published config) or nn.BatchNorm1d (ssl_head.py:52,56,175-186) of a head layer."""
+    return LayerNorm(dim) if ln else BatchNorm1d(dim)
+
+
+def _per_pass(fn, x, passes, order):
+    """Apply fn to the row blocks of a batch that stacks `passes` forward passes of the reference, one block at a time in
+    the reference's call order: BatchNorm statistics (and their running averages) are per CALL there — the clean and the
+    masked clips, the un-masked and the masked captions each go through the head on their own (:102, :150, :159)."""
+    blocks = list(x.chunk(passes, dim=0))
+    outs = [None] * passes
+    for i in (order if order is not None else range(passes)):
+        outs[i] = fn(blocks[i])
+    return torch.cat(outs, dim=0)
 
 
 @HEADS.register_module()
@@ -32,8 +42,6 @@ class NCEHeadForMM(nn.Module):
     def __init__(self, visual_in_channels, text_in_channels, img_hidden_dim, vts_embed_dim, spatial_type='avg',
                  text_agg_type='avg', ln=False, text_bn=False, dropout_ratio=0.1, init_std=0.01, **kwargs):
         super().__init__()
-        _no_bn(not ln, 'NCEHeadForMM(ln=False)')
-        _no_bn(text_bn, 'NCEHeadForMM(text_bn=True)')
         self.vis_in_channels = visual_in_channels
         self.text_in_channels = text_in_channels
         self.spatial_type = spatial_type
@@ -45,10 +53,16 @@ class NCEHeadForMM(nn.Module):
         self.ln = ln
         self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
         self.img_projector = nn.Sequential(
-            Linear(visual_in_channels, img_hidden_dim), LayerNorm(img_hidden_dim), GELU(),
-            Linear(img_hidden_dim, vts_embed_dim), LayerNorm(vts_embed_dim))
-        self.text_projector = nn.Sequential(
-            Linear(text_in_channels, text_in_channels), GELU(), Linear(text_in_channels, vts_embed_dim))
+            Linear(visual_in_channels, img_hidden_dim), _norm(img_hidden_dim, ln), GELU(),
+            Linear(img_hidden_dim, vts_embed_dim), _norm(vts_embed_dim, ln))
+        if text_bn:                                          # :58-64 (the indices of the Sequential are state_dict keys)
+            self.text_projector = nn.Sequential(
+                Linear(text_in_channels, text_in_channels), BatchNorm1d(text_in_channels), GELU(),
+                Linear(text_in_channels, vts_embed_dim))
+        else:
+            self.text_projector = nn.Sequential(
+                Linear(text_in_channels, text_in_channels), GELU(), Linear(text_in_channels, vts_embed_dim))
+        self.text_bn = text_bn
         self.init_weights()
         self.text_agg_type = text_agg_type
 
@@ -58,17 +72,21 @@ class NCEHeadForMM(nn.Module):
     def forward(self, img, text, text_mask=None, token_ids=None):
         return self.forward_vision(img), self.forward_text(text, text_mask, token_ids)
 
-    def forward_vision(self, img, channels_last=False):
-        """img [N,C,T,h,w] (reference layout) or [N,T,h,w,C] with channels_last=True -> [N,vts] fp32."""
+    def forward_vision(self, img, channels_last=False, passes=1, order=None):
+        """img [N,C,T,h,w] (reference layout) or [N,T,h,w,C] with channels_last=True -> [N,vts] fp32.
+        passes > 1: the batch stacks that many forward passes of the reference (the recognizer's doubled clean + masked
+        pass); a BatchNorm projector then runs per pass (see _per_pass), a LayerNorm one does not care."""
         if self.spatial_type == 'avg':
             img = img.float().mean(dim=(1, 2, 3) if channels_last else (2, 3, 4))
         else:
             raise NotImplementedError('spatial_type other than avg')
         if self.dropout is not None:
             img = self.dropout(img)
+        if passes > 1 and not self.ln:
+            return _per_pass(self.img_projector, img, passes, order).float()
         return self.img_projector(img).float()
 
-    def forward_text(self, text, text_mask=None, token_ids=None):
+    def forward_text(self, text, text_mask=None, token_ids=None, passes=1, order=None):
         if self.text_agg_type == 'avg':
             text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
             text = text[:, 1:].float()
@@ -79,6 +97,8 @@ class NCEHeadForMM(nn.Module):
         elif self.text_agg_type == 'max':
             text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
             text = (text[:, 1:].float() * text_mask[:, 1:].unsqueeze(-1)).max(dim=1)[0]
+        if passes > 1 and self.text_bn:
+            return _per_pass(self.text_projector, text, passes, order).float()
         return self.text_projector(text).float()
 
 
@@ -87,7 +107,6 @@ class NCEHeadForVision(nn.Module):
     def __init__(self, cross_in_channels=768, visual_in_channels=1024, hidden_dim=768, vts_embed_dim=768,
                  dropout_ratio=0.1, ln=False, init_std=0.01, **kwargs):
         super().__init__()
-        _no_bn(not ln, 'NCEHeadForVision(ln=False)')
         self.cross_in_channels = cross_in_channels
         self.visual_in_channels = visual_in_channels
         self.vts_embed_dim = vts_embed_dim
@@ -96,10 +115,10 @@ class NCEHeadForVision(nn.Module):
         self.ln = ln
         self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
         self.img_fc1 = Linear(visual_in_channels, hidden_dim * 2)
-        self.img_bn1 = LayerNorm(hidden_dim * 2)
+        self.img_bn1 = _norm(hidden_dim * 2, ln)
         self.img_act = GELU()
         self.img_fc2 = Linear(hidden_dim * 2, vts_embed_dim)
-        self.img_bn2 = LayerNorm(vts_embed_dim)
+        self.img_bn2 = _norm(vts_embed_dim, ln)
         self.init_weights()
 
     def init_weights(self):
@@ -123,7 +142,6 @@ class NCEHeadForVision(nn.Module):
 class NCEHeadForText(nn.Module):
     def __init__(self, cross_in_channels=768, vts_embed_dim=768, dropout_ratio=0.1, text_bn=False, **kwargs):
         super().__init__()
-        _no_bn(text_bn, 'NCEHeadForText(text_bn=True)')
         self.cross_in_channels = cross_in_channels
         self.vts_embed_dim = vts_embed_dim
         self.dropout_ratio = dropout_ratio
@@ -131,7 +149,7 @@ class NCEHeadForText(nn.Module):
         self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
         self.text_bn = text_bn
         self.fc1 = Linear(cross_in_channels, cross_in_channels)
-        self.bn = None
+        self.bn = BatchNorm1d(cross_in_channels) if text_bn else None
         self.act = GELU()
         self.fc2 = Linear(cross_in_channels, vts_embed_dim)
         self.init_weights()
@@ -140,7 +158,10 @@ class NCEHeadForText(nn.Module):
         _init_head(self)
 
     def forward(self, mask_word_feat):
-        x = self.act(self.fc1(mask_word_feat))
+        x = self.fc1(mask_word_feat)
+        if self.bn is not None:
+            x = self.bn(x)
+        x = self.act(x)
         if self.dropout is not None:
             x = self.dropout(x)
         return self.fc2(x).float()

@@ -1,6 +1,7 @@
 """Building blocks shared by the registered modules: nn.Linear / nn.LayerNorm subclasses
 (so mmcv-style param-group rules that test ``isinstance(m, nn.LayerNorm)`` keep working and
-state_dict keys stay ``weight``/``bias``) whose forward runs the bf16 HIP/hipBLASLt path.
+state_dict keys stay ``weight``/``bias``) whose forward runs the bf16 HIP kernels of ``clover_amd.ops`` (no library GEMM:
+a shape the kernels do not cover goes through ``ops._library_gemm``, which counts and announces it).
 
 Precision policy (maps the reference's fp16 policy, fp16_utils.py:215-259, to bf16):
 parameters are fp32 masters; GEMM operands are bf16 (fp32 accumulate in MFMA); LayerNorm
@@ -44,6 +45,19 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x, residual=None, return_sum=False, x_scale=None, x_dropout_p=0.0, fork=False):
         return ops.layer_norm(x, self.weight, self.bias, self.eps, residual=residual, return_sum=return_sum,
                               x_scale=x_scale, x_dropout_p=x_dropout_p, fork=fork)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose forward is the HIP kernel; [B, D] rows only
+    (the projection heads' use, ssl_head.py:52,56,60,175-186)."""
+
+    def forward(self, x):
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError('BatchNorm1d(momentum=None / affine=False / track_running_stats=False)')
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm1d(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                self.momentum, self.eps)
 
 
 class GELU(nn.Module):

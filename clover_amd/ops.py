@@ -30,6 +30,26 @@ def _need_gpu(*ts):
                                'got a tensor on %s' % t.device)
 
 
+LIBRARY_GEMM_CALLS = {}     # {(site, shape): calls} of every GEMM that left the own kernels for the ROCm library (below)
+
+
+def _library_gemm(site, shape):
+    """Every GEMM of the Clover configs runs on the own kernels; a shape they do not take (a contraction that is not a
+    multiple of 64, a sequence beyond 896 keys, ...) falls back to the ROCm library THROUGH HERE: counted in
+    LIBRARY_GEMM_CALLS (bench.py prints the table, the step tests assert it stays empty), announced once per shape, and
+    refused with CLOVER_STRICT_OWN_GEMM=1 — never silent."""
+    key = (site, tuple(int(v) for v in shape))
+    n = LIBRARY_GEMM_CALLS.get(key, 0)
+    LIBRARY_GEMM_CALLS[key] = n + 1
+    if os.environ.get('CLOVER_STRICT_OWN_GEMM') == '1':
+        raise RuntimeError(f'CLV_ERR_UNSUPPORTED: {site} {key[1]} is not covered by the HIP GEMM kernels '
+                           f'(CLOVER_STRICT_OWN_GEMM=1 refuses the library fallback)')
+    if n == 0:
+        import warnings
+        warnings.warn(f'clover_amd: {site} with shape {key[1]} runs on the ROCm library GEMM, not on the HIP kernels '
+                      f'(shape outside their coverage)', RuntimeWarning, stacklevel=3)
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -233,6 +253,7 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
             check(_lib.lib().clv_colsum(_ptr(dy2), _ptr(db), M, N, dy2.stride(0), _stream()), 'clv_colsum')
         else:
             db.add_(dy2.sum(0, dtype=torch.float32))
+    _library_gemm('linear_wgrad', (M, N, K))
     if sink:
         if ow:
             torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
@@ -474,6 +495,7 @@ def linear_dgrad(dy2, wb, weight=None, pre=None):
         return rowgemm(dy2, _wt(weight, wb), None)['y']
     if own_gemm_ok(dy2, K, N) and (pre is None or os.environ.get('CLOVER_DGELU_FUSE', '1') == '1'):
         return gemm_nt(dy2, _wt(weight, wb), aux=pre, epilogue=GEMM_EPI_DGELU if pre is not None else GEMM_EPI_NONE)
+    _library_gemm('linear_dgrad', (dy2.shape[0], K, N))
     dx = torch.mm(dy2, wb)
     if pre is not None:
         out = torch.empty_like(dx)
@@ -601,6 +623,7 @@ class _Linear(torch.autograd.Function):
             y = gemm_nt(x2, wb, bias.detach() if bias is not None else None,
                         epilogue=GEMM_EPI_BIAS if bias is not None else GEMM_EPI_NONE).view(xb.shape[:-1] + (N,))
         else:
+            _library_gemm('linear', (x2.shape[0], N, K))
             y = torch.nn.functional.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.has_bias = bias is not None
@@ -807,6 +830,7 @@ class _FusedMLP(torch.autograd.Function):
             out = gemm_nt(o1['y'], w2b, b2.detach() if b2 is not None else None,
                           epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
         else:
+            _library_gemm('fused_mlp fc2', (o1['y'].shape[0], w2b.shape[0], w2b.shape[1]))
             out = torch.nn.functional.linear(o1['y'], w2b, b2b)
         ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b, o1['xhat'])
         ctx.has_res = r is not None
@@ -826,6 +850,7 @@ class _FusedMLP(torch.autograd.Function):
         if rowgemm_supported(Hd, C_) and C_ <= 288:
             dpre = rowgemm(do2, _wt(ctx.w2ref, w2b), None, epilogue=2, pre_in=pre)['y']
         else:
+            _library_gemm('fused_mlp fc2 dgrad', (do2.shape[0], Hd, C_))
             dact = torch.mm(do2, w2b)
             dpre = torch.empty_like(dact)
             check(_lib.lib().clv_gelu_bwd(_ptr(dact), _ptr(pre), _ptr(dpre), dact.numel(), 0, _stream()), 'clv_gelu_bwd')
@@ -923,6 +948,7 @@ class _MlpGelu(torch.autograd.Function):
             out = gemm_nt(act, w2b, b2.detach() if b2 is not None else None,
                           epilogue=GEMM_EPI_BIAS if b2 is not None else GEMM_EPI_NONE)
         else:
+            _library_gemm('mlp_gelu fc2', (act.shape[0], C_, Hd))
             b2b = getattr(b2, '_clv_shadow', None) if b2 is not None else None
             out = torch.nn.functional.linear(act, w2b, b2b if b2b is not None or b2 is None else b2.to(BF16))
         ctx.save_for_backward(x2, pre, act, w1b, w2b)
@@ -968,9 +994,9 @@ def _gemm_kname(M, N, K, epi, fp8, split=False):
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     t64 = ((M + 63) // 64) * ((N + 127) // 128)
     ws = 0 if fp8 else int(os.environ.get('CLV_GEMM_WS', '3'))
-    if (ws & 2) and M <= 1024 and K >= 512 and t64 <= 256:
+    if (ws & 2) and M <= 1024 and K >= 512 and t64 <= 256 and N <= 3072:          # N <= GN_MAX_BIAS (gemm_nt.hip gn_plan)
         return f"gemm_ws_kernel<64, 128, 2, 2, 2, 4, {6 if split else epi}>"
-    if (ws & 1) and t128 <= 256 and K >= 1536:
+    if (ws & 1) and t128 <= 256 and K >= 1536 and N <= 3072:
         return f"gemm_ws_kernel<128, 128, 2, 4, 2, 4, {6 if split else epi}>"
     if not fp8 and os.environ.get('CLV_GEMM_T192', '1') != '0' and N % 192 == 0 and N <= 576 and M >= 8192:
         if ((M + 127) // 128) * (N // 192) <= 256:
@@ -1321,6 +1347,47 @@ def gelu(x):
 
 
 # --------------------------------------------------------------------------- embedding
+class _BatchNorm1d(torch.autograd.Function):
+    """nn.BatchNorm1d on [B, D] fp32 (the BatchNorm variants of the projection heads, ssl_head.py:50-66,175-186,252-262)
+    on clv_batchnorm1d_fwd / _bwd; running statistics are updated in place in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        _need_gpu(x)
+        x2 = _c(x.float())
+        if x2.dim() != 2:
+            raise ValueError('BatchNorm1d of the projection heads takes [B, D] rows')
+        B, D = x2.shape
+        if training and B < 2:
+            raise ValueError('Expected more than 1 value per channel when training')     # torch's own check
+        y = torch.empty_like(x2)
+        mean = torch.empty(D, device=x2.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(_lib.lib().clv_batchnorm1d_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                             _ptr(y), _ptr(mean), _ptr(rstd), B, D, float(eps), float(momentum),
+                                             int(bool(training)), _stream()), 'clv_batchnorm1d_fwd')
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.training = bool(training)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        B, D = x2.shape
+        dy2 = _c(dy.float())
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dg = torch.empty(D, device=x2.device, dtype=torch.float32) if weight is not None else None
+        db = torch.empty(D, device=x2.device, dtype=torch.float32) if ctx.has_bias else None
+        check(_lib.lib().clv_batchnorm1d_bwd(_ptr(dy2), _ptr(x2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg),
+                                             _ptr(db), B, D, int(ctx.training), _stream()), 'clv_batchnorm1d_bwd')
+        return dx, dg, db, None, None, None, None, None
+
+
+def batch_norm1d(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    return _BatchNorm1d.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
+
+
 class _Embedding(torch.autograd.Function):
     """weight[ids] with the gradient scattered straight into the engine's gradient slab (index_add_ of the few
     hundred looked-up rows) instead of a dense [vocab, H] zero-fill + scatter + fp32 add of 94 MB each.
@@ -1536,6 +1603,7 @@ class _LongSeqAttention(torch.autograd.Function):
         Cdim = C3 // 3
         hd = Cdim // num_heads
         q, k, v = (qkv[..., i * Cdim:(i + 1) * Cdim].view(B, S, num_heads, hd).permute(0, 2, 1, 3) for i in range(3))
+        _library_gemm('seq_attention (more than %d keys)' % SEQ_FUSED_MAX_KEYS, (B, num_heads, S, hd))
         scores = torch.matmul(q, k.transpose(-1, -2))                         # [B, nH, S, S] bf16
         p = torch.empty_like(scores)
         pd = torch.empty_like(scores) if dropout_p > 0 else None
@@ -1748,9 +1816,15 @@ class _MLMDecoder(torch.autograd.Function):
         weight, bias = ctx.refs
         Vp, V = weight._clv_pad_shadow.shape[0], weight.shape[0]
         R = xb.shape[0]
-        if (dy.dtype == BF16 and dy.stride() == (Vp, 1) and dy.storage_offset() == 0 and dy.data_ptr() in PADDED_GRADS):
-            PADDED_GRADS.discard(dy.data_ptr())
-            dyp = dy.as_strided((R, Vp), (Vp, 1))                  # the focal backward's buffer, padding columns zeroed
+        if (dy.dtype == BF16 and dy.stride() == (Vp, 1) and dy.storage_offset() == 0
+                and dy.untyped_storage().nbytes() >= R * Vp * 2):
+            # a [R, V] view of a [R, Vp] buffer (the focal backward writes rows of the scores' stride): contract over it in
+            # place.  Its Vp - V padding columns are cleared HERE, whoever produced the buffer (6 columns: one small fill;
+            # round 4 trusted a global set of data_ptr values for "already zeroed" — a stale entry could have let the GEMM
+            # contract over garbage)
+            dyp = dy.as_strided((R, Vp), (Vp, 1))
+            if Vp > V:
+                dyp[:, V:].zero_()
         else:
             dyp = torch.zeros(R, Vp, device=dy.device, dtype=BF16)
             dyp[:, :V].copy_(dy)
@@ -1776,7 +1850,6 @@ def mlm_decoder(x, weight, bias):
 
 
 # --------------------------------------------------------------------------- focal MLM loss
-PADDED_GRADS = set()        # data_ptr of [rows, ld] gradient buffers whose padding columns the focal backward has zeroed
 
 
 class _FocalCE(torch.autograd.Function):
@@ -1812,9 +1885,7 @@ class _FocalCE(torch.autograd.Function):
         check(_lib.lib().clv_focal_ce_bwd_ld(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
                                              _ptr(count), _ptr(dl), _ptr(buf), rows, V, ld, ctx.gamma, _stream()),
               'clv_focal_ce_bwd_ld')
-        if ld != V:
-            PADDED_GRADS.add(buf.data_ptr())           # its columns [V, ld) are zero: the decoder's backward contracts over ld
-        return buf[:, :V], None, None
+        return buf[:, :V], None, None      # (the kernel also zeroes the padding columns [V, ld))
 
 
 def focal_ce_masked(logits, labels, gamma=2.0):

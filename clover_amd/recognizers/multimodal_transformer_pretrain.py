@@ -64,12 +64,21 @@ class CloverPretrain(BaseRecognizer):
         """Everything of the step that touches only THIS rank's samples: the three encoders, the heads
         and the MLM loss.  Returns (emb fp32 [B, 6, D] in EMB_NAMES order, mlm_loss).  No collective
         and no data-dependent shape inside — the engine captures it (and its backward) as hipGraphs."""
-        if not hasattr(self, 'ssl_head') or self.mlm_ssl_V_head is None or self.mlm_ssl_T_head is None \
-                or not self.use_Cmask or not self.symmetry_rank or mlm_label is None or v_token_mask is None \
-                or self.mlm_head is None:
-            raise NotImplementedError('the MI355X path implements the full pre-training recipe (ssl_head + '
-                                      'mlm_head + mlm_ssl_head V/T + use_Cmask + symmetry_rank + mlm_label + '
-                                      'v_token_mask), i.e. configs/exp_local/pretrain_webvid_cc3m.py')
+        # Ablation switches of forward_train (:129-169): mlm_head=None (no MLM loss), mlm_ssl_head=None (no V / T
+        # reconstruction heads: the first ssl_loss call is skipped, :147), symmetry_rank=False (no second ssl_loss call, :155),
+        # mlm_loss=None (CrossEntropyLoss of loss_type over the rows, :141-142).  What the reference itself cannot run is
+        # refused with its reason: use_Cmask=False hands None to cos_norm (contrastive_loss.py:114-115), symmetry_rank
+        # without a T head calls None (:157), and mlm_label / v_token_mask are read unconditionally (:97, :114).
+        if not hasattr(self, 'ssl_head'):
+            raise NotImplementedError('CloverPretrain without ssl_head: forward_train reads visual_emb / text_emb of the '
+                                      'ssl_head branch unconditionally (:102, :151)')
+        if not self.use_Cmask and (self.mlm_ssl_V_head is not None or self.symmetry_rank):
+            raise ValueError('use_Cmask=False passes text_mask_embd=None into ExclusiveNCEwithRankingLoss, whose cos_norm '
+                             '(contrastive_loss.py:114) fails on None: not a runnable configuration of the reference')
+        if self.symmetry_rank and self.mlm_ssl_T_head is None:
+            raise ValueError('symmetry_rank=True needs mlm_ssl_head["T"] (multimodal_transformer_pretrain.py:157)')
+        if mlm_label is None or v_token_mask is None:
+            raise ValueError('forward_train needs mlm_label and v_token_mask (multimodal_transformer_pretrain.py:97, :114)')
         if self.training and imgs.is_cuda:
             ops.dropout_seeds_begin(imgs.device)        # one RNG-counter kernel for all dropout sites of the step
         imgs = imgs.reshape((-1,) + imgs.shape[2:])                                   # :81
@@ -100,7 +109,7 @@ class CloverPretrain(BaseRecognizer):
             with torch.cuda.stream(side):
                 text_ids2, text_mask2 = text_inputs()        # the text tower's own input glue: off the video encoder's stream
                 text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
-                txt_emb_both = self.ssl_head.forward_text(text_out)          # :150 / :102, also text-only
+                txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0))   # :150 / :102, also text-only
                 fusion_prep = None
                 if os.environ.get('CLOVER_HEADS_SIDE', '1') == '1' and hasattr(self.multimodal_backbone, 'prepare'):
                     # the video-independent part of the fusion encoder's input (text + type embeddings, position table,
@@ -126,7 +135,7 @@ class CloverPretrain(BaseRecognizer):
         else:
             text_ids2, text_mask2 = text_inputs()
             text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
-            txt_emb_both = self.ssl_head.forward_text(text_out)
+            txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0))   # (reference order: un-masked :102, masked :150)
             fusion_prep = None
 
         # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack.
@@ -138,9 +147,9 @@ class CloverPretrain(BaseRecognizer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 vis_both.record_stream(side)
-                vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
+                vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2)
         else:
-            vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True)
+            vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2)
         mask_word_emb, text_emb = txt_emb_both.view(2, B, -1).unbind(0)
 
         # ---- fusion: block 0 = t_fusion (clean video, masked text) (:119); block 1 = v_fusion (masked video,
@@ -157,26 +166,37 @@ class CloverPretrain(BaseRecognizer):
 
         # ---- the two reconstruction heads (:148-149, :156-157; a dozen launch-bound kernels) on the side stream, under
         # the MLM decoder GEMM + focal loss
+        def recon_heads():
+            # a switched-off head leaves its slot of the packed embeddings zero (no gradient): contrastive_losses skips
+            # the loss call that would read it
+            mvr = self.mlm_ssl_V_head(v_fusion_t[:, 0]) if self.mlm_ssl_V_head is not None else None        # :148-149
+            mwr = self.mlm_ssl_T_head(t_last_hidden_state[:, 0]) if self.symmetry_rank else None            # :156-157
+            return mvr, mwr
         if heads_side:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 t_all.record_stream(side)
-                mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])
-                mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])
+                mask_visual_recon_emb, mask_word_recon_emb = recon_heads()
 
         # ---- MLM (:129-143): all B*L rows through the decoder, the fused focal kernel skips label == -100
-        score = self.mlm_head(t_last_hidden_state)
-        fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
-        mlm_loss = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
+        mlm_loss = None
+        if self.mlm_head is not None:
+            score = self.mlm_head(t_last_hidden_state)
+            fn = self.mlm_loss_func if self.mlm_loss_func is not None else self.loss_func
+            mlm_loss = fn(score.reshape(-1, self.text_vocab_size), mlm_label.reshape(-1))
 
         if heads_side:
             main.wait_stream(side)
             for t in (vis_emb_both, mask_visual_recon_emb, mask_word_recon_emb):
-                t.record_stream(main)
+                if t is not None:
+                    t.record_stream(main)
         else:
-            mask_visual_recon_emb = self.mlm_ssl_V_head(v_fusion_t[:, 0])             # :148-149
-            mask_word_recon_emb = self.mlm_ssl_T_head(t_last_hidden_state[:, 0])      # :156-157
+            mask_visual_recon_emb, mask_word_recon_emb = recon_heads()
         visual_emb, mask_visual_emb = vis_emb_both.view(2, B, -1).unbind(0)
+        if mask_visual_recon_emb is None:
+            mask_visual_recon_emb = torch.zeros_like(visual_emb)
+        if mask_word_recon_emb is None:
+            mask_word_recon_emb = torch.zeros_like(visual_emb)
         emb = torch.stack([visual_emb, text_emb, mask_word_emb, mask_visual_recon_emb, mask_visual_emb,
                            mask_word_recon_emb], dim=1).float()
         return emb, mlm_loss
@@ -205,13 +225,15 @@ class CloverPretrain(BaseRecognizer):
         g = (gathered if gathered is not None
              else gather_rows(emb.float(), equal_sizes=self.ssl_loss.equal_batch).contiguous())
         V, T, MW, MVR, MV, MWR = range(6)                      # EMB_NAMES order
-        losses = dict(mlm_loss=mlm_loss)
-        losses.update(self.ssl_loss.forward_gathered(g, (V, T, MW, MVR)))                              # :151
-        l2 = self.ssl_loss.forward_gathered(g, (T, V, MV, MWR))                                        # :161
-        l2['v_nce_loss'] = l2.pop('nce_loss')
-        if self.ssl_loss.use_rank:
-            l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')
-        losses.update(l2)
+        losses = dict(mlm_loss=mlm_loss) if mlm_loss is not None else {}
+        if self.mlm_ssl_V_head is not None:                                                                # :147
+            losses.update(self.ssl_loss.forward_gathered(g, (V, T, MW, MVR)))                              # :151
+        if self.symmetry_rank:                                                                             # :155
+            l2 = self.ssl_loss.forward_gathered(g, (T, V, MV, MWR))                                        # :161
+            l2['v_nce_loss'] = l2.pop('nce_loss')
+            if self.ssl_loss.use_rank:
+                l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')
+            losses.update(l2)
         return losses
 
     def forward_train(self, imgs, label, token_ids=None, segment_ids=None, input_mask=None, mlm_label=None,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 9
+#define CLV_ABI_VERSION 10
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -183,6 +183,18 @@ int clv_ln_fold_fwd(const float* w, const float* b, const float* gamma, const fl
                     int32_t N, int32_t K, void* stream);
 int clv_ln_fold_bwd(const float* dwf, const float* dbf, const float* w, const float* gamma, const float* beta,
                     float* dw, float* db, float* dgamma, float* dbeta, int32_t N, int32_t K, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d of the projection heads
+ * nn.BatchNorm1d on [B][D] fp32 rows — the ln=False / text_bn=True variants of NCEHeadForMM / NCEHeadForVision /
+ * NCEHeadForText (mmaction/models/heads/ssl_head.py:50-66,175-186,252-262).  training != 0: batch statistics (biased
+ * variance), running_mean / running_var (may both be NULL) updated with `momentum` and the unbiased variance; training == 0:
+ * the running statistics normalise.  save_mean / save_rstd (float [D]) are outputs the backward reads.  Backward: dx (or NULL),
+ * dgamma, dbeta (or NULL) are WRITTEN; in training mode dx carries the dependence of the statistics on the batch. */
+int clv_batchnorm1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* y, float* save_mean, float* save_rstd, int32_t B, int32_t D, float eps, float momentum,
+                        int32_t training, void* stream);
+int clv_batchnorm1d_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                        float* dx, float* dgamma, float* dbeta, int32_t B, int32_t D, int32_t training, void* stream);
 
 /* ------------------------------------------------------------------ GELU (erf)
  * nn.GELU / HF 'gelu' (swin_transformer_3d.py:264; BertIntermediate; ssl_head.py:53). */

@@ -434,22 +434,27 @@ def forward_train(P, batch, cfg, gather=True):
     t_fusion = fusion_forward(P, 'multimodal_backbone.', vt, tmask, text_with_mask, cfg['fusion'])    # :119
     t_last = t_fusion['t_last_hidden_state']
 
+    # ablation switches of the recognizer's constructor (:26-43), all on in the published recipe:
+    # cfg['mlm_head'] (:129), cfg['mlm_ssl_head'] (:147: the V / T reconstruction heads), cfg['symmetry_rank'] (:155)
     losses = {}
-    scores = mlm_head(P, 'mlm_head.', t_last)                                      # :134
-    rows = torch.where(mlm_label.reshape(-1) != -100)[0]                           # :137
-    losses['mlm_loss'] = focal_loss_multiclass(scores.reshape(-1, scores.shape[-1])[rows],
-                                               mlm_label.reshape(-1)[rows], cfg.get('gamma', 2.0))
+    if cfg.get('mlm_head', True):
+        scores = mlm_head(P, 'mlm_head.', t_last)                                  # :134
+        rows = torch.where(mlm_label.reshape(-1) != -100)[0]                       # :137
+        losses['mlm_loss'] = focal_loss_multiclass(scores.reshape(-1, scores.shape[-1])[rows],
+                                                   mlm_label.reshape(-1)[rows], cfg.get('gamma', 2.0))
 
     kw = dict(temperature=cfg.get('temperature', 0.05), margin=cfg.get('margin', 5.0), gather=gather)
-    mask_visual_recon = nce_vision_head(P, 'mlm_ssl_V_head.', v_fusion['t_last_hidden_state'][:, 0])  # :148-149
-    mask_word_emb = nce_mm_forward_text(P, 'ssl_head.', text_with_mask)            # :150
-    losses.update(exclusive_nce_rank_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon, **kw))  # :151
+    if cfg.get('mlm_ssl_head', True):                                              # :147
+        mask_visual_recon = nce_vision_head(P, 'mlm_ssl_V_head.', v_fusion['t_last_hidden_state'][:, 0])  # :148-149
+        mask_word_emb = nce_mm_forward_text(P, 'ssl_head.', text_with_mask)        # :150
+        losses.update(exclusive_nce_rank_loss(visual_emb, text_emb, mask_word_emb, mask_visual_recon, **kw))  # :151
 
-    mask_word_recon = nce_text_head(P, 'mlm_ssl_T_head.', t_last[:, 0])            # :156-157
-    mask_visual_emb = nce_mm_forward_vision(P, 'ssl_head.', visual_masked)         # :159
-    l2 = exclusive_nce_rank_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon, **kw)       # :161
-    losses['v_nce_loss'] = l2['nce_loss']                                          # :162
-    losses['rank_v_vm_loss'] = l2['rank_t_tm_loss']                                # :165
+    if cfg.get('symmetry_rank', True):                                             # :155
+        mask_word_recon = nce_text_head(P, 'mlm_ssl_T_head.', t_last[:, 0])        # :156-157
+        mask_visual_emb = nce_mm_forward_vision(P, 'ssl_head.', visual_masked)     # :159
+        l2 = exclusive_nce_rank_loss(text_emb, visual_emb, mask_visual_emb, mask_word_recon, **kw)   # :161
+        losses['v_nce_loss'] = l2['nce_loss']                                      # :162
+        losses['rank_v_vm_loss'] = l2['rank_t_tm_loss']                            # :165
     return losses
 
 

@@ -7,7 +7,8 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test, finetune.
+Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test, finetune, full (benchmark shapes:
+~10 minutes and ~40 GB on 8 cores; not part of the default list).
 """
 import json
 import os
@@ -418,11 +419,75 @@ def gen_dist():
     save('g_dist.npz', out)
 
 
+# --------------------------------------------------------------------------- #
+# BASELINE configs 2 and 5 at FULL shapes: the real reference on the weights / batch the GPU tests use
+FULL_GRAD_KEYS = {
+    'T': ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.3.attn.relative_position_bias_table',
+          'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
+          'text_backbone.bert.encoder.layer.6.attention.self.query.weight',
+          'multimodal_backbone.bert_encoder.layer.2.output.dense.weight', 'mlm_head.predictions.decoder.weight'],
+    'B': ['backbone.patch_embed.proj.weight', 'backbone.layers.2.blocks.11.attn.relative_position_bias_table',
+          'backbone.layers.2.blocks.14.mlp.fc1.weight', 'backbone.layers.2.blocks.17.attn.qkv.weight',
+          'backbone.layers.1.downsample.reduction.weight', 'backbone.layers.3.blocks.1.mlp.fc2.weight',
+          'multimodal_backbone.fc_in.weight', 'multimodal_backbone.bert_encoder.layer.2.output.dense.weight',
+          'text_backbone.bert.encoder.layer.6.attention.self.query.weight', 'mlm_head.predictions.decoder.weight'],
+}
+
+
+def gen_full():
+    """The REAL reference at benchmark shapes: VideoSwin-T + BERT-base, 8 frames (BASELINE config 2)
+    and VideoSwin-B + BERT-base, 32 frames (config 5's model and clip length), 224^2, 32 tokens, B = 2 — on exactly the
+    weights (seed-4321 init of the registered modules) and batch (bench.synthetic_batch seed 77) that
+    tests/gutil.py::full_size_oracle hands to the GPU tests.  Stored: the six logged losses, packed gradients of the
+    parameters the full-size GPU tests look at, seconds per iteration of the reference on this container's cores."""
+    import time
+    ROOT = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, ROOT)
+    import bench
+    import clover_amd
+    H.make_bert_dir(SCRATCH + '_base', hidden=768, layers=12, heads=12, inter=3072, vocab=30522, max_pos=512)
+    H.init_dist_single()
+    out = {}
+    for variant, frames in (('T', 8), ('B', 32)):
+        tag = f'{variant}{frames}'
+        cfg = bench.model_cfg(variant, frames)
+        torch.manual_seed(4321)
+        own = clover_amd.build_model(cfg).eval()
+        sd = {k: v.detach().clone() for k, v in own.state_dict().items()}
+        del own
+        rcfg = bench.model_cfg(variant, frames)
+        for part in ('mm_backbone', 'text_backbone'):           # the reference classes read the HF directory instead
+            rcfg[part].pop('bert_config', None)
+        m = H.build_reference_model(rcfg, SCRATCH + '_base')
+        missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=False)
+        assert all('relative_position_index' in k or 'position_ids' in k for k in missing), missing[:5]
+        assert not unexpected, unexpected[:5]
+        m.eval()
+        batch = bench.synthetic_batch(2, frames, 32, seed=77)
+        torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+        t0 = time.time()
+        loss, lv = _step(m, batch)
+        loss.backward()
+        out[f'{tag}.ref_seconds_fwd_bwd'] = np.float64(time.time() - t0)
+        out[f'{tag}.cores'] = np.int64(len(os.sched_getaffinity(0)))
+        for k, v in lv.items():
+            out[f'{tag}.{k}'] = np.float64(v)
+        named = dict(m.named_parameters())
+        for k in FULL_GRAD_KEYS[variant]:
+            pack(out, f'{tag}.grad.{k}', named[k].grad)
+        print(tag, {k: round(float(v), 6) for k, v in lv.items()}, 'seconds', out[f'{tag}.ref_seconds_fwd_bwd'])
+        del m, named, loss
+    save('g_full.npz', out)
+
+
 SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
             step=gen_step, dist=gen_dist, inflate=gen_inflate, test=gen_test, finetune=gen_finetune)
 
+HEAVY = dict(full=gen_full)      # only on request
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SETS)
+    SETS.update(HEAVY)
     torch.set_num_threads(8)
     for s in which:
         SETS[s]()

@@ -248,6 +248,38 @@ def test_use_checkpoint_under_the_engine():
         assert abs(a - c) <= 1e-3 * max(1.0, abs(a)), res
 
 
+def test_optimizer_state_from_another_slab_layout():
+    """a checkpoint whose flat Adam moments were laid out with other slot offsets (the slab alignment / phantom
+    padding changed between rounds) must load per parameter by name, not by copying the flat buffers."""
+    from clover_amd.engine import CloverEngine
+    b = batch(2, 'optlay')
+    eng = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.01, grad_clip=15.0, max_iters=10 ** 9)
+    eng.step(b)
+    eng.step(b)
+    st = eng.optimizer_state()
+    for seg_state, sg in zip(st['segments'], eng.segments):
+        off, pos, m_chunks, v_chunks = [], 0, [], []
+        for i, p_ in enumerate(sg.params):
+            n, pad = p_.numel(), (i % 3) * 2                  # the "old" layout: other gaps between the slots
+            off.append(pos)
+            for chunks, key in ((m_chunks, 'exp_avg'), (v_chunks, 'exp_avg_sq')):
+                chunks.append(seg_state[key][sg.offsets[i]:sg.offsets[i] + n])
+                chunks.append(torch.full((pad,), 7.0))         # garbage in the gaps must not reach any parameter
+            pos += n + pad
+        seg_state['offsets'] = off + [pos]
+        seg_state['exp_avg'], seg_state['exp_avg_sq'] = torch.cat(m_chunks), torch.cat(v_chunks)
+        assert seg_state['exp_avg'].numel() != sg.exp_avg.numel() or off != list(sg.offsets[:len(off)])
+    eng2 = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.01, grad_clip=15.0, max_iters=10 ** 9)
+    eng2.load_optimizer_state(st)
+    assert eng2.adam_steps() == eng.adam_steps()
+    for sg, sg2 in zip(eng.segments, eng2.segments):
+        for i, (name, p_) in enumerate(zip(sg.names, sg.params)):
+            a, n = sg.offsets[i], p_.numel()
+            assert torch.equal(sg.exp_avg[a:a + n], sg2.exp_avg[a:a + n]), name
+            assert torch.equal(sg.exp_avg_sq[a:a + n], sg2.exp_avg_sq[a:a + n]), name
+        assert float(sg2.exp_avg.abs().max()) < 7.0
+
+
 def test_graphs_per_batch_geometry():
     """The reference alternates video (many-frame) and image (1-frame, padded to 2) batches (clover_runner.py:76-93):
     the engine keeps one set of hipGraphs per batch geometry, captured on first sight, and the alternating

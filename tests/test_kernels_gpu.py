@@ -1156,4 +1156,87 @@ def test_mlm_decoder_padded_vocabulary(R, V, H):
     assert rel(bias._clv_pad_grad[:V], br.grad) < 3e-2
     if Vp > V:
         assert float(weight._clv_pad_grad[V:].abs().max()) == 0.0 and float(bias._clv_pad_grad[V:].abs().max()) == 0.0
-    assert not L.PADDED_GRADS
+
+
+# ----------------------------------------------------------------------------- BatchNorm variants of the projection heads
+@pytest.mark.parametrize('B,D', [(8, 768), (16, 1536), (5, 96), (300, 1000)])
+def test_batchnorm1d_kernel(B, D):
+    """clv_batchnorm1d_fwd / _bwd against torch.nn.BatchNorm1d (fp32, CPU): training mode (batch statistics, running
+    averages with the unbiased variance, the gradient through the statistics) and eval mode (running statistics)."""
+    from clover_amd.nn import BatchNorm1d
+    x = rnd(B, D, seed=1300) * 2.0 + 0.5
+    dy = rnd(B, D, seed=1301)
+    ref, own = torch.nn.BatchNorm1d(D), BatchNorm1d(D).to(DEV)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.1 * rnd(D, seed=1302)); ref.bias.copy_(0.1 * rnd(D, seed=1303))
+        ref.running_mean.copy_(0.2 * rnd(D, seed=1304)); ref.running_var.copy_(1 + 0.3 * rnd(D, seed=1305).abs())
+    own.load_state_dict(ref.state_dict())
+    assert set(own.state_dict()) == set(ref.state_dict())
+    for mode in ('train', 'train', 'eval'):
+        ref.train(mode == 'train'); own.train(mode == 'train')
+        xr, xg = x.clone().requires_grad_(), x.to(DEV).requires_grad_()
+        ref.zero_grad(); own.zero_grad()
+        yr, y = ref(xr), own(xg)
+        yr.backward(dy); y.backward(dy.to(DEV))
+        assert rel(y, yr) < 2e-5, (mode, rel(y, yr))
+        assert rel(xg.grad, xr.grad) < 2e-4, (mode, rel(xg.grad, xr.grad))
+        assert rel(own.weight.grad, ref.weight.grad) < 2e-5 and rel(own.bias.grad, ref.bias.grad) < 2e-5
+        assert rel(own.running_mean, ref.running_mean) < 1e-5 and rel(own.running_var, ref.running_var) < 1e-5
+        assert int(own.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_heads_batchnorm_variants():
+    """NCEHeadForMM(ln=False, text_bn=True), NCEHeadForVision(ln=False), NCEHeadForText(text_bn=True)
+    (ssl_head.py:50-66,175-186,252-262): same state_dict keys as the reference's module tree, outputs and parameter gradients
+    equal to an fp32 torch restatement of that tree; a batch that stacks two forward passes (the recognizer's doubled clean +
+    masked pass) is normalised per pass, in the reference's call order."""
+    import torch.nn as nn
+    from clover_amd.heads.ssl_head import NCEHeadForMM, NCEHeadForText, NCEHeadForVision
+    torch.manual_seed(7)
+    Cv, Ct, Hd, E, B = 96, 64, 128, 64, 6
+    mm = NCEHeadForMM(Cv, Ct, Hd, E, ln=False, text_bn=True, dropout_ratio=0, text_agg_type='cls').to(DEV).train()
+    ref_img = nn.Sequential(nn.Linear(Cv, Hd), nn.BatchNorm1d(Hd), nn.GELU(), nn.Linear(Hd, E), nn.BatchNorm1d(E))
+    ref_txt = nn.Sequential(nn.Linear(Ct, Ct), nn.BatchNorm1d(Ct), nn.GELU(), nn.Linear(Ct, E))
+    assert set(mm.img_projector.state_dict()) == set(ref_img.state_dict())
+    assert set(mm.text_projector.state_dict()) == set(ref_txt.state_dict())
+    ref_img.load_state_dict({k: v.cpu() for k, v in mm.img_projector.state_dict().items()})
+    ref_txt.load_state_dict({k: v.cpu() for k, v in mm.text_projector.state_dict().items()})
+    vis = rnd(2 * B, 2, 3, 3, Cv, seed=1310)                  # channels-last [2B, T, h, w, C]: clean ; masked
+    txt = rnd(2 * B, 5, Ct, seed=1311)                        # [masked captions ; un-masked captions]
+    w = rnd(2 * B, E, seed=1312)
+    y = mm.forward_vision(vis.to(DEV), channels_last=True, passes=2)
+    pooled = vis.mean(dim=(1, 2, 3))
+    yr = torch.cat([ref_img(pooled[:B]), ref_img(pooled[B:])])          # clean first (:102), masked second (:159)
+    assert rel(y, yr) < 1e-4, rel(y, yr)
+    t = mm.forward_text(txt.to(DEV), passes=2, order=(1, 0))
+    cls = txt[:, 0]
+    t1 = ref_txt(cls[B:])                                               # un-masked first (:102) ...
+    tr = torch.cat([ref_txt(cls[:B]), t1])                              # ... masked second (:150)
+    assert rel(t, tr) < 1e-4, rel(t, tr)
+    ((y * w.to(DEV)).sum() + (t * w.to(DEV)).sum()).backward()
+    ((yr * w).sum() + (tr * w).sum()).backward()
+    for own_m, ref_m in ((mm.img_projector, ref_img), (mm.text_projector, ref_txt)):
+        for (n, p), (_, q) in zip(own_m.named_parameters(), ref_m.named_parameters()):
+            assert rel(p.grad, q.grad) < 5e-4, (n, rel(p.grad, q.grad))
+        for (n, b_), (_, c_) in zip(own_m.named_buffers(), ref_m.named_buffers()):
+            assert rel(b_.float(), c_.float()) < 1e-5, n                # running statistics after two calls, in order
+    v = NCEHeadForVision(cross_in_channels=Ct, visual_in_channels=Ct, hidden_dim=32, vts_embed_dim=E, ln=False,
+                         dropout_ratio=0).to(DEV).train()
+    assert isinstance(v.img_bn1, nn.BatchNorm1d) and isinstance(v.img_bn2, nn.BatchNorm1d)
+    tt = NCEHeadForText(cross_in_channels=Ct, vts_embed_dim=E, text_bn=True, dropout_ratio=0).to(DEV).train()
+    assert isinstance(tt.bn, nn.BatchNorm1d)
+    xin = rnd(B, Ct, seed=1313)
+    rv = nn.Sequential(nn.Linear(Ct, 64), nn.BatchNorm1d(64), nn.GELU(), nn.Linear(64, E), nn.BatchNorm1d(E))
+    rv.load_state_dict({k2: v.state_dict()[k1].cpu() for k1, k2 in zip(
+        [f'{m}.{s}' for m in ('img_fc1', 'img_bn1', 'img_fc2', 'img_bn2') for s in
+         (('weight', 'bias') if 'fc' in m else ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'))],
+        [f'{i}.{s}' for i, m in ((0, 'fc'), (1, 'bn'), (3, 'fc'), (4, 'bn')) for s in
+         (('weight', 'bias') if m == 'fc' else ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'))])})
+    assert rel(v(xin.to(DEV)), rv(xin)) < 1e-4
+    rt = nn.Sequential(nn.Linear(Ct, Ct), nn.BatchNorm1d(Ct), nn.GELU(), nn.Linear(Ct, E))
+    rt.load_state_dict({k2: tt.state_dict()[k1].cpu() for k1, k2 in zip(
+        ['fc1.weight', 'fc1.bias', 'bn.weight', 'bn.bias', 'bn.running_mean', 'bn.running_var', 'bn.num_batches_tracked',
+         'fc2.weight', 'fc2.bias'],
+        ['0.weight', '0.bias', '1.weight', '1.bias', '1.running_mean', '1.running_var', '1.num_batches_tracked',
+         '3.weight', '3.bias'])})
+    assert rel(tt(xin.to(DEV)), rt(xin)) < 1e-4

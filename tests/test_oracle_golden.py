@@ -203,3 +203,50 @@ def test_finetune_separate_test(P, ocfg):
         v, t = om.finetune_embeddings(P, b2, ocfg)
         gutil.assert_close(v, g['test.clips2.visual_emb'], rtol=2e-4, name='visual_emb clips2')
         gutil.assert_close(t, g['test.clips2.text_emb'], rtol=2e-4, name='text_emb clips2')
+
+
+# ------------------------------------------------------------------ G-full: the REAL reference at benchmark shapes
+def _packed_rel(g, name, t):
+    sub, stats = gutil.packed(t)
+    gsub = g[name + '.sub'].astype(np.float64)
+    assert g[name + '.stats'][2] == stats[2]
+    return np.abs(sub - gsub).max() / max(np.abs(gsub).max(), 1e-20)
+
+
+def test_oracle_matches_reference_at_config2_shapes():
+    """g_full.npz (make_goldens.py full): the real reference run at BASELINE config 2's shapes (VideoSwin-T + BERT-base, 8 f x
+    224^2, 32 tokens, B = 2) on the seed-4321 weights and the bench's synthetic batch (seed 77) — exactly what
+    tests/gutil.py::full_size_oracle hands the GPU tests.  The oracle must reproduce its six losses (2e-5 absolute on
+    values of 5-30: fp32 summation order) and the gradients the full-size GPU tests read (1e-3 of max)."""
+    g = gutil.load('g_full.npz')
+    cfg, sd, batch, lv, grads = gutil.full_size_oracle('T', 8)
+    for k in ('mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss'):
+        assert abs(lv[k] - float(g[f'T8.{k}'])) <= 2e-5 * max(1.0, abs(float(g[f'T8.{k}']))), (k, lv[k], float(g[f'T8.{k}']))
+    names = [n[len('T8.grad.'):-4] for n in g.files if n.startswith('T8.grad.') and n.endswith('.sub')]
+    assert len(names) >= 5
+    for n in names:
+        e = _packed_rel(g, f'T8.grad.{n}', grads[n])
+        assert e < 1e-3, (n, e)
+
+
+def test_oracle_matches_reference_at_config5_model_and_clip_length():
+    """The same pin for VideoSwin-B + BERT-base at 32 frames (config 5's model and clip length; the (4,3,3)-shifted
+    (8,7,7) windows, 816-token fusion sequences): the oracle's forward (no backward here: the CPU suite stays short — the
+    GPU tests take the gradients from the oracle, whose backward is torch autograd over the same graph) against the
+    reference's six losses."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    g = gutil.load('g_full.npz')
+    torch.manual_seed(4321)
+    cfg = bench.model_cfg('B', 32)
+    m = clover_amd.build_model(cfg).eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items() if 'relative_position_index' not in k}
+    del m
+    batch = bench.synthetic_batch(2, 32, 32, seed=77)
+    with torch.no_grad():
+        _, lv = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
+    for k in ('mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss'):
+        assert abs(float(lv[k]) - float(g[f'B32.{k}'])) <= 2e-5 * max(1.0, abs(float(g[f'B32.{k}']))), (k, float(lv[k]), float(g[f'B32.{k}']))

@@ -160,6 +160,63 @@ def test_step_losses_and_grads(model, B):
     assert unused == gutil.unused_params()
 
 
+@pytest.mark.parametrize('switch', ['symmetry_rank', 'mlm_ssl_head', 'mlm_head', 'mlm_loss'])
+def test_forward_train_ablation_switches(model, switch):
+    """The constructor switches of CloverPretrain.forward_train (multimodal_transformer_pretrain.py:129-169): with
+    symmetry_rank=False the second ssl_loss call disappears, with mlm_ssl_head=None (and symmetry_rank=False) both do, with
+    mlm_head=None the MLM loss; the losses that remain keep the value they have in the full recipe (reference golden) and
+    equal the oracle run with the same switch; no gradient reaches a switched-off head.  mlm_loss=None routes the MLM
+    scores through loss_type's CrossEntropyLoss over the labelled rows (:141-142)."""
+    import clover_amd
+    from oracle import model as om
+    cfg = cf.tiny_model_cfg()
+    ocfg = dict(cf.oracle_cfg_from(cf.tiny_model_cfg()))
+    if switch == 'symmetry_rank':
+        cfg['symmetry_rank'] = False
+        ocfg['symmetry_rank'] = False
+        gone = {'v_nce_loss', 'rank_v_vm_loss'}
+    elif switch == 'mlm_ssl_head':
+        cfg['symmetry_rank'], cfg['mlm_ssl_head'] = False, None
+        ocfg['symmetry_rank'], ocfg['mlm_ssl_head'] = False, False
+        gone = {'v_nce_loss', 'rank_v_vm_loss', 'nce_loss', 'rank_t_tm_loss'}
+    elif switch == 'mlm_head':
+        cfg['mlm_head'] = None
+        ocfg['mlm_head'] = False
+        gone = {'mlm_loss'}
+    else:
+        cfg['mlm_loss'] = None
+        gone = set()
+    m = clover_amd.build_model(cfg)
+    sd = cf.cf_state(gutil.manifest())
+    missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=False)
+    assert not unexpected and all('relative_position_index' in k for k in missing), (missing, unexpected)
+    m = m.to(DEV).eval()
+    B = 2
+    batch_cpu = cf.cf_batch(B, tag=f'step{B}')
+    out = m.train_step(to_dev(batch_cpu), None)
+    lv = out['log_vars']
+    g = gutil.load('g_step.npz')
+    assert set(lv) == (set(LOSS_KEYS) - gone), (set(lv), gone)
+    if switch != 'mlm_loss':
+        ref = om.forward_train(sd, batch_cpu, ocfg, gather=False)
+        assert set(ref) == set(lv) - {'loss'}
+        for k in set(lv) - {'loss'}:
+            assert abs(lv[k] - float(ref[k])) <= LOSS_TOL[k], (k, lv[k], float(ref[k]))
+            assert abs(lv[k] - float(g[f'B{B}.{k}'])) <= LOSS_TOL[k], (k, lv[k], float(g[f'B{B}.{k}']))
+    else:
+        # CrossEntropyLoss (mean over the labelled rows) of the same scores the focal loss reads in the full recipe
+        full = model.train_step(to_dev(batch_cpu), None)['log_vars']
+        for k in ('nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss'):
+            assert abs(lv[k] - full[k]) <= 1e-3 * max(1.0, abs(full[k])), k
+        assert lv['mlm_loss'] > full['mlm_loss'] > 0            # focal (gamma = 2) down-weights the same cross entropy
+    out['loss'].backward()
+    named = dict(m.named_parameters())
+    if switch in ('symmetry_rank', 'mlm_ssl_head'):
+        dead = [n for n in named if n.startswith('mlm_ssl_T_head.')]
+        assert all(named[n].grad is None or float(named[n].grad.abs().max()) == 0.0 for n in dead)
+    assert all(torch.isfinite(p.grad).all() for p in named.values() if p.grad is not None)
+
+
 # ----------------------------------------------------------------------------- retrieval fine-tuning (SURVEY 8f-4)
 @pytest.fixture(scope='module')
 def ft_model():

@@ -14,7 +14,7 @@ rm -rf $R/gpurun_out/prof; mkdir -p $R/gpurun_out/prof
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err); echo "rocprof rc=$?"
 f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_bench_default_final.csv && head -8 "$f" | cut -c1-150
-echo "{\"commit\": \"$CLOVER_COMMIT\", \"command\": \"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline\"}" > gpurun_out/${TAG}_kernel_stats_bench_default_final.meta.json
+echo "{\"commit\": \"$CLOVER_COMMIT\", \"csrc_sha16\": \"$(python3 tools/csrc_hash.py)\", \"command\": \"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline\"}" > gpurun_out/${TAG}_kernel_stats_bench_default_final.meta.json
 find gpurun_out/prof -name '*kernel_trace.csv' -delete; find gpurun_out/prof -name '*.db' -delete
 bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 bash tools/pmc_mfma.sh > gpurun_out/${TAG}_pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma.json gpurun_out/${TAG}_pmc_mfma.json

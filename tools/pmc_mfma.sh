@@ -35,9 +35,11 @@ for k, d in acc.items():
                   valu_active_frac_of_wave_cycles=round(m.get('SQ_ACTIVE_INST_VALU', 0) / max(m.get('SQ_WAVE_CYCLES', 1), 1), 4),
                   wait_frac_of_wave_cycles=round(m.get('SQ_WAIT_ANY', 0) / max(m.get('SQ_WAVE_CYCLES', 1), 1), 4),
                   mfma_insts_per_launch=round(m.get('SQ_INSTS_MFMA', 0)), gui_active_cycles=round(m['GRBM_GUI_ACTIVE']))
-import os
+import os, sys
+sys.path.insert(0, 'tools')
+from csrc_hash import csrc_sha16
 res = dict(sorted(out.items(), key=lambda kv: -kv[1]['gui_active_cycles'] * kv[1]['launches']))
-res['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ' + os.environ.get('BENCH_ARGS', ''))
+res['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), csrc_sha16=csrc_sha16(), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ' + os.environ.get('BENCH_ARGS', ''))
 print(json.dumps(res, indent=1))
 PY
 head -c 1800 gpurun_out/pmc_mfma.json

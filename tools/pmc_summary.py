@@ -30,6 +30,8 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 1])[0]
     out[k] = dict(launches=f[1], fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                   hbm_bytes_per_launch=round(fb + wb))
 import os
-out['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ' + os.environ.get('BENCH_ARGS', ''),
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_sha16
+out['_meta'] = dict(commit=os.environ.get('CLOVER_COMMIT', 'unknown'), csrc_sha16=csrc_sha16(), command='bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ' + os.environ.get('BENCH_ARGS', ''),
                     note='FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B); per launch = mean over the launches of the run')
 print(json.dumps(out, indent=1))

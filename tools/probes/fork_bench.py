@@ -7,8 +7,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from clover_amd import ops
-from clover_amd.utils.gemm_tuning import enable_tuned_gemms
-enable_tuned_gemms()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 12544
 dims = [(384, 1536), (1536, 384)] * 6                      # (N out-features of this layer's dy, K in-features)
 dev = 'cuda'

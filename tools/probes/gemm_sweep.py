@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch, torch.nn.functional as F
 from clover_amd import ops
-from clover_amd.utils.gemm_tuning import enable_tuned_gemms
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from lib_gemm_tuning import enable_tuned_gemms
 enable_tuned_gemms()
 
 

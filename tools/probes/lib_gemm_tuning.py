@@ -1,17 +1,16 @@
-"""Library-GEMM algorithm selection (PyTorch TunableOp over hipBLASLt / rocBLAS).
+"""Probe helper: tuned LIBRARY GEMMs (PyTorch TunableOp over hipBLASLt / rocBLAS) as the comparison baseline of the GEMM
+probes (gemm_sweep.py, gemm_tiles.py, gemm_bench.py: "own kernel vs the library's best on this shape").
 
-The plain GEMMs of the step (Swin stages 1-3 forward/dgrad, BERT, fusion, MLM decoder) go through the
-ROCm libraries; their default heuristics are tuned for large square problems and pick poor kernels
-for several of this workload's tall-skinny shapes.  ``clover_amd/tuning/*.csv`` holds the per-shape
-winners measured once on an MI355X (``bench.py --tune-gemms`` regenerates the file); loading it costs
-nothing at run time and shapes that are not listed keep the library default.  torch validates the file
-header (torch / hipBLASLt / rocBLAS versions, gfx arch) and ignores a file that does not match."""
+No product code uses it: since round 4 no library GEMM is left on the step.  ``tools/probes/tuning/*.csv`` holds the
+per-shape winners measured once on an MI355X — the library's default heuristics pick poor kernels for several of this
+workload's tall-skinny shapes, and an untuned baseline would flatter the own kernels.  torch validates the file header
+(torch / hipBLASLt / rocBLAS versions, gfx arch) and ignores a file that does not match."""
 import os
 import tempfile
 
 import torch
 
-_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_FILE = os.path.join(_HERE, 'tuning', 'gemm_gfx950_bench_b8.csv')
 
 

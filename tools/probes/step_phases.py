@@ -5,8 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch, bench, clover_amd
 from clover_amd.engine import CloverEngine
-from clover_amd.utils.gemm_tuning import enable_tuned_gemms
-enable_tuned_gemms()
 dev = torch.device('cuda', 0)
 import torch.distributed as dist
 if os.environ.get('CLOVER_FORCE_COLLECTIVES') == '1':
