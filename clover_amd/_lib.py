@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -43,6 +43,15 @@ class ClvWgradEntry(C.Structure):
 WGRAD_GROUP_MAX = 40
 
 
+class ClvDbiasGather(C.Structure):
+    """Mirror of ``struct ClvDbiasGather`` (include/clover_hip.h): one pending table-gradient gather."""
+    _fields_ = [('partial', _p), ('dtable', _p), ('index', _p), ('split_stride', _i64), ('nkt', _i32), ('nH', _i32),
+                ('N', _i32), ('nsplit', _i32), ('slot0', _i32), ('nslots', _i32), ('block_begin', _i32), ('pad', _i32)]
+
+
+DBIAS_GATHER_MAX = 32
+
+
 class ClvLnReduceEntry(C.Structure):
     _fields_ = [('partial', _p), ('dgamma', _p), ('dbeta', _p), ('nblk', _i32), ('C', _i32), ('block_begin', _i32),
                 ('pad', _i32)]
@@ -65,6 +74,8 @@ SIGNATURES = {
     'clv_attn_bwd_one_kernel': (C.c_int, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index_count': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p]),
+    'clv_attn_dbias_gather_entry': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p, C.POINTER(ClvDbiasGather)]),
+    'clv_attn_dbias_gather_batch': (C.c_int, [C.POINTER(ClvDbiasGather), _i32, _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),
     'clv_softmax_rows_fwd': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _f, _f, _p]),
     'clv_softmax_rows_bwd': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _f, _f, _p]),

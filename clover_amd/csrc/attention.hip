@@ -1128,7 +1128,20 @@ __global__ void __launch_bounds__(256) dbias_sum_kernel(const bf16_t* __restrict
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int g = blockIdx.y; g < groups; g += gridDim.y) {
+    // four groups per trip: their 16-byte loads are in flight together (a slice is long since round 5: few slices keep the
+    // gather that follows short — it reads every slice's partial sum of every (table row, key) pair)
+    int g = blockIdx.y;
+    const int gs = gridDim.y;
+    for (; g + 3 * gs < groups; g += 4 * gs) {
+        Frag8 v0, v1, v2, v3;
+        v0.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)g * E2 + e) * 8);
+        v1.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)(g + gs) * E2 + e) * 8);
+        v2.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)(g + 2 * gs) * E2 + e) * 8);
+        v3.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)(g + 3 * gs) * E2 + e) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (bf2f(v0.h[i]) + bf2f(v1.h[i])) + (bf2f(v2.h[i]) + bf2f(v3.h[i]));
+    }
+    for (; g < groups; g += gs) {
         Frag8 v;
         v.u4 = *reinterpret_cast<const uint4*>(ds + ((int64_t)g * E2 + e) * 8);
 #pragma unroll
@@ -1214,6 +1227,40 @@ __global__ void __launch_bounds__(256) dbias_gather_tab_kernel(const float* __re
     }
     a = wave_sum(a);
     if (lane == 0) dtable[w] += a;
+}
+
+// The gathers of SEVERAL attention blocks as one launch (clv_attn_dbias_gather_batch): nothing reads a table gradient
+// before the optimizer, so a backward segment leaves the slices' partial sums in its work buffers (stage bit 8 of
+// clv_attn_bwd) and gathers all blocks at its end — 12 latency-bound launches per step become one.
+struct GatherTable {
+    ClvDbiasGather e[CLV_DBIAS_GATHER_MAX];
+    int n;
+};
+__global__ void __launch_bounds__(256) dbias_gather_batch_kernel(GatherTable tab) {
+    int idx = 0;
+    for (int i = 1; i < tab.n; ++i)
+        if ((int)blockIdx.x >= tab.e[i].block_begin) idx = i;
+    const ClvDbiasGather& en = tab.e[idx];
+    const int wl = ((int)blockIdx.x - en.block_begin) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wl >= en.nslots * en.nH) return;
+    const int slot = en.slot0 + wl / en.nH, h = wl % en.nH;
+    const int NK = en.nkt * 16, nqt = (en.N + 15) >> 4;
+    const float* dh = static_cast<const float*>(en.partial) + (int64_t)h * nqt * en.nkt * 256;
+    const int* trow = static_cast<const int*>(en.index) + slot * NK;
+    const int nsplit = en.nsplit;
+    const int64_t split_stride = en.split_stride;
+    float a = 0.f;
+    for (int kb = lane; kb < NK; kb += 64) {
+        const int off = trow[kb];
+        if (off < 0) continue;
+        const float* pe = dh + off;
+        int sp = 0;
+        for (; sp + 4 <= nsplit; sp += 4)
+            a += (pe[sp * split_stride] + pe[(sp + 1) * split_stride]) + (pe[(sp + 2) * split_stride] + pe[(sp + 3) * split_stride]);
+        for (; sp < nsplit; ++sp) a += pe[sp * split_stride];
+    }
+    a = wave_sum(a);
+    if (lane == 0) static_cast<float*>(en.dtable)[slot * en.nH + h] += a;
 }
 
 // ------------------------------------------------------------------------- fp32 parity kernel
@@ -1570,6 +1617,14 @@ constexpr int DBIAS_SPLITS = 32;      // group slices of the dS reduction (parti
 
 // bytes of the bf16 dS scratch (16 x 16 fragments of every (group, head)), rounded so that the fp32 dense sums that
 // follow it in `work` stay 256-byte aligned
+// Group slices of the streaming dS sum: 64 groups each (round 5; 16 before).  Every slice's partial sum of every (table row,
+// key) pair is read by the gather, so few long slices (four loads in flight per thread in dbias_sum_kernel) beat many
+// short ones: same-box 11.41 / 11.44 -> 11.29 / 11.34 ms per step.
+inline int dbias_splits(const Geom& G) {
+    static const int gps = getenv("CLV_DBIAS_GROUPS_PER_SLICE") ? atoi(getenv("CLV_DBIAS_GROUPS_PER_SLICE")) : 64;
+    int splits = G.g.groups / (gps > 0 ? gps : 64);
+    return splits < 1 ? 1 : (splits > DBIAS_SPLITS ? DBIAS_SPLITS : splits);
+}
 inline int64_t ds_scratch_bytes(const Geom& G, int nkt) {
     const int64_t b = (int64_t)G.g.groups * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 2;
     return (b + 255) / 256 * 256;
@@ -1700,15 +1755,14 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     float* partial = bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT)) : nullptr;
     // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
     // bf16 scratch itself once a slice covers only 4 groups
-    int splits = G.g.groups / 16;
-    splits = splits < 1 ? 1 : (splits > DBIAS_SPLITS ? DBIAS_SPLITS : splits);
+    const int splits = dbias_splits(G);
     // The dS scratch of a stage-0 block is 266 MB at 16 clips: written by the dQ kernel, read once by the streaming sum —
     // a 0.5 GB HBM round trip per block that exists only to feed the table gradient.  Run the pair in CHUNKS of groups that
     // reuse one scratch region small enough for the Infinity Cache (256 MB): the sum then reads what the dQ kernel just
     // wrote from the cache, and the next chunk overwrites the same lines before they are ever written back.
     static const int chunk_mb = getenv("CLV_DBIAS_CHUNK_MB") ? atoi(getenv("CLV_DBIAS_CHUNK_MB")) : 128;      // same-box A/B: 12.52 -> 12.46 ms per step
     int nch = 1;
-    if (bias && stages == 7 && chunk_mb > 0 && G.nparts == 1) {
+    if (bias && (stages & 7) == 7 && chunk_mb > 0 && G.nparts == 1) {
         const int64_t per_group = E * 2;                       // scratch bytes per group
         while (nch < 8 && (G.g.groups / nch) * per_group > (int64_t)chunk_mb << 20 && G.g.groups % (2 * nch) == 0 &&
                splits % (2 * nch) == 0)
@@ -1747,7 +1801,9 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
             hipLaunchKernelGGL(dbias_sum_kernel, dim3((unsigned)((E / 2 + 255) / 256), splits), dim3(256), 0, st,
                                (const bf16_t*)work, reinterpret_cast<float4*>(partial), G.g.groups, E / 2);
         (void)dense;
-        if (G.g.dbias_index) {
+        if (stages & 8) {
+            // the caller gathers later (clv_attn_dbias_gather_batch): nothing more to launch here
+        } else if (G.g.dbias_index) {
             hipLaunchKernelGGL(dbias_gather_tab_kernel, dim3((G.tbn * G.g.nH + 3) / 4), dim3(256), 0, st, partial, dbias,
                                G.g.dbias_index, NKT, G, splits, E * 4, G.tb0, G.tbn);
         }
@@ -1871,6 +1927,45 @@ extern "C" int clv_attn_bwd(const void* q, const void* k, const void* v, const v
     DISPATCH_NKT(64, launch_bwd, q, k, v, o, dout, lse, bias, rid, kmask, dq, dk, dv, dbias, dsum, work, sp, stages, G, st)
 }
 
+
+extern "C" int clv_attn_dbias_gather_entry(const ClvAttnGeom* geom, void* work, float* dbias, ClvDbiasGather* out) {
+    Geom G;
+    if (!geom || !work || !dbias || !out || !make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0 || !G.g.dbias_index)
+        return CLV_ERR_ARG;
+    const int nkt = pick_nkt(G.g.N);
+    if (nkt < 0) return CLV_ERR_UNSUPPORTED;
+    const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * nkt * 64;
+    out->partial = reinterpret_cast<char*>(work) + ds_scratch_bytes(G, nkt);
+    out->dtable = dbias;
+    out->index = G.g.dbias_index;
+    out->split_stride = E * 4;
+    out->nkt = nkt;
+    out->nH = G.g.nH;
+    out->N = G.g.N;
+    out->nsplit = dbias_splits(G);
+    out->slot0 = G.tb0;
+    out->nslots = G.tbn;
+    out->block_begin = 0;
+    out->pad = 0;
+    return CLV_OK;
+}
+
+extern "C" int clv_attn_dbias_gather_batch(const ClvDbiasGather* entries, int32_t n, void* stream) {
+    if (!entries || n <= 0 || n > CLV_DBIAS_GATHER_MAX) return CLV_ERR_ARG;
+    static_assert(sizeof(ClvDbiasGather) == 64, "ClvDbiasGather layout is part of the ABI");
+    GatherTable tab;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ClvDbiasGather en = entries[i];
+        if (!en.partial || !en.dtable || !en.index || en.nsplit <= 0 || en.nslots <= 0 || en.nH <= 0) return CLV_ERR_ARG;
+        en.block_begin = blocks;
+        blocks += (en.nslots * en.nH + 3) / 4;
+        tab.e[i] = en;
+    }
+    tab.n = n;
+    hipLaunchKernelGGL(dbias_gather_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
+    return clv_check_launch();
+}
 
 extern "C" int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias,
                                 const int32_t* rid, const float* kmask, const ClvAttnGeom* geom, int32_t round_p,

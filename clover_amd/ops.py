@@ -267,6 +267,7 @@ FOLD_DEFER = None           # list while a backward segment defers its weight-gr
 LN_DEFER = None             # ... and the reductions of its LayerNorm-backward partials
 WGRAD_DEFER = None          # ... and whole weight-gradient launches (grouped into one grid)
 POST_DEFER = None           # ... and what consumes a deferred weight gradient (the LayerNorm un-fold), run after the folds
+DBIAS_DEFER = None          # ... and the table-gradient gathers of the window-attention blocks (one launch for all of them)
 
 
 class defer_folds:
@@ -275,7 +276,8 @@ class defer_folds:
     Only for gradients nobody reads before the context closes (the engine wraps whole backward segments)."""
 
     def __enter__(self):
-        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER, DBIAS_DEFER
+        self.prev_db, DBIAS_DEFER = DBIAS_DEFER, ([] if os.environ.get('CLOVER_DEFER_DBIAS', '1') == '1' else None)
         self.prev, FOLD_DEFER = FOLD_DEFER, []
         self.prev_ln, LN_DEFER = LN_DEFER, ([] if os.environ.get('CLOVER_DEFER_LN', '1') == '1' else None)
         self.prev_wg, WGRAD_DEFER = WGRAD_DEFER, ([] if os.environ.get('CLOVER_GROUP_WGRAD', '1') == '1' else None)
@@ -283,7 +285,8 @@ class defer_folds:
         return self
 
     def __exit__(self, *exc):
-        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER
+        global FOLD_DEFER, LN_DEFER, WGRAD_DEFER, POST_DEFER, DBIAS_DEFER
+        pending_db, DBIAS_DEFER = DBIAS_DEFER, self.prev_db
         pending, FOLD_DEFER = FOLD_DEFER, self.prev
         pending_ln, LN_DEFER = LN_DEFER, self.prev_ln
         pending_wg, WGRAD_DEFER = WGRAD_DEFER, self.prev_wg
@@ -294,6 +297,7 @@ class defer_folds:
             for fn in pending_post:
                 fn()
             flush_ln_reduces(pending_ln or [])
+            flush_dbias_gathers(pending_db or [])
         return False
 
 
@@ -380,6 +384,25 @@ def flush_folds(pending):
             e.nk, e.e2, e.splits = N * K, N * K + N, slices
             e.overwrite = int(ow[0]) if ow else 0
         check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
+
+
+def flush_dbias_gathers(pending):
+    """The deferred table-gradient gathers (entry, work, d table, index) as launches of <= DBIAS_GATHER_MAX blocks; two
+    gathers into the SAME table (a module applied twice in the segment) never share a launch — each adds without atomics."""
+    chunk, seen = [], set()
+
+    def go():
+        if chunk:
+            arr = (_lib.ClvDbiasGather * len(chunk))(*[c[0] for c in chunk])
+            check(_lib.lib().clv_attn_dbias_gather_batch(arr, len(chunk), _stream()), 'clv_attn_dbias_gather_batch')
+    for item in pending:
+        key = item[2].data_ptr()
+        if len(chunk) == _lib.DBIAS_GATHER_MAX or key in seen:
+            go()
+            chunk, seen = [], set()
+        chunk.append(item)
+        seen.add(key)
+    go()
 
 
 def flush_ln_reduces(pending):
@@ -1481,7 +1504,14 @@ class _Attention(torch.autograd.Function):
         args = (C.c_void_p(b), C.c_void_p(b + 2 * Cdim), C.c_void_p(b + 4 * Cdim), _ptr(o), _ptr(doc), _ptr(lse),
                 _ptr(tab), _ptr(rid), _ptr(kmask), C.c_void_p(d), C.c_void_p(d + 2 * Cdim),
                 C.c_void_p(d + 4 * Cdim), _ptr(dtab), _ptr(dsum), _ptr(work), _ptr(seed))
-        if PROF is None:
+        if PROF is None and DBIAS_DEFER is not None and sink is not None:
+            # nothing reads a table gradient before the optimizer: leave the slices' partial sums in `work` (stage bit 8) and
+            # gather every attention block of this backward segment in ONE launch when it closes (flush_dbias_gathers)
+            check(L.clv_attn_bwd(*args, 15, C.byref(g), _stream()), 'clv_attn_bwd')
+            ent = _lib.ClvDbiasGather()
+            check(L.clv_attn_dbias_gather_entry(C.byref(g), _ptr(work), _ptr(dtab), C.byref(ent)), 'clv_attn_dbias_gather_entry')
+            DBIAS_DEFER.append((ent, work, dtab, g.dbias_index))
+        elif PROF is None:
             check(L.clv_attn_bwd(*args, 0, C.byref(g), _stream()), 'clv_attn_bwd')
         elif tab is not None and L.clv_attn_bwd_one_kernel(C.byref(g)) == 1:
             fl, by = _attn_work(g, True)           # dQ / dK / dV as one kernel (stage mask 5), then the table gradient (2)

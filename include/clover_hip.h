@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 10
+#define CLV_ABI_VERSION 11
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -98,6 +98,22 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const float* lse, const float* bias, const int32_t* rid, const float* kmask,
                  void* dq, void* dk, void* dv, float* dbias, float* dsum, void* work,
                  const void* seed, int32_t stages, const ClvAttnGeom* geom_host, void* stream);
+/* Deferred table gradient (swin_transformer_3d.py:382-386, the backward of the relative_position_bias_table gather): with
+ * bit 8 set in `stages` (e.g. 15 = everything but the gather) clv_attn_bwd leaves the slices' partial sums of dS in `work` and
+ * does NOT add them into dbias; clv_attn_dbias_gather_entry describes that pending gather (work / dbias / geom as passed to
+ * clv_attn_bwd, geom->dbias_index required) and clv_attn_dbias_gather_batch runs up to CLV_DBIAS_GATHER_MAX of them as ONE
+ * launch (dbias is accumulated into).  `work` must stay untouched in between.  Nothing reads a table gradient before the
+ * optimizer, so a backward pass gathers all its attention blocks at its end. */
+#define CLV_DBIAS_GATHER_MAX 32
+typedef struct ClvDbiasGather {
+    const void* partial;       /* float partial sums inside the work buffer */
+    void* dtable;              /* float [rows][nH] */
+    const void* index;         /* int32 table of clv_attn_dbias_index() */
+    int64_t split_stride;
+    int32_t nkt, nH, N, nsplit, slot0, nslots, block_begin, pad;
+} ClvDbiasGather;
+int clv_attn_dbias_gather_entry(const ClvAttnGeom* geom_host, void* work, float* dbias, ClvDbiasGather* out);
+int clv_attn_dbias_gather_batch(const ClvDbiasGather* entries, int32_t n, void* stream);
 
 /* ---- unfused attention for long sequences (N > 448 keys: K/V of one (group, head) no longer fit LDS in the
  * kernels above; the fusion encoder at 32 frames has 16*49 + 32 = 816 tokens).  Q.K^T, P.V and their gradients are

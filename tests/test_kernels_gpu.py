@@ -186,6 +186,50 @@ def test_merge_layer_norm(B, D, H, W, C, with_res, with_scale):
         assert xg.grad[0].abs().max().item() == 0.0          # dropped path: no gradient into the branch
 
 
+def test_window_attention_deferred_table_gradient():
+    """ops.defer_folds(): the table-gradient gathers of several window-attention blocks (different geometries, one table
+    used twice) are left pending by their backward calls and run as batched launches when the segment closes
+    (clv_attn_dbias_gather_batch); the sinks end up with what the immediate gathers give."""
+    from clover_amd.backbones.swin_transformer_3d import window_geometry
+    cases = [(2, 4, 14, 14, 64, 2, True), (1, 8, 14, 14, 96, 3, False), (2, 4, 7, 7, 64, 2, False)]
+    inputs = []
+    for i, (B, D, H, W, Cc, nH, shifted) in enumerate(cases):
+        ws, ss, rid = window_geometry((D, H, W), (8, 7, 7), (4, 3, 3) if shifted else (0, 0, 0), DEV)
+        inputs.append((rnd(B, D, H, W, 3 * Cc, seed=610 + i).to(BF).to(DEV), rnd(15 * 13 * 13, nH, scale=0.5, seed=620 + i).to(DEV),
+                       rnd(B, D, H, W, Cc, seed=630 + i).to(BF).to(DEV), rid, ws, ss, nH))
+
+    def run(deferred):
+        sinks, grads = [], []
+        tabs = []
+        for qkv, table, do, rid, ws, ss, nH in inputs:
+            t = table.clone().requires_grad_()
+            t._clv_grad = torch.zeros_like(table)              # an engine-style gradient sink: accumulated in place
+            t._clv_ready = lambda: None
+            tabs.append(t)
+            sinks.append(t._clv_grad)
+
+        def body():
+            for (qkv, table, do, rid, ws, ss, nH), t in zip(inputs, tabs):
+                for rep in range(2):                           # every table takes part in two blocks of the segment
+                    q = qkv.clone().requires_grad_()
+                    ops().window_attention(q, t, rid, ws, ss, nH, table_window=(8, 7, 7)).backward(do)
+                    grads.append(q.grad)
+        if deferred:
+            with ops().defer_folds():
+                body()
+                assert len(ops().DBIAS_DEFER) == 2 * len(inputs)
+        else:
+            body()
+        torch.cuda.synchronize()
+        return sinks, grads
+    s0, g0 = run(False)
+    s1, g1 = run(True)
+    for a, b in zip(s0, s1):
+        assert float(a.abs().max()) > 0 and rel(b, a) < 1e-5, rel(b, a)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('D,N', [(4, 196), (16, 392)])
 def test_window_attention_one_kernel_stage_masks(D, N, monkeypatch):
     """clv_attn_bwd on the one-kernel geometries: `clv_attn_bwd_one_kernel` reports them, the stage masks 5 (dQ / dK / dV
@@ -1217,7 +1261,10 @@ def test_heads_batchnorm_variants():
     ((yr * w).sum() + (tr * w).sum()).backward()
     for own_m, ref_m in ((mm.img_projector, ref_img), (mm.text_projector, ref_txt)):
         for (n, p), (_, q) in zip(own_m.named_parameters(), ref_m.named_parameters()):
-            assert rel(p.grad, q.grad) < 5e-4, (n, rel(p.grad, q.grad))
+            # (the bias of a Linear that feeds a BatchNorm has an exactly-zero gradient — the batch mean is removed — so both
+            # sides hold 1e-6 round-off there: absolute floor)
+            err = float((p.grad.cpu() - q.grad).abs().max())
+            assert err <= 5e-4 * float(q.grad.abs().max()) + 2e-5, (n, err)
         for (n, b_), (_, c_) in zip(own_m.named_buffers(), ref_m.named_buffers()):
             assert rel(b_.float(), c_.float()) < 1e-5, n                # running statistics after two calls, in order
     v = NCEHeadForVision(cross_in_channels=Ct, visual_in_channels=Ct, hidden_dim=32, vts_embed_dim=E, ln=False,
