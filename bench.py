@@ -145,7 +145,11 @@ def cpu_baseline(cfg, state, frames, L, budget_s=25.0):
     if not times:                       # slow host: the warm-up iteration is all the budget allows
         times, note = [warm], 'iter (the warm-up itself; budget exhausted)'
     per = sum(times) / len(times)
+    # kind "port": the oracle restatement, not the reference itself (which cannot travel to the GPU box).  Same cores, same
+    # weights / batch, the two differ by -20 % .. +30 % (oracle / reference speed 0.81-1.15 at these shapes,
+    # 1.28-1.32 at Swin-B / 32 f)
     return dict(value=round(B / per, 4), unit='pairs/s', cores=ncores, kind='port', losses=ref_losses,
+                port_speed_over_reference='0.81-1.15 at config-2 shapes, 1.28-1.32 at Swin-B 32 f (BASELINE.md section 5)',
                 sample=f'oracle forward_train+backward, fp32, B={B}, {frames}f x 224^2, L={L}, '
                        f'{len(times)} {note} ({per:.2f} s/iter)')
 
