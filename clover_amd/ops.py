@@ -326,6 +326,9 @@ def flush_wgrads(pending):
     folds = []
     L = _lib.lib()
     for chunk in wgrad_chunks(pending):
+        if os.environ.get('CLOVER_WGRAD_LOG') == '1':       # probe: the (M, N, K) of every grouped launch
+            print('WGRAD_GROUP', len(chunk), sorted({(c[4], c[5], c[6]): 0 for c in chunk}.keys()),
+                  [(c[4], c[5], c[6]) for c in chunk], flush=True)
         arr = (_lib.ClvWgradEntry * len(chunk))()
         for e, (dy2, x2, dw, db, M, N, K, *_) in zip(arr, chunk):
             e.dy, e.x, e.M, e.N, e.K = dy2.data_ptr(), x2.data_ptr(), M, N, K

@@ -152,6 +152,41 @@ def test_parity_step_losses_vs_reference(model, B):
         assert errs[k] <= PARITY_TOL, (k, lv[k], float(g[f'B{B}.{k}']))
 
 
+def test_parity_isolation_per_rounding_source(model):
+    """tools/parity_isolate.py as a test (ADVICE r3 / VERDICT r4 item 7): parity mode with ONE bf16 rounding source re-injected
+    at a time (activations a kernel writes / the Swin residual stream / GEMM weights / attention probabilities / the clip as
+    patch-embedding operand), config 1, B = 2 and 4, against the reference's own losses.  Claims pinned: (i) plain parity
+    mode holds 1e-3; (ii) every single source stays inside the bf16 path's tolerances (tests/test_step_gpu.py LOSS_TOL);
+    (iii) bf16 activation storage or bf16 weights ALONE already move a contrastive / rank loss past 1e-3 — which is why the
+    shipped bf16 path cannot meet the north-star bound and the fp32 parity mode exists; (iv) all five together land within
+    the bf16 tolerances of the reference, i.e. the emulation accounts for the training path's error."""
+    from clover_amd import parity
+    from test_step_gpu import LOSS_TOL
+    g = gutil.load('g_step.npz')
+    broke = set()
+    for B in (2, 4):
+        batch = {k: v.to(DEV) for k, v in cf.cf_batch(B, tag=f'step{B}').items()}
+        ref = {k: float(g[f'B{B}.{k}']) for k in LOSS_KEYS}
+
+        def errs(rounds):
+            with parity.mode(round=rounds), torch.no_grad():
+                lv = model.train_step(batch, None)['log_vars']
+            return {k: abs(lv[k] - ref[k]) for k in LOSS_KEYS}
+        e0 = errs(())
+        assert max(e0.values()) <= PARITY_TOL, e0
+        for kind in parity.ROUND_KINDS:
+            e = errs((kind,))
+            print('parity +', kind, B, {k: f'{v:.1e}' for k, v in e.items()})
+            for k in LOSS_KEYS:
+                assert e[k] <= LOSS_TOL[k], (kind, k, e[k])
+            if max(e[k] for k in LOSS_KEYS if k != 'mlm_loss') > PARITY_TOL:
+                broke.add(kind)
+        ea = errs(parity.ROUND_KINDS)
+        for k in LOSS_KEYS:
+            assert ea[k] <= LOSS_TOL[k], ('all', k, ea[k])
+    assert {'act', 'weight'} & broke, broke
+
+
 def test_parity_modules_vs_reference(model):
     """Feature maps of the three encoders in parity mode against the reference goldens: 1e-4 of max (the bf16 path
     asserts 2-3e-2 on the same fixtures)."""

@@ -7,10 +7,23 @@ InfoNCE + rank) are checked at 1e-4 .. 1e-3.  The north-star bound on the step l
 tests/test_parity_gpu.py on the fp32 parity mode of the same path (measured 1e-6 .. 8e-6).  THIS file runs the bf16
 training path: every activation is stored in bf16 and every GEMM operand is bf16, and the isolation runs of
 tools/parity_isolate.py (profiles/r03_parity_isolate.json) show that either of those two roundings alone already moves
-the contrastive / rank losses by 2e-3 .. 1e-2 (cosine logits are divided by the temperature 0.05).  LOSS_TOL below is
-what the bf16 path is measured to hold with ~2x margin (round 3: mlm <= 3.3e-3, nce <= 9.6e-3, rank <= 9.6e-3, total
-<= 1.5e-2 over config 1 B = 1, 2, 4 and the config-2 / config-4 shapes); feature maps / gradients are relative to their
-max magnitude as written below."""
+the contrastive / rank losses by 2e-3 .. 1e-2 (cosine logits are divided by the temperature 0.05).  LOSS_TOL below is,
+per key, 1.5 x the largest |loss - reference| this path has been MEASURED at (not the north-star 1e-3: that bound is
+held by the parity mode only); feature maps / gradients are relative to their max magnitude as written below.
+
+Measured |loss - reference| of the bf16 path (round 5 run; "all rounds" adds the maxima rounds 3-4 recorded, bench line
+included — the contrastive terms move by a few 1e-3 between boxes / builds because the loss kernels accumulate atomically):
+
+    workload (reference)                       mlm      nce      rank_t_tm  v_nce    rank_v_vm  total
+    config 1, B = 1 (golden)                   3.0e-3   0        6.7e-3     0        9.5e-3     1.3e-2
+    config 1, B = 2 (golden)                   1.1e-3   3.6e-3   8.4e-3     1.1e-2   1.0e-2     3.4e-3
+    config 1, B = 4 (golden)                   5.8e-4   2.0e-3   8.9e-4     5.7e-3   7.1e-3     2.5e-4
+    Swin-T 8 f full size, B = 2 (oracle)       8.9e-5   4.4e-3   4.7e-3     7.5e-3   1.3e-3     9.2e-3
+    Swin-B 16 f full size, B = 2 (oracle)      1.5e-3   1.7e-3   3.6e-3     1.5e-2   4.8e-4     1.8e-2
+    Swin-B 32 f full size, B = 2 (oracle)      2.0e-3   2.2e-3   6.7e-3     1.9e-3   1.9e-3     1.0e-2
+    max, all rounds                            3.3e-3   9.6e-3   9.6e-3     1.64e-2  1.1e-2     1.84e-2
+    LOSS_TOL = 1.5 x that                      5.0e-3   1.5e-2   1.5e-2     2.5e-2   1.7e-2     2.8e-2
+"""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +34,7 @@ import gutil
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']
-LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=2e-2, rank_t_tm_loss=2e-2, v_nce_loss=2e-2, rank_v_vm_loss=2e-2, loss=3e-2)
+LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=1.5e-2, rank_t_tm_loss=1.5e-2, v_nce_loss=2.5e-2, rank_v_vm_loss=1.7e-2, loss=2.8e-2)
 
 
 def grad_tol(name):
