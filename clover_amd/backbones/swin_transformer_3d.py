@@ -240,9 +240,10 @@ class SwinTransformerBlock3D(nn.Module):
                                     self.norm1.eps)
         o = ops.window_attention(qkv, at.relative_position_bias_table, rid if any(s > 0 for s in ss) else None, ws, ss,
                                  self.num_heads, table_window=at.window_size)
-        a = self.drop_path(at.proj(o))
+        a = at.proj(o)
+        # the branch's DropPath factor rides in the residual add of the LayerNorm + fc1 kernel (and in its backward)
         m, s1 = ops.fused_mlp(a, s0, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
-                              self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps)
+                              self.mlp.fc2.weight, self.mlp.fc2.bias, self.norm2.eps, x_scale=self._dp_scale(a))
         return s1, m, self._dp_scale(m)        # the consumer applies / folds the factor (next LayerNorm or merge)
 
     def forward(self, x, mask_matrix=None):

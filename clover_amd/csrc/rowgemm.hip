@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, bf16_t* __restrict__ sum_out,
     float* __restrict__ mean, float* __restrict__ rstd, bf16_t* __restrict__ xhat_out, const bf16_t* __restrict__ wt,
     const float* __restrict__ bias, const bf16_t* __restrict__ pre_in, bf16_t* __restrict__ y,
-    bf16_t* __restrict__ pre_out, int64_t M, int N, int ldx, int ldy, float eps) {
+    bf16_t* __restrict__ pre_out, int64_t M, int N, int ldx, int ldy, float eps, const float* __restrict__ xscale,
+    int rows_per_sample) {
     using C = RGCfg<KS>;
     constexpr int K = C::K, TN = C::TN, LDW = C::LDW, LDO = C::LDO, NT = TN / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -96,6 +97,8 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
         if (STD || res) {
             float xs[KS * 8];
             float sum = 0.f;
+            // per-sample factor on x (the DropPath factor of the branch whose residual add this prologue performs)
+            const float xsc = (xscale && rv) ? xscale[row / rows_per_sample] : 1.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 Frag8 a, r;
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
                                    : make_uint4(0, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = bf2f(a.h[e]) + bf2f(r.h[e]);
+                    const float v = fmaf(bf2f(a.h[e]), xsc, bf2f(r.h[e]));
                     xs[s * 8 + e] = v;
                     sum += v;
                 }
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 && KS <= 4) ? 6 : 1) rowgemm
 template <int KS, bool STD, int EPI, int NW = RG_WAVES>
 int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out, const void* wt,
               const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int N, int ldx, int ldy,
-              float eps, hipStream_t st) {
+              float eps, hipStream_t st, const float* xscale = nullptr, int rps = 1) {
     using C = RGCfg<KS>;
     constexpr int NST = (EPI == EPI_NONE) ? 1 : 2;
     const size_t lds = (size_t)C::TN * C::LDW * 2 + (size_t)NW * NST * 16 * C::LDO * 2 + (size_t)C::TN * 4;
@@ -217,10 +220,10 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
         if (wbytes >= 48 * 1024) {
             if ((wv == 12 || (KS <= 8 && wv >= 8)) && wbytes + 12 * per_wave <= 160 * 1024)
                 return launch_rg<KS, STD, EPI, 12>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
-                                                   ldy, eps, st);
+                                                   ldy, eps, st, xscale, rps);
             if (wv >= 8 && wbytes + 8 * per_wave <= 160 * 1024)
                 return launch_rg<KS, STD, EPI, 8>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx,
-                                                  ldy, eps, st);
+                                                  ldy, eps, st, xscale, rps);
         }
     }
     // K <= 128 with the GELU' epilogue (fc1's input gradient at stage 0) or the LayerNorm prologue (qkv, fc1): 8-wave
@@ -230,7 +233,7 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
         static const int w3 = getenv("CLV_RG_WAVES3") ? atoi(getenv("CLV_RG_WAVES3")) : 8;
         if (w3 == 8)
             return launch_rg<KS, STD, EPI, 8>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy,
-                                              eps, st);
+                                              eps, st, xscale, rps);
     }
     static bool attr = false;
     if (!attr) {
@@ -258,15 +261,15 @@ int launch_rg(const void* x, const void* res, void* sum_out, float* mean, float*
     if (gx > row_blocks) gx = row_blocks;
     rowgemm_kernel<KS, STD, EPI, NW><<<dim3((unsigned)(gx * ny)), dim3(64 * NW), lds, st>>>(
         (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)sum_out, mean, rstd, (bf16_t*)xhat_out, (const bf16_t*)wt, bias,
-        (const bf16_t*)pre_in, (bf16_t*)y, (bf16_t*)pre_out, M, N, ldx, ldy, eps);
+        (const bf16_t*)pre_in, (bf16_t*)y, (bf16_t*)pre_out, M, N, ldx, ldy, eps, xscale, rps > 0 ? rps : 1);
     return clv_check_launch();
 }
 
 template <int KS>
 int dispatch_rg(bool stdz, int epi, const void* x, const void* res, void* sum_out, float* mean, float* rstd,
                 void* xhat_out, const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int N,
-                int ldx, int ldy, float eps, hipStream_t st) {
-#define RG_CALL(S, E) launch_rg<KS, S, E>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st)
+                int ldx, int ldy, float eps, hipStream_t st, const float* xscale, int rps) {
+#define RG_CALL(S, E) launch_rg<KS, S, E>(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st, xscale, rps)
     if (stdz) {
         if constexpr (KS <= 8) {                            // standardisation keeps the fp32 row in registers
             if (epi == EPI_NONE) return RG_CALL(true, EPI_NONE);
@@ -293,11 +296,10 @@ extern "C" int clv_rowgemm_supported(int32_t N, int32_t K, int32_t standardise) 
     return 1;
 }
 
-extern "C" int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
-                           const void* wt,
-                           const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
-                           int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
-                           void* stream) {
+static int rowgemm_impl(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
+                        const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+                        int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
+                        const float* xscale, int32_t rows_per_sample, void* stream) {
     if (!x || !wt || !y || M <= 0 || !clv_rowgemm_supported(N, K, standardise) || (ldx & 7) || (ldy & 7) || ldx < K ||
         ldy < N)
         return CLV_ERR_ARG;
@@ -306,12 +308,30 @@ extern "C" int clv_rowgemm(const void* x, const void* res, void* sum_out, float*
     if (epilogue == EPI_GELU && !pre_out) return CLV_ERR_ARG;
     if (epilogue == EPI_GELU_BWD && !pre_in) return CLV_ERR_ARG;
     if (res && !standardise) return CLV_ERR_UNSUPPORTED;
+    if (xscale && (!res || rows_per_sample <= 0)) return CLV_ERR_ARG;       // the factor belongs to the residual-add prologue
     hipStream_t st = (hipStream_t)stream;
     const bool sz = standardise != 0;
-#define RG_KS(V) case V: return dispatch_rg<V>(sz, epilogue, x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st)
+#define RG_KS(V) case V: return dispatch_rg<V>(sz, epilogue, x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, ldx, ldy, eps, st, xscale, rows_per_sample)
     switch (K / 32) {
         RG_KS(3); RG_KS(4); RG_KS(6); RG_KS(8); RG_KS(9); RG_KS(12); RG_KS(16); RG_KS(18); RG_KS(24);
         default: return CLV_ERR_UNSUPPORTED;
     }
 #undef RG_KS
+}
+
+extern "C" int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
+                           const void* wt,
+                           const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+                           int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
+                           void* stream) {
+    return rowgemm_impl(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, K, ldx, ldy, standardise,
+                        epilogue, eps, nullptr, 1, stream);
+}
+
+extern "C" int clv_rowgemm_xs(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
+                              const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M,
+                              int32_t N, int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue,
+                              float eps, const float* xscale, int32_t rows_per_sample, void* stream) {
+    return rowgemm_impl(x, res, sum_out, mean, rstd, xhat_out, wt, bias, pre_in, y, pre_out, M, N, K, ldx, ldy, standardise,
+                        epilogue, eps, xscale, rows_per_sample, stream);
 }

@@ -691,7 +691,7 @@ def _raw_bf16(w):
     return wb if wb is not None else w.detach().to(BF16)
 
 
-def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum, gamma=None):
+def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum, gamma=None, xscale=None, rows_per_sample=1):
     """dx = LayerNorm-backward of dxhat w.r.t. x for the affine-free standardisation (+ dsum).  gamma: dxhat is the
     gradient w.r.t. the AFFINE output (taken through the raw, un-folded weight): the kernel applies gamma itself —
     d xhat = (dy W) * gamma == dy (W * gamma), so the backward needs no transpose of the folded weight."""
@@ -713,12 +713,16 @@ def _ln_bwd_noaffine(dxhat, x, mean, rstd, dsum, gamma=None):
         ds2 = _c(dsum).view(rows, C_)
         if ds2.dtype != BF16:
             ds2 = ds2.to(BF16)
-    ex = _lib.ClvLnExtra(None, 1, 0.0, None, None, None, 0, 0, 0, 0, 0)
+    # xscale: x is the saved SUM t = xscale * a + r (x_is_sum); dx then receives d t times the factor (the gradient of a)
+    # and dres d t itself (the gradient of r) — both from the one kernel
+    dres = torch.empty_like(x) if xscale is not None else None
+    ex = _lib.ClvLnExtra(_ptr(xscale), int(rows_per_sample), 0.0, None, None, _ptr(dres), 1 if xscale is not None else 0,
+                         0, 0, 0, 0)
     ex.no_reduce = 1                        # nobody reads dgamma / dbeta of the affine-free norm: skip their reduction launch
     check(L.clv_layernorm_bwd(_ptr(dxhat), _ptr(x), _ptr(None), _ptr(ones), _ptr(mean), _ptr(rstd), _ptr(ds2),
                               _ptr(dx), _ptr(junk), C.c_void_p(junk.data_ptr() + 4 * C_), _ptr(partial), rows, C_, 0,
                               C.byref(ex), _stream()), 'clv_layernorm_bwd')
-    return dx
+    return dx if xscale is None else (dx, dres)
 
 
 def fold_layernorm(weight, bias, gamma, beta):
@@ -835,13 +839,21 @@ class _FusedMLP(torch.autograd.Function):
     backward with the residual-path gradient folded in (swin_transformer_3d.py:482-483,262-268,503)."""
 
     @staticmethod
-    def forward(ctx, a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps):
+    def forward(ctx, a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps, x_scale=None):
         _need_gpu(a, w1)
         K = a.shape[-1]
         a2 = _c(a).view(-1, K)
         r2 = _c(r).view(-1, K) if r is not None else None
         wt1, bf1 = fold_layernorm(w1, b1, ln_weight, ln_bias)
-        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps, want_xhat=any(ctx.needs_input_grad))
+        # x_scale fp32 [B]: the per-sample DropPath factor of the branch a — folded into the residual add of the kernel's
+        # prologue (t = x_scale * a + r) and, in the backward, into the LayerNorm-backward kernel (round 5: the block
+        # multiplied a 19 M-element tensor by it with an elementwise pass each way, 2 x 18 us on the critical path)
+        assert x_scale is None or r is not None
+        xsc = _c(x_scale.detach().float()) if x_scale is not None else None
+        rps = a2.shape[0] // a.shape[0]
+        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps, want_xhat=any(ctx.needs_input_grad),
+                     xscale=xsc, rows_per_sample=rps)
+        ctx.xsc, ctx.rps = xsc, rps
         xs = o1['sum'] if r is not None else a2
         w2b = getattr(w2, '_clv_shadow', None)
         if w2b is None:
@@ -897,14 +909,19 @@ class _FusedMLP(torch.autograd.Function):
         # fc1 + LayerNorm
         w1, b1, gamma, beta = ctx.prefs
         dxhat = linear_dgrad(dpre, _raw_bf16(w1), w1)
-        dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma).view(ctx.shape)
+        if ctx.xsc is not None:
+            dx, dr = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma, xscale=ctx.xsc, rows_per_sample=ctx.rps)
+            dx, dr = dx.view(ctx.shape), dr.view(ctx.shape)
+        else:
+            dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma).view(ctx.shape)
+            dr = dx
         dw1, db1, dg, dbt = _wgrad_folded(dpre, xhat, xs, mean, rstd, w1, b1, gamma, beta)
-        return dx, (dx if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None
+        return dx, (dr if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None, None
 
 
-def fused_mlp(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps=1e-5):
-    """out = fc2(GELU(fc1(LayerNorm(a [+ r])))), s = a + r."""
-    return _FusedMLP.apply(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps)
+def fused_mlp(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps=1e-5, x_scale=None):
+    """out = fc2(GELU(fc1(LayerNorm(x_scale * a [+ r])))), s = x_scale * a + r (x_scale fp32 [B] per sample, or None)."""
+    return _FusedMLP.apply(a, r, ln_weight, ln_bias, w1, b1, w2, b2, eps, x_scale)
 
 
 def fused_block_supported(C_, hidden):
@@ -1091,8 +1108,10 @@ def rowgemm_supported(N, K, standardise=False):
     return bool(_lib.lib().clv_rowgemm_supported(int(N), int(K), int(bool(standardise))))
 
 
-def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=None, eps=1e-5, want_xhat=False):
+def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=None, eps=1e-5, want_xhat=False,
+            xscale=None, rows_per_sample=1):
     """Raw launcher of clv_rowgemm (no autograd).  x bf16 [M,K]; wt bf16 [N,K]; bias fp32 [N] | None.
+    xscale fp32 [M / rows_per_sample]: per-sample factor on x inside the residual-add prologue (x * xscale + res).
     Returns dict(y, sum, mean, rstd, pre) (entries None when not produced)."""
     _need_gpu(x, wt)
     M, K = x.shape
@@ -1105,9 +1124,15 @@ def rowgemm(x, wt, bias=None, res=None, standardise=False, epilogue=0, pre_in=No
     pre = torch.empty_like(y) if epilogue == 1 else None
     bf = _c(bias.float()) if bias is not None else None
     xhat = torch.empty_like(x) if (want_xhat and standardise and os.environ.get('CLOVER_XHAT', '1') == '1') else None
-    check(_lib.lib().clv_rowgemm(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(xhat), _ptr(wt), _ptr(bf),
-                                 _ptr(pre_in), _ptr(y), _ptr(pre), M, N, K, x.stride(0), N, int(bool(standardise)),
-                                 int(epilogue), float(eps), _stream()), 'clv_rowgemm')
+    if xscale is not None:
+        check(_lib.lib().clv_rowgemm_xs(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(xhat), _ptr(wt), _ptr(bf),
+                                        _ptr(pre_in), _ptr(y), _ptr(pre), M, N, K, x.stride(0), N, int(bool(standardise)),
+                                        int(epilogue), float(eps), _ptr(xscale), int(rows_per_sample), _stream()),
+              'clv_rowgemm_xs')
+    else:
+        check(_lib.lib().clv_rowgemm(_ptr(x), _ptr(res), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(xhat), _ptr(wt), _ptr(bf),
+                                     _ptr(pre_in), _ptr(y), _ptr(pre), M, N, K, x.stride(0), N, int(bool(standardise)),
+                                     int(epilogue), float(eps), _stream()), 'clv_rowgemm')
     return dict(y=y, sum=ssum, mean=mean, rstd=rstd, pre=pre, xhat=xhat)
 
 

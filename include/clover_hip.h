@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 11
+#define CLV_ABI_VERSION 12
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -318,6 +318,13 @@ int clv_rowgemm(const void* x, const void* res, void* sum_out, float* mean, floa
                 const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
                 int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
                 void* stream);
+/* The same with a per-sample factor on X inside the residual-add prologue: x = xscale[row / rows_per_sample] * X + res — the
+ * DropPath factor of the attention branch whose residual add (swin_transformer_3d.py:498) the LayerNorm + fc1 kernel performs
+ * (res required).  Round 5: the stage-0 block multiplied the branch by its factor with an elementwise pass each way. */
+int clv_rowgemm_xs(const void* x, const void* res, void* sum_out, float* mean, float* rstd, void* xhat_out,
+                   const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
+                   int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
+                   const float* xscale, int32_t rows_per_sample, void* stream);
 
 /* db[n] += sum_m dy[m][n] (bf16 dy, row stride ld; N, ld multiples of 8): the bias gradient of the
  * library-GEMM Linear layers (BERT / fusion / MLM head), ACCUMULATED into db. */

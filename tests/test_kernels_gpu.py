@@ -1132,6 +1132,34 @@ def test_fused_ln_linear_and_mlp(C, with_res):
         assert rel(gp[k], gp_ref[k]) < 3e-2, (k, rel(gp[k], gp_ref[k]))
 
 
+@pytest.mark.parametrize('C', [96, 128])
+def test_fused_mlp_with_drop_path_factor(C):
+    """fused_mlp(x_scale=...): the per-sample DropPath factor of the attention branch inside the residual add of the
+    LayerNorm + fc1 kernel (t = factor[b] * a + r) and inside its backward (d a = factor[b] * d t, d r = d t) — against the
+    plain fp32 composition; a dropped sample (factor 0) gets no gradient into its branch."""
+    B, rows_per, Hd = 4, 700, 4 * C
+    a, r = rnd(B, rows_per, C, seed=141).to(BF), rnd(B, rows_per, C, seed=142).to(BF)
+    sc = torch.tensor([1.25, 0.0, 1.25, 1.25])
+    P = dict(g=1 + 0.1 * rnd(C, seed=143), b=0.1 * rnd(C, seed=144), w1=rnd(Hd, C, scale=0.1, seed=145),
+             b1=0.1 * rnd(Hd, seed=146), w2=rnd(C, Hd, scale=0.05, seed=147), b2=0.1 * rnd(C, seed=148))
+    dm, ds = rnd(B, rows_per, C, seed=149).to(BF), rnd(B, rows_per, C, seed=150).to(BF)
+    ar, rr = a.float().requires_grad_(), r.float().requires_grad_()
+    Q = {k: v.clone().requires_grad_() for k, v in P.items()}
+    t = ar * sc.view(B, 1, 1) + rr
+    y = F.layer_norm(t, (C,), Q['g'], Q['b'], 1e-5)
+    m_ref = F.linear(om.gelu(F.linear(y, Q['w1'], Q['b1'])), Q['w2'], Q['b2'])
+    torch.autograd.backward([m_ref, t], [dm.float(), ds.float()])
+    ag, rg = a.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+    G = {k: v.to(DEV).clone().requires_grad_() for k, v in P.items()}
+    m, s2 = ops().fused_mlp(ag, rg, G['g'], G['b'], G['w1'], G['b1'], G['w2'], G['b2'], x_scale=sc.to(DEV))
+    torch.autograd.backward([m, s2], [dm.to(DEV), ds.to(DEV)])
+    assert rel(m, m_ref) < 2e-2 and rel(s2, t) < 1e-2
+    assert rel(ag.grad, ar.grad) < 3e-2 and rel(rg.grad, rr.grad) < 3e-2
+    assert float(ag.grad[1].abs().max()) == 0.0
+    for k in P:
+        assert rel(G[k].grad, Q[k].grad) < 3e-2, (k, rel(G[k].grad, Q[k].grad))
+
+
 def test_gemm_nt_gelu_grad_epilogues():
     """CLV_GEMM_EPI_BIAS_GELU_D (c2 = GELU'(pre)) and CLV_GEMM_EPI_MUL (c = acc * aux): the pair that keeps the GELU
     backward free of transcendentals, against torch fp32."""
