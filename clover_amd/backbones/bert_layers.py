@@ -252,7 +252,8 @@ class BertModel(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None):
         kmask = extended_attention_mask(attention_mask)
-        h = self.encoder(self.embeddings(input_ids), kmask)
+        # flush_point: the encoder's backward ends here — its deferred weight gradients leave on the stream it ran on
+        h = self.encoder(ops.flush_point(self.embeddings(input_ids)), kmask)
         return {'last_hidden_state': h}
 
 

@@ -220,7 +220,8 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         if WGRAD_DEFER is not None and sink and xstats is None:
             # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
             # backward segment (dy2 / x2 stay alive in the list until then)
-            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K, 1 if ow else 0))
+            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K, 1 if ow else 0,
+                                torch.cuda.current_stream().cuda_stream))
             return None, None
         if ow:
             dw_out.zero_()                     # the stand-alone launches only accumulate
@@ -292,6 +293,7 @@ class defer_folds:
         pending_wg, WGRAD_DEFER = WGRAD_DEFER, self.prev_wg
         pending_post, POST_DEFER = POST_DEFER, self.prev_post
         if exc[0] is None:
+            join_aux_streams()
             pending = pending + flush_wgrads(pending_wg or [])
             flush_folds(pending)
             for fn in pending_post:
@@ -299,6 +301,80 @@ class defer_folds:
             flush_ln_reduces(pending_ln or [])
             flush_dbias_gathers(pending_db or [])
         return False
+
+
+_AUX_STREAMS = {}           # device index -> auxiliary stream of flush_stream_wgrads(aux=True)
+_AUX_HOLD = []              # (stream, flushed items, their fold entries): alive until the calling stream has joined it
+
+
+def flush_stream_wgrads(aux=False):
+    """Launch NOW the deferred weight gradients that were queued from the current stream (and the folds of their
+    partials), leaving the others pending.
+    aux=False: on the current stream.  The text tower's backward runs on a side stream beside the video tower's: at its end
+    (`flush_point` on the embedding output) its 48 few-row weight gradients go out there, under the rest of the video
+    backward, instead of as the last grouped launch of the step on the main stream.
+    aux=True: on an auxiliary stream that forks from the current one here and is joined when the backward segment closes
+    (`join_aux_streams`): the heads' / fusion encoder's weight gradients, complete when the fusion backward ends, run under
+    the video tower's backward.  Everything they read or write stays referenced until the join."""
+    global WGRAD_DEFER
+    if WGRAD_DEFER is None or not WGRAD_DEFER:
+        return
+    cur_s = torch.cuda.current_stream()
+    cur = cur_s.cuda_stream
+    mine = [it for it in WGRAD_DEFER if len(it) > 8 and it[8] == cur]
+    if not mine:
+        return
+    WGRAD_DEFER[:] = [it for it in WGRAD_DEFER if not (len(it) > 8 and it[8] == cur)]
+    if not aux:
+        folds = flush_wgrads(mine)
+        if folds:
+            flush_folds(folds)
+        return
+    dev = mine[0][0].device
+    st = _AUX_STREAMS.get(dev.index)
+    if st is None:
+        st = _AUX_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    st.wait_stream(cur_s)
+    with torch.cuda.stream(st):
+        folds = flush_wgrads(mine)
+        if folds:
+            flush_folds(folds)
+    _AUX_HOLD.append((st, mine, folds))
+
+
+def join_aux_streams():
+    """The current stream waits for every auxiliary flush of this backward segment; their operands may be released then."""
+    if _AUX_HOLD:
+        cur = torch.cuda.current_stream()
+        for st, _, _ in _AUX_HOLD:
+            cur.wait_stream(st)
+        del _AUX_HOLD[:]
+
+
+class _FlushPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, aux):
+        ctx.aux = aux
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_stream_wgrads(ctx.aux)
+        return g, None
+
+
+def flush_point(x, aux=False):
+    """Identity whose backward flushes the deferred weight gradients of the stream it runs on (see flush_stream_wgrads)."""
+    on = WGRAD_FLUSH_AUX if aux else WGRAD_FLUSH_POINTS
+    if on and x.requires_grad and x.is_cuda:
+        return _FlushPoint.apply(x, bool(aux))
+    return x
+
+
+# (off by default: same-box 11.09 / 11.16 -> 11.28 / 11.33 ms — MFMA-heavy grouped launches beside the video chain take
+# the CUs and the HBM that chain is bound by, as the early video launches of round 4 did)
+WGRAD_FLUSH_AUX = os.environ.get('CLOVER_FUSION_WGRAD_AUX', '0') == '1'
+WGRAD_FLUSH_POINTS = os.environ.get('CLOVER_TEXT_WGRAD_SIDE', '1') == '1'
 
 
 def wgrad_chunks(pending):

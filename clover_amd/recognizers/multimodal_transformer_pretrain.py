@@ -158,7 +158,9 @@ class CloverPretrain(BaseRecognizer):
             for v_ in fusion_prep.values():
                 if torch.is_tensor(v_):
                     v_.record_stream(main)
-        fusion = self.multimodal_backbone(visual_token=vis_both.reshape(2 * B, T, h * w, D),
+        # flush_point(aux): the fusion encoder's backward ends at its visual input — the weight gradients of the heads and of
+        # the fusion encoder, complete by then, leave on an auxiliary stream under the video tower's backward
+        fusion = self.multimodal_backbone(visual_token=ops.flush_point(vis_both.reshape(2 * B, T, h * w, D), aux=True),
                                           text_input_mask=text_mask2, text_input_embeds=text_out,
                                           prepared=fusion_prep if side is not None else None)
         t_all = fusion['t_last_hidden_state']
