@@ -12,7 +12,12 @@ if os.environ.get('CLOVER_FORCE_COLLECTIVES') == '1':
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
 torch.manual_seed(1234)
-model = clover_amd.build_model(bench.model_cfg('T', 8)).to(dev); model.train()
+cfg = bench.model_cfg('T', 8)
+if os.environ.get('TEXT_LAYERS'):          # diagnostic only: is the text tower (side stream) on the critical path of a phase?
+    cfg['text_backbone']['num_hidden_layers'] = int(os.environ['TEXT_LAYERS'])
+if os.environ.get('SWIN_DEPTH2'):          # ... or the video tower: depth of Swin stage 2
+    cfg['backbone']['depths'][2] = int(os.environ['SWIN_DEPTH2'])
+model = clover_amd.build_model(cfg).to(dev); model.train()
 batch = {k: v.to(dev) for k, v in bench.synthetic_batch(8, 8, 32, 1000).items()}
 eng = CloverEngine(model, batch, lr=1e-5, weight_decay=0.005, grad_clip=15.0, max_iters=100000)
 eng.step(batch); eng.capture(batch)
