@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -105,6 +105,8 @@ SIGNATURES = {
     'clv_infonce_work_floats': (C.c_int64, [_i32, _i32]),
     'clv_infonce_fwd': (C.c_int, [_p] * 6 + [_i32, _i32, _i32, _f, _f, _p]),
     'clv_infonce_bwd': (C.c_int, [_p] * 10 + [_i32, _i32, _i32, _f, _f, _p]),
+    'clv_infonce_pair_fwd': (C.c_int, [_p] * 4 + [_i32, _i32, _i32, _f, _f, _p]),
+    'clv_infonce_pair_bwd': (C.c_int, [_p] * 4 + [_i32, _i32, _i32, _f, _f, _p]),
     'clv_normsoftmax_work_floats': (C.c_int64, [_i32, _i32]),
     'clv_normsoftmax_fwd': (C.c_int, [_p] * 5 + [_i32, _i32, _f, _f, _p]),
     'clv_normsoftmax_bwd': (C.c_int, [_p] * 6 + [_i32, _i32, _f, _p]),
@@ -132,6 +134,7 @@ SIGNATURES = {
     'clv_sumsq_bf16': (C.c_int, [_p, _p, _i64, _p]),
     'clv_adamw_step_dev_bf16g': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
     'clv_sgemm_strided': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _p]),
+    'clv_sgemm_strided_rowsum': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _p]),
     'clv_sgemm_nt': (C.c_int, [_p] * 4 + [_i64, _i32, _i32, _i64, _i64, _i64, _p]),
     'clv_attn_f32_fwd': (C.c_int, [_p] * 7 + [C.POINTER(ClvAttnGeom), _i32, _p]),
     'clv_attn_f32_bwd_work_floats': (C.c_int64, [C.POINTER(ClvAttnGeom)]),

@@ -199,8 +199,8 @@ __host__ __device__ inline NceWork nce_carve(float* w, int G, int Dm) {
 }
 
 // one wave per row: en = e / max(|e|, 1e-8)   (cos_norm, contrastive_loss.py:20-25)
-__global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, const float* e1, const float* e2,
-                                                            const float* e3, NceWork W, int G, int Dm, int ld) {
+__device__ __forceinline__ void nce_normalize_body(const float* e0, const float* e1, const float* e2, const float* e3,
+                                                   const NceWork& W, int G, int Dm, int ld) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 4 * G) return;
@@ -217,16 +217,38 @@ __global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, con
         W.enT[((int64_t)d * 4 + k) * G + i] = v;
     }
 }
+__global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, const float* e1, const float* e2,
+                                                            const float* e3, NceWork W, int G, int Dm, int ld) {
+    nce_normalize_body(e0, e1, e2, e3, W, G, Dm, ld);
+}
+
+// The recognizer evaluates the loss TWICE per step on slots of one packed [G, k, Dm] tensor (video -> text and text -> video,
+// multimodal_transformer_pretrain.py:151,161): the *_pair kernels run both evaluations ("directions") in the same launches —
+// blockIdx.y (or the batch index of the GEMMs) is the direction, each with its own work area — so that the loss section
+// is 3 + 4 dependent launches instead of 6 + 8 (+ the zero fills and the add of the two gradients).
+struct NcePair {
+    NceWork w[2];
+    const float* e[2][4];
+    int slot[2][4];
+};
+__global__ void __launch_bounds__(256) nce_pair_normalize_kernel(NcePair P, int G, int Dm, int ld) {
+    const int d = blockIdx.y;
+    nce_normalize_body(P.e[d][0], P.e[d][1], P.e[d][2], P.e[d][3], P.w[d], G, Dm, ld);
+}
 
 // C[i][j] (ldc) = alpha * sum_k A[i][k] * B[j][k]   — exact-f32 MFMA 16x16x4, one wave per
 // 16x16 tile.  K multiple of 16 is NOT required (tail guarded); rows/cols guarded.
 __global__ void __launch_bounds__(64) sgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int M, int N, int K, int lda, int ldb,
-                                                      int ldc, int64_t sA, int64_t sB, int64_t sC, float alpha) {
+                                                      int ldc, int64_t sA, int64_t sB, int64_t sC, float alpha,
+                                                      int zb, int64_t s2) {
+    // batch index z = z1 * zb + z0: operand offsets (sA, sB, sC) * z0 + s2 * z1 (the pair form: z1 = direction, one work
+    // area of s2 floats each)
     const int lane = threadIdx.x, lg = lane >> 4, lr = lane & 15;
-    A += sA * blockIdx.z;
-    B += sB * blockIdx.z;
-    C += sC * blockIdx.z;
+    const int z1 = blockIdx.z / zb, z0 = blockIdx.z - z1 * zb;
+    A += sA * z0 + s2 * z1;
+    B += sB * z0 + s2 * z1;
+    C += sC * z0 + s2 * z1;
     const int i = blockIdx.y * 16 + lr, j = blockIdx.x * 16 + lr;
     const float* ap = A + (int64_t)(i < M ? i : 0) * lda;
     const float* bp = B + (int64_t)(j < N ? j : 0) * ldb;
@@ -260,7 +282,7 @@ __device__ __forceinline__ float nce_entry(const float* sim, int G, int kx, int 
 }
 
 // single block: all log-sum-exps, the two losses.
-__global__ void __launch_bounds__(1024) nce_loss_kernel(NceWork W, float* __restrict__ out, int G, float margin) {
+__device__ __forceinline__ void nce_loss_body(const NceWork& W, float* __restrict__ out, int G, float margin) {
     __shared__ float sh[16];
     const float* sim = W.sim;
     float part_v = 0.f, part_t = 0.f, part_r = 0.f;
@@ -302,9 +324,15 @@ __global__ void __launch_bounds__(1024) nce_loss_kernel(NceWork W, float* __rest
         out[1] = sr / (float)G;
     }
 }
+__global__ void __launch_bounds__(1024) nce_loss_kernel(NceWork W, float* __restrict__ out, int G, float margin) {
+    nce_loss_body(W, out, G, margin);
+}
+__global__ void __launch_bounds__(1024) nce_pair_loss_kernel(NcePair P, float* __restrict__ out, int G, float margin) {
+    nce_loss_body(P.w[blockIdx.x], out + 2 * blockIdx.x, G, margin);
+}
 
 // elementwise: d loss / d sim[k][i][j]
-__global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* __restrict__ dout, int G, float margin) {
+__device__ __forceinline__ void nce_dsim_body(const NceWork& W, const float* __restrict__ dout, int G, float margin) {
     const int64_t total = (int64_t)3 * G * G;
     const float gn = dout[0], gr = dout[1];
     const float invG = 1.0f / (float)G, inv3G = 1.0f / (float)(3 * G);
@@ -331,6 +359,12 @@ __global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* _
         W.dsimT[((int64_t)k * G + j) * G + i] = g;
     }
 }
+__global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* __restrict__ dout, int G, float margin) {
+    nce_dsim_body(W, dout, G, margin);
+}
+__global__ void __launch_bounds__(256) nce_pair_dsim_kernel(NcePair P, const float* __restrict__ dout, int G, float margin) {
+    nce_dsim_body(P.w[blockIdx.y], dout + 2 * blockIdx.y, G, margin);
+}
 
 // d e = invn * (d en - en * <en, d en>)   (valid while |e| >= eps; below eps: d e = d en * invn)
 __global__ void __launch_bounds__(256) nce_norm_bwd_kernel(NceWork W, float* d0, float* d1, float* d2, float* d3,
@@ -348,6 +382,45 @@ __global__ void __launch_bounds__(256) nce_norm_bwd_kernel(NceWork W, float* d0,
     const float inv = W.invn[row];
     const bool clamped = inv >= 1e8f;
     for (int c = lane; c < Dm; c += 64) d[c] = clamped ? de[c] * inv : inv * (de[c] - en[c] * s);
+}
+
+// The pair form writes the WHOLE packed gradient [G][k][Dm]: one wave per (row i, slot s) sums d en over the (direction,
+// position) pairs that read slot s (video and text are read by both directions; the map d e = invn (d en - en <en, d en>) is
+// linear in d en and en / invn of a slot are the same numbers in both work areas), a slot nobody read gets zeros.
+__global__ void __launch_bounds__(256) nce_pair_norm_bwd_kernel(NcePair P, float* __restrict__ dp, int G, int k, int Dm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= k * G) return;
+    const int i = row / k, sl = row - i * k;
+    float* d = dp + (int64_t)row * Dm;
+    const float* en = nullptr;
+    const float* de[2] = {nullptr, nullptr};
+    float inv = 0.f;
+    int n = 0;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (P.slot[dir][q] == sl && n < 2) {
+                const int64_t r = (int64_t)q * G + i;
+                if (!n) {
+                    en = P.w[dir].en + r * Dm;
+                    inv = P.w[dir].invn[r];
+                }
+                de[n++] = P.w[dir].den + r * Dm;
+            }
+    if (!n) {
+        for (int c = lane; c < Dm; c += 64) d[c] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int c = lane; c < Dm; c += 64) s += en[c] * (de[0][c] + (n > 1 ? de[1][c] : 0.f));
+    s = wave_sum(s);
+    const bool clamped = inv >= 1e8f;
+    for (int c = lane; c < Dm; c += 64) {
+        const float g = de[0][c] + (n > 1 ? de[1][c] : 0.f);
+        d[c] = clamped ? g * inv : inv * (g - en[c] * s);
+    }
 }
 
 
@@ -525,9 +598,10 @@ extern "C" int clv_focal_ce_bwd_ld(const void* logits, int32_t is_bf16, const in
 extern "C" int64_t clv_infonce_work_floats(int32_t G, int32_t Dm) { return nce_work_floats(G, Dm); }
 
 static int nce_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                    int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st) {
-    hipLaunchKernelGGL(sgemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16, batch), dim3(64), 0, st, A, B, C, M, N, K,
-                       lda, ldb, ldc, sA, sB, sC, alpha);
+                    int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st, int outer = 1,
+                    int64_t s2 = 0) {
+    hipLaunchKernelGGL(sgemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16, batch * outer), dim3(64), 0, st, A, B, C, M, N,
+                       K, lda, ldb, ldc, sA, sB, sC, alpha, batch, s2);
     return clv_check_launch();
 }
 
@@ -572,6 +646,65 @@ extern "C" int clv_infonce_bwd(const float* e0, const float* e1, const float* e2
     if (rc) return rc;
     hipLaunchKernelGGL(nce_norm_bwd_kernel, dim3((4 * G + 3) / 4), dim3(256), 0, st, W, d0, d1, d2, d3, (int)G, (int)Dm,
                        (int)ldd);
+    return clv_check_launch();
+}
+
+static bool nce_pair_setup(NcePair& P, const float* packed, float* work, const int32_t* slots, int G, int k, int Dm) {
+    const int64_t ws = nce_work_floats(G, Dm);
+    for (int d = 0; d < 2; ++d) {
+        P.w[d] = nce_carve(work + d * ws, G, Dm);
+        for (int q = 0; q < 4; ++q) {
+            const int sl = slots[d * 4 + q];
+            if (sl < 0 || sl >= k) return false;
+            for (int r = 0; r < q; ++r)
+                if (slots[d * 4 + r] == sl) return false;               // the four slots of a direction are distinct
+            P.slot[d][q] = sl;
+            P.e[d][q] = packed ? packed + (int64_t)sl * Dm : nullptr;
+        }
+    }
+    return true;
+}
+
+extern "C" int clv_infonce_pair_fwd(const float* packed, const int32_t* slots, float* out, float* work, int32_t G,
+                                    int32_t k, int32_t Dm, float temperature, float margin, void* stream) {
+    if (!packed || !slots || !out || !work || G <= 0 || k < 4 || Dm <= 0 || temperature <= 0.f) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NcePair P;
+    if (!nce_pair_setup(P, packed, work, slots, G, k, Dm)) return CLV_ERR_ARG;
+    const int64_t ws = nce_work_floats(G, Dm);
+    hipLaunchKernelGGL(nce_pair_normalize_kernel, dim3((4 * G + 3) / 4, 2), dim3(256), 0, st, P, (int)G, (int)Dm,
+                       (int)(k * Dm));
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    rc = nce_gemm(P.w[0].en, P.w[0].en + (int64_t)G * Dm, P.w[0].sim, G, G, Dm, Dm, Dm, G, 3, 0, (int64_t)G * Dm,
+                  (int64_t)G * G, 1.0f / temperature, st, 2, ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_pair_loss_kernel, dim3(2), dim3(1024), 0, st, P, out, (int)G, margin);
+    return clv_check_launch();
+}
+
+extern "C" int clv_infonce_pair_bwd(const float* dout, const float* work, const int32_t* slots, float* dpacked,
+                                    int32_t G, int32_t k, int32_t Dm, float temperature, float margin, void* stream) {
+    if (!dout || !work || !slots || !dpacked || G <= 0 || k < 4 || Dm <= 0 || temperature <= 0.f) return CLV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NcePair P;
+    if (!nce_pair_setup(P, nullptr, const_cast<float*>(work), slots, G, k, Dm)) return CLV_ERR_ARG;
+    const int64_t ws = nce_work_floats(G, Dm);
+    int64_t total = (int64_t)3 * G * G;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(nce_pair_dsim_kernel, dim3(grid, 2), dim3(256), 0, st, P, dout, (int)G, margin);
+    int rc = clv_check_launch();
+    if (rc) return rc;
+    const float it = 1.0f / temperature;
+    const NceWork& W = P.w[0];
+    rc = nce_gemm(W.dsim, W.enT + G, W.den, G, Dm, 3 * G, 3 * G, 4 * G, Dm, 1, 0, 0, 0, it, st, 2, ws);
+    if (rc) return rc;
+    rc = nce_gemm(W.dsimT, W.enT, W.den + (int64_t)G * Dm, G, Dm, G, G, 4 * G, Dm, 3, (int64_t)G * G, 0,
+                  (int64_t)G * Dm, it, st, 2, ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_pair_norm_bwd_kernel, dim3((k * G + 3) / 4), dim3(256), 0, st, P, dpacked, (int)G, (int)k,
+                       (int)Dm);
     return clv_check_launch();
 }
 

@@ -89,7 +89,7 @@ template <int SS_WAVES>
 __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ bias, float* __restrict__ C, int M,
                                                            int N, int K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk,
-                                                           int64_t ldc, int accumulate) {
+                                                           int64_t ldc, int accumulate, float* __restrict__ rowsum) {
     // 8 waves share one 16 x 16 output tile and split the contraction (these layers have 8-64 rows: a tile per wave left
     // under a hundred waves walking K = 768..1536 alone: 29 us per launch); partial tiles meet in LDS.  The weight-gradient
     // form of the same layers contracts over those 8-64 rows and has 2 304 tiles: one wave per tile (SS_WAVES = 1).
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const floa
     const int kchunk = ((K + SS_WAVES * 16 - 1) / (SS_WAVES * 16)) * 16;     // per wave, a multiple of 16
     const int kb = wave * kchunk, ke = min(K, kb + kchunk);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f;                                         // rowsum: sum_k A(i, k) (the bias gradient of the weight-gradient form)
     constexpr int KT = 8;                                     // two 16-deep blocks per trip: 16 loads in flight
     for (int k0 = kb; k0 < ke; k0 += 4 * KT) {
         float a[KT], b[KT];
@@ -110,9 +111,15 @@ __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const floa
             const int k = k0 + e * 4 + lg;                    // k-step e: lane group lg holds k = k0 + 4e + lg
             a[e] = (av && k < ke) ? ap[k * sak] : 0.f;
             b[e] = (bv && k < ke) ? bp[k * sbk] : 0.f;
+            if (SS_WAVES == 1) asum += a[e];
         }
 #pragma unroll
         for (int e = 0; e < KT; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    if (SS_WAVES == 1 && rowsum && blockIdx.x == 0) {         // the first column tile of a row tile also owns its row sums
+        asum += __shfl_xor(asum, 16);
+        asum += __shfl_xor(asum, 32);
+        if (lg == 0 && av) rowsum[i] = (accumulate ? rowsum[i] : 0.f) + asum;
     }
     if (SS_WAVES > 1) {
         if (wave > 0) {
@@ -140,20 +147,34 @@ __global__ void __launch_bounds__(64 * SS_WAVES) sgemm_strided_kernel(const floa
 
 }  // namespace
 
-extern "C" int clv_sgemm_strided(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
-                                 int32_t K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc,
-                                 int32_t accumulate, void* stream) {
+static int sgemm_strided_impl(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
+                              int32_t K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc,
+                              int32_t accumulate, float* rowsum, void* stream) {
     if (!A || !B || !C || M < 0 || N <= 0 || K <= 0 || ldc < N) return CLV_ERR_ARG;
     if (M == 0) return CLV_OK;
     if (M > 0x7fffffff) return CLV_ERR_UNSUPPORTED;
+    if (rowsum && K > 96) return CLV_ERR_UNSUPPORTED;
     const dim3 grid((N + 15) / 16, (unsigned)((M + 15) / 16));
     if (K <= 96)                                             // a short contraction (weight-gradient form): nothing to split
         hipLaunchKernelGGL(sgemm_strided_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K, sai,
-                           sak, sbj, sbk, ldc, accumulate);
+                           sak, sbj, sbk, ldc, accumulate, rowsum);
     else
         hipLaunchKernelGGL(sgemm_strided_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, A, B, bias, C, (int)M, N, K, sai,
-                           sak, sbj, sbk, ldc, accumulate);
+                           sak, sbj, sbk, ldc, accumulate, (float*)nullptr);
     return clv_check_launch();
+}
+
+extern "C" int clv_sgemm_strided(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
+                                 int32_t K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc,
+                                 int32_t accumulate, void* stream) {
+    return sgemm_strided_impl(A, B, bias, C, M, N, K, sai, sak, sbj, sbk, ldc, accumulate, nullptr, stream);
+}
+
+extern "C" int clv_sgemm_strided_rowsum(const float* A, const float* B, float* C, float* rowsum, int64_t M, int32_t N,
+                                        int32_t K, int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc,
+                                        int32_t accumulate, void* stream) {
+    if (!rowsum) return CLV_ERR_ARG;
+    return sgemm_strided_impl(A, B, nullptr, C, M, N, K, sai, sak, sbj, sbk, ldc, accumulate, rowsum, stream);
 }
 
 extern "C" int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,

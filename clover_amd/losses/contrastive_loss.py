@@ -50,6 +50,12 @@ class ExclusiveNCEwithRankingLoss(nn.Module):
         nce, rank = ops.exclusive_infonce_rank_packed(gathered, slots, self.t, self.margin_ttm)
         return self._pack_losses(nce, rank)
 
+    def forward_gathered_pair(self, gathered, slots_a, slots_b):
+        """``forward_gathered`` on two slot quadruples of the same tensor in the same kernel launches (the recognizer's
+        video -> text and text -> video evaluations): -> (losses of slots_a, losses of slots_b)."""
+        nce_a, rank_a, nce_b, rank_b = ops.exclusive_infonce_rank_pair(gathered, slots_a, slots_b, self.t, self.margin_ttm)
+        return self._pack_losses(nce_a, rank_a), self._pack_losses(nce_b, rank_b)
+
 
 @LOSSES.register_module()
 class NormSoftmaxLoss(nn.Module):

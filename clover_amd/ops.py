@@ -663,12 +663,18 @@ class _LinearF32(torch.autograd.Function):
         bsink = getattr(bias, '_clv_grad', None) if bias is not None else None
         sink = wsink is not None and wsink.dtype == torch.float32 and (bias is None or bsink is not None)
         dw = wsink if sink else torch.empty(N, K, device=dy2.device, dtype=torch.float32)
-        _sgemm_strided(dy2, (1, N), x2, (1, K), None, dw, N, K, M, sink)              # dW[n][k] (+)= sum_m dy[m][n] x[m][k]
         db = None
         if bias is not None:
             db = bsink if sink else torch.empty(N, device=dy2.device, dtype=torch.float32)
-            ones = _ones_f32(M, dy2.device)
-            _sgemm_strided(dy2, (1, N), ones, (0, 1), None, db.view(N, 1), N, 1, M, sink)   # db[n] (+)= sum_m dy[m][n]
+        if bias is not None and M <= 96:
+            # dW[n][k] (+)= sum_m dy[m][n] x[m][k] and db[n] (+)= sum_m dy[m][n] in ONE launch (the row sums of the A operand)
+            check(_lib.lib().clv_sgemm_strided_rowsum(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(db), N, K, M, 1, N, 1, K,
+                                                      dw.stride(0), int(sink), _stream()), 'clv_sgemm_strided_rowsum')
+        else:
+            _sgemm_strided(dy2, (1, N), x2, (1, K), None, dw, N, K, M, sink)          # dW[n][k] (+)= sum_m dy[m][n] x[m][k]
+            if bias is not None:
+                ones = _ones_f32(M, dy2.device)
+                _sgemm_strided(dy2, (1, N), ones, (0, 1), None, db.view(N, 1), N, 1, M, sink)   # db[n] (+)= sum_m dy[m][n]
         if sink:
             weight._clv_ready()
             if bias is not None:
@@ -2087,6 +2093,44 @@ class _InfoNCEPacked(torch.autograd.Function):
         check(_lib.lib().clv_infonce_bwd(None, None, None, None, _ptr(dout), _ptr(work), *ds, G, Dm, k * Dm, temp,
                                          margin, _stream()), 'clv_infonce_bwd')
         return dp, None, None, None
+
+
+class _InfoNCEPair(torch.autograd.Function):
+    """Both evaluations of the step (video -> text, text -> video) on slots of one packed fp32 [G, k, Dm] tensor in the same
+    launches (clv_infonce_pair_fwd / _bwd): 3 + 4 dependent kernels instead of 6 + 8, no zero fill of the gradient and no
+    add of two partial gradients — the backward writes the whole [G, k, Dm] gradient."""
+
+    @staticmethod
+    def forward(ctx, packed, slots_a, slots_b, temperature, margin):
+        _need_gpu(packed)
+        assert packed.dtype == torch.float32 and packed.dim() == 3 and packed.is_contiguous()
+        assert len(slots_a) == 4 and len(slots_b) == 4
+        G, k, Dm = packed.shape
+        L = _lib.lib()
+        slots = (C.c_int32 * 8)(*[int(v) for v in tuple(slots_a) + tuple(slots_b)])
+        work = torch.empty(2 * L.clv_infonce_work_floats(G, Dm), device=packed.device, dtype=torch.float32)
+        out = torch.empty(4, device=packed.device, dtype=torch.float32)
+        check(L.clv_infonce_pair_fwd(_ptr(packed), slots, _ptr(out), _ptr(work), G, k, Dm, float(temperature),
+                                     float(margin), _stream()), 'clv_infonce_pair_fwd')
+        ctx.save_for_backward(work)
+        ctx.cfg = (G, k, Dm, slots, float(temperature), float(margin))
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, *douts):
+        work, = ctx.saved_tensors
+        G, k, Dm, slots, temp, margin = ctx.cfg
+        dout = torch.stack([(d if d is not None else work.new_zeros(())).float().reshape(()) for d in douts]).contiguous()
+        dp = torch.empty(G, k, Dm, device=work.device, dtype=torch.float32)
+        check(_lib.lib().clv_infonce_pair_bwd(_ptr(dout), _ptr(work), slots, _ptr(dp), G, k, Dm, temp, margin, _stream()),
+              'clv_infonce_pair_bwd')
+        return dp, None, None, None, None
+
+
+def exclusive_infonce_rank_pair(packed, slots_a, slots_b, temperature=0.05, margin=5.0):
+    """(nce_a, rank_a, nce_b, rank_b): exclusive_infonce_rank_packed on slots_a and on slots_b of the same packed tensor."""
+    assert len(set(int(v) for v in slots_a)) == 4 and len(set(int(v) for v in slots_b)) == 4
+    return _InfoNCEPair.apply(packed, tuple(slots_a), tuple(slots_b), temperature, margin)
 
 
 def exclusive_infonce_rank_packed(packed, slots, temperature=0.05, margin=5.0):

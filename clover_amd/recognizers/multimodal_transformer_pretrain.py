@@ -228,10 +228,16 @@ class CloverPretrain(BaseRecognizer):
              else gather_rows(emb.float(), equal_sizes=self.ssl_loss.equal_batch).contiguous())
         V, T, MW, MVR, MV, MWR = range(6)                      # EMB_NAMES order
         losses = dict(mlm_loss=mlm_loss) if mlm_loss is not None else {}
-        if self.mlm_ssl_V_head is not None:                                                                # :147
+        pair = (self.mlm_ssl_V_head is not None and self.symmetry_rank and g.is_cuda
+                and os.environ.get('CLOVER_LOSS_PAIR', '1') == '1')
+        if pair:                                               # both evaluations in the same kernel launches
+            l1, l2 = self.ssl_loss.forward_gathered_pair(g, (V, T, MW, MVR), (T, V, MV, MWR))              # :151, :161
+            losses.update(l1)
+        elif self.mlm_ssl_V_head is not None:                                                              # :147
             losses.update(self.ssl_loss.forward_gathered(g, (V, T, MW, MVR)))                              # :151
         if self.symmetry_rank:                                                                             # :155
-            l2 = self.ssl_loss.forward_gathered(g, (T, V, MV, MWR))                                        # :161
+            if not pair:
+                l2 = self.ssl_loss.forward_gathered(g, (T, V, MV, MWR))                                    # :161
             l2['v_nce_loss'] = l2.pop('nce_loss')
             if self.ssl_loss.use_rank:
                 l2['rank_v_vm_loss'] = l2.pop('rank_t_tm_loss')

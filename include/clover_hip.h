@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 12
+#define CLV_ABI_VERSION 13
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -369,6 +369,17 @@ int clv_infonce_fwd(const float* e0, const float* e1, const float* e2, const flo
 int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const float* e3,
                     const float* dout, const float* work, float* d0, float* d1, float* d2, float* d3,
                     int32_t G, int32_t Dm, int32_t ldd, float temperature, float margin, void* stream);
+/* The pre-training step evaluates the loss twice on slots of ONE packed fp32 [G][k][Dm] tensor — video -> text on
+ * (video, text, masked text, video-recon) and text -> video on (text, video, masked video, text-recon)
+ * (multimodal_transformer_pretrain.py:147-169).  The pair form runs both evaluations in the same launches (3 forward,
+ * 4 backward).  slots: HOST int32 [8] = the four slot indices of evaluation 0, then of evaluation 1 (distinct within an
+ * evaluation, < k).  out float [4] = {nce_0, rank_0, nce_1, rank_1}; work >= 2 * clv_infonce_work_floats(G, Dm) floats.
+ * Backward: dout float [4] (device) = the upstream gradients of `out`; dpacked [G][k][Dm] is WRITTEN in full (a slot read by
+ * both evaluations receives the sum, a slot read by none zeros). */
+int clv_infonce_pair_fwd(const float* packed, const int32_t* slots, float* out, float* work, int32_t G, int32_t k,
+                         int32_t Dm, float temperature, float margin, void* stream);
+int clv_infonce_pair_bwd(const float* dout, const float* work, const int32_t* slots, float* dpacked, int32_t G,
+                         int32_t k, int32_t Dm, float temperature, float margin, void* stream);
 
 /* NormSoftmaxLoss (mmaction/models/losses/contrastive_loss.py:26-68), the retrieval fine-tuning loss
  * (multimodal_transformer_finetune.py:83-86): x = normalise(video) . normalise(text)^T / temperature,
@@ -473,6 +484,11 @@ int clv_sgemm_nt(const float* A, const float* B, const float* bias, float* C, in
  * slab).  Forward x W^T, input gradient dy W and weight gradient dy^T x are this one kernel with different strides. */
 int clv_sgemm_strided(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
                       int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc, int32_t accumulate, void* stream);
+/* The same with rowsum[i] (+)= sum_k A[i*sai + k*sak] from the same launch (ABI 13): the weight-gradient form of a head layer
+ * (A = dy^T) delivers the bias gradient with it.  Contractions K <= 96 only (the rows of a batch), else CLV_ERR_UNSUPPORTED. */
+int clv_sgemm_strided_rowsum(const float* A, const float* B, float* C, float* rowsum, int64_t M, int32_t N, int32_t K,
+                             int64_t sai, int64_t sak, int64_t sbj, int64_t sbk, int64_t ldc, int32_t accumulate,
+                             void* stream);
 int clv_attn_f32_fwd(const float* q, const float* k, const float* v, float* o, const float* bias, const int32_t* rid,
                      const float* kmask, const ClvAttnGeom* geom, int32_t round_p, void* stream);
 /* Backward of clv_attn_f32_fwd in fp32 (ABI 8): dq / dk / dv with the strides of q / k / v, dbias (may be NULL) ACCUMULATED

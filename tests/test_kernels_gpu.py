@@ -394,6 +394,41 @@ def test_infonce_packed_slots(G):
         assert pg.grad[:, unused].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize('G', [1, 2, 8, 64, 200])
+def test_infonce_pair_equals_two_packed_evaluations(G):
+    """clv_infonce_pair_fwd / _bwd (both evaluations of the step in the same launches, the whole packed gradient written by
+    the backward) against two calls of the packed entry: the four losses bit for bit; the gradient bit for bit on the slots
+    one evaluation reads, to rounding (the two contributions are summed before the normalisation's Jacobian instead of after)
+    on the two slots both read; a slot nobody reads gets zeros.  Distinct upstream gradients per loss."""
+    Dm, k = 768, 7
+    packed = rnd(G, k, Dm, seed=181)
+    packed[:, 1] = packed[:, 0] * 0.7 + packed[:, 1] * 0.5
+    packed[:, 4] = packed[:, 1] * 0.6 + packed[:, 4] * 0.6
+    sa, sb = (0, 1, 2, 3), (1, 0, 4, 5)
+    wts = (1.3, 0.7, 0.9, 1.1)
+    pg = packed.to(DEV).requires_grad_()
+    outs = ops().exclusive_infonce_rank_pair(pg, sa, sb, 0.05, 5.0)
+    sum(w * o for w, o in zip(wts, outs)).backward()
+    pr = packed.to(DEV).requires_grad_()
+    na, ra = ops().exclusive_infonce_rank_packed(pr, sa, 0.05, 5.0)
+    nb, rb = ops().exclusive_infonce_rank_packed(pr, sb, 0.05, 5.0)
+    (wts[0] * na + wts[1] * ra + wts[2] * nb + wts[3] * rb).backward()
+    for o, r in zip(outs, (na, ra, nb, rb)):
+        assert o.item() == r.item(), (o.item(), r.item())
+    for s_ in (2, 3, 4, 5):
+        assert torch.equal(pg.grad[:, s_], pr.grad[:, s_]), s_
+    for s_ in (0, 1):
+        assert rel(pg.grad[:, s_], pr.grad[:, s_]) < 1e-5, (s_, rel(pg.grad[:, s_], pr.grad[:, s_]))
+    assert pg.grad[:, 6].abs().max().item() == 0.0
+    import ctypes as C
+    from clover_amd import _lib
+    L = _lib.lib()
+    bad = (C.c_int32 * 8)(0, 1, 2, 2, 1, 0, 4, 5)              # a repeated slot inside one evaluation
+    out = torch.empty(4, device=DEV)
+    work = torch.empty(2 * L.clv_infonce_work_floats(G, Dm), device=DEV)
+    assert L.clv_infonce_pair_fwd(pg.data_ptr(), bad, out.data_ptr(), work.data_ptr(), G, k, Dm, 0.05, 5.0, None) != 0
+
+
 def test_norm_softmax_loss_goldens():
     """clv_normsoftmax_fwd/bwd against the reference's own NormSoftmaxLoss numbers (g_finetune.npz): both norm
     clamps, ragged widths, a zero-norm row, the sim_mat entry."""

@@ -55,7 +55,8 @@ def test_sgemm_nt_strided_rows():
     assert rel(c, a.double() @ b.double().t()) < 2e-6
 
 
-@pytest.mark.parametrize('M,N,K,bias', [(16, 1536, 768, True), (8, 768, 1536, True), (3, 130, 70, False), (40, 768, 768, True)])
+@pytest.mark.parametrize('M,N,K,bias', [(16, 1536, 768, True), (8, 768, 1536, True), (3, 130, 70, False), (40, 768, 768, True),
+                                          (3, 130, 70, True), (100, 96, 64, True)])     # (> 96 rows: bias gradient as its own launch)
 def test_linear_f32_heads(M, N, K, bias):
     """ops.linear_f32 (clv_sgemm_strided: the fp32 Linear of the contrastive projection heads, on the TRAINING path):
     forward, input gradient, weight / bias gradient against fp64 torch — returned to autograd and accumulated into
