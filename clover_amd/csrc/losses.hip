@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(256) nce_normalize_kernel(const float* e0, con
 struct NcePair {
     NceWork w[2];
     const float* e[2][4];
+    const float* dout[4];      // backward: device scalars, the upstream gradients of {nce_0, rank_0, nce_1, rank_1} (null: 0)
     int slot[2][4];
 };
 __global__ void __launch_bounds__(256) nce_pair_normalize_kernel(NcePair P, int G, int Dm, int ld) {
@@ -332,9 +333,8 @@ __global__ void __launch_bounds__(1024) nce_pair_loss_kernel(NcePair P, float* _
 }
 
 // elementwise: d loss / d sim[k][i][j]
-__device__ __forceinline__ void nce_dsim_body(const NceWork& W, const float* __restrict__ dout, int G, float margin) {
+__device__ __forceinline__ void nce_dsim_body(const NceWork& W, const float gn, const float gr, int G, float margin) {
     const int64_t total = (int64_t)3 * G * G;
-    const float gn = dout[0], gr = dout[1];
     const float invG = 1.0f / (float)G, inv3G = 1.0f / (float)(3 * G);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(idx / ((int64_t)G * G));
@@ -360,10 +360,12 @@ __device__ __forceinline__ void nce_dsim_body(const NceWork& W, const float* __r
     }
 }
 __global__ void __launch_bounds__(256) nce_dsim_kernel(NceWork W, const float* __restrict__ dout, int G, float margin) {
-    nce_dsim_body(W, dout, G, margin);
+    nce_dsim_body(W, dout[0], dout[1], G, margin);
 }
-__global__ void __launch_bounds__(256) nce_pair_dsim_kernel(NcePair P, const float* __restrict__ dout, int G, float margin) {
-    nce_dsim_body(P.w[blockIdx.y], dout + 2 * blockIdx.y, G, margin);
+__global__ void __launch_bounds__(256) nce_pair_dsim_kernel(NcePair P, int G, float margin) {
+    const float* gn = P.dout[2 * blockIdx.y];
+    const float* gr = P.dout[2 * blockIdx.y + 1];
+    nce_dsim_body(P.w[blockIdx.y], gn ? *gn : 0.f, gr ? *gr : 0.f, G, margin);
 }
 
 // d e = invn * (d en - en * <en, d en>)   (valid while |e| >= eps; below eps: d e = d en * invn)
@@ -662,6 +664,7 @@ static bool nce_pair_setup(NcePair& P, const float* packed, float* work, const i
             P.e[d][q] = packed ? packed + (int64_t)sl * Dm : nullptr;
         }
     }
+    for (int q = 0; q < 4; ++q) P.dout[q] = nullptr;
     return true;
 }
 
@@ -683,17 +686,18 @@ extern "C" int clv_infonce_pair_fwd(const float* packed, const int32_t* slots, f
     return clv_check_launch();
 }
 
-extern "C" int clv_infonce_pair_bwd(const float* dout, const float* work, const int32_t* slots, float* dpacked,
+extern "C" int clv_infonce_pair_bwd(const float* const* dout, const float* work, const int32_t* slots, float* dpacked,
                                     int32_t G, int32_t k, int32_t Dm, float temperature, float margin, void* stream) {
     if (!dout || !work || !slots || !dpacked || G <= 0 || k < 4 || Dm <= 0 || temperature <= 0.f) return CLV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     NcePair P;
     if (!nce_pair_setup(P, nullptr, const_cast<float*>(work), slots, G, k, Dm)) return CLV_ERR_ARG;
+    for (int q = 0; q < 4; ++q) P.dout[q] = dout[q];
     const int64_t ws = nce_work_floats(G, Dm);
     int64_t total = (int64_t)3 * G * G;
     int grid = (int)((total + 255) / 256);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(nce_pair_dsim_kernel, dim3(grid, 2), dim3(256), 0, st, P, dout, (int)G, margin);
+    hipLaunchKernelGGL(nce_pair_dsim_kernel, dim3(grid, 2), dim3(256), 0, st, P, (int)G, margin);
     int rc = clv_check_launch();
     if (rc) return rc;
     const float it = 1.0f / temperature;

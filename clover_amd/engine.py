@@ -504,6 +504,8 @@ class CloverEngine:
                 run()
 
     # ------------------------------------------------------------------ hipGraph mode
+    _one = None
+
     _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
                        '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts', 'graph_loss', '_loss_io',
                        '_stale_views', '_prepacked')
@@ -560,7 +562,9 @@ class CloverEngine:
             mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
             losses = self.model.contrastive_losses(emb, mlm)
             loss, log_vars = self.model._parse_losses(losses)
-            loss.backward()
+            if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+                self._one = torch.ones_like(loss)
+            loss.backward(gradient=self._one)       # (a cached root gradient: no ones_like fill per step)
             self._static_demb.copy_(emb.grad)
             if mlm is not None:
                 self._static_dmlm.copy_(mlm.grad)

@@ -1989,6 +1989,39 @@ def mlm_decoder(x, weight, bias):
     return y.view(x.shape[:-1] + (weight.shape[0],))
 
 
+# --------------------------------------------------------------------------- fusion encoder output -> MLM decoder / reconstruction heads
+class _FusionTextOut(torch.autograd.Function):
+    """h [2B, S, D], the fusion encoder's output (rows [n_vis:] of a sample are its caption tokens) -> (the caption rows of
+    the first B samples, [B, L, D] contiguous: the MLM decoder's input; the caption-CLS row of all 2B samples as fp32
+    [2, B, D]: the two reconstruction heads' inputs).  ONE backward node that writes d h once — zeros, the caption rows, the
+    CLS rows added in fp32 — where autograd's slice / unbind / select chain on the step's critical path took two zero fills,
+    three copies, two casts, two adds and a cat (multimodal_transformer_pretrain.py:119-157 reads the same rows)."""
+
+    @staticmethod
+    def forward(ctx, h, n_vis):
+        B2, S, D = h.shape
+        ctx.cfg = (B2, S, D, int(n_vis), h.dtype)
+        t_last = h[:B2 // 2, n_vis:].contiguous()
+        cls = h[:, n_vis].float().reshape(2, B2 // 2, D)
+        return t_last, cls
+
+    @staticmethod
+    def backward(ctx, d_t, d_cls):
+        B2, S, D, n_vis, dtype = ctx.cfg
+        ref = d_t if d_t is not None else d_cls
+        dh = torch.zeros(B2, S, D, device=ref.device, dtype=dtype)
+        if d_t is not None:
+            dh[:B2 // 2, n_vis:].copy_(d_t)
+        if d_cls is not None:
+            dh[:, n_vis].add_(d_cls.reshape(B2, D))
+        return dh, None
+
+
+def fusion_text_outputs(h, n_vis):
+    assert h.dim() == 3 and h.shape[0] % 2 == 0 and 0 <= n_vis < h.shape[1]
+    return _FusionTextOut.apply(h, int(n_vis))
+
+
 # --------------------------------------------------------------------------- focal MLM loss
 
 
@@ -2120,9 +2153,11 @@ class _InfoNCEPair(torch.autograd.Function):
     def backward(ctx, *douts):
         work, = ctx.saved_tensors
         G, k, Dm, slots, temp, margin = ctx.cfg
-        dout = torch.stack([(d if d is not None else work.new_zeros(())).float().reshape(()) for d in douts]).contiguous()
+        # the four upstream gradients are read where autograd left them (no stack kernel): device pointers, NULL = 0
+        ds = [d if d is None or d.dtype == torch.float32 else d.float() for d in douts]
+        dout = (C.c_void_p * 4)(*[None if d is None else d.data_ptr() for d in ds])
         dp = torch.empty(G, k, Dm, device=work.device, dtype=torch.float32)
-        check(_lib.lib().clv_infonce_pair_bwd(_ptr(dout), _ptr(work), slots, _ptr(dp), G, k, Dm, temp, margin, _stream()),
+        check(_lib.lib().clv_infonce_pair_bwd(dout, _ptr(work), slots, _ptr(dp), G, k, Dm, temp, margin, _stream()),
               'clv_infonce_pair_bwd')
         return dp, None, None, None, None
 

@@ -163,21 +163,23 @@ class CloverPretrain(BaseRecognizer):
         fusion = self.multimodal_backbone(visual_token=ops.flush_point(vis_both.reshape(2 * B, T, h * w, D), aux=True),
                                           text_input_mask=text_mask2, text_input_embeds=text_out,
                                           prepared=fusion_prep if side is not None else None)
-        t_all = fusion['t_last_hidden_state']
-        t_last_hidden_state, v_fusion_t = t_all.unflatten(0, (2, B)).unbind(0)
+        # row block 0 = t_fusion, block 1 = v_fusion: the caption tokens of block 0 feed the MLM decoder (:129), the caption
+        # CLS rows of both blocks the reconstruction heads (:148-149, :156-157) — one autograd node (ops.fusion_text_outputs)
+        h_all = fusion['last_hidden_state']
+        t_last_hidden_state, cls_rows = ops.fusion_text_outputs(h_all, h_all.shape[1] - fusion['t_last_hidden_state'].shape[1])
 
         # ---- the two reconstruction heads (:148-149, :156-157; a dozen launch-bound kernels) on the side stream, under
         # the MLM decoder GEMM + focal loss
         def recon_heads():
             # a switched-off head leaves its slot of the packed embeddings zero (no gradient): contrastive_losses skips
             # the loss call that would read it
-            mvr = self.mlm_ssl_V_head(v_fusion_t[:, 0]) if self.mlm_ssl_V_head is not None else None        # :148-149
-            mwr = self.mlm_ssl_T_head(t_last_hidden_state[:, 0]) if self.symmetry_rank else None            # :156-157
+            mvr = self.mlm_ssl_V_head(cls_rows[1]) if self.mlm_ssl_V_head is not None else None             # :148-149
+            mwr = self.mlm_ssl_T_head(cls_rows[0]) if self.symmetry_rank else None                          # :156-157
             return mvr, mwr
         if heads_side:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                t_all.record_stream(side)
+                cls_rows.record_stream(side)
                 mask_visual_recon_emb, mask_word_recon_emb = recon_heads()
 
         # ---- MLM (:129-143): all B*L rows through the decoder, the fused focal kernel skips label == -100

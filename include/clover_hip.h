@@ -374,11 +374,12 @@ int clv_infonce_bwd(const float* e0, const float* e1, const float* e2, const flo
  * (multimodal_transformer_pretrain.py:147-169).  The pair form runs both evaluations in the same launches (3 forward,
  * 4 backward).  slots: HOST int32 [8] = the four slot indices of evaluation 0, then of evaluation 1 (distinct within an
  * evaluation, < k).  out float [4] = {nce_0, rank_0, nce_1, rank_1}; work >= 2 * clv_infonce_work_floats(G, Dm) floats.
- * Backward: dout float [4] (device) = the upstream gradients of `out`; dpacked [G][k][Dm] is WRITTEN in full (a slot read by
- * both evaluations receives the sum, a slot read by none zeros). */
+ * Backward: dout = HOST array of four DEVICE pointers to the fp32 upstream gradients of out[0..3] (each where autograd left
+ * it; NULL = 0); dpacked [G][k][Dm] is WRITTEN in full (a slot read by both evaluations receives the sum, a slot read by
+ * none zeros). */
 int clv_infonce_pair_fwd(const float* packed, const int32_t* slots, float* out, float* work, int32_t G, int32_t k,
                          int32_t Dm, float temperature, float margin, void* stream);
-int clv_infonce_pair_bwd(const float* dout, const float* work, const int32_t* slots, float* dpacked, int32_t G,
+int clv_infonce_pair_bwd(const float* const* dout, const float* work, const int32_t* slots, float* dpacked, int32_t G,
                          int32_t k, int32_t Dm, float temperature, float margin, void* stream);
 
 /* NormSoftmaxLoss (mmaction/models/losses/contrastive_loss.py:26-68), the retrieval fine-tuning loss

@@ -59,7 +59,7 @@ around(model.text_backbone.bert.embeddings, 'forward', None, None, 'text bwd: gr
 around(model.backbone, 'forward_both', 'video fwd in', 'video fwd out', 'video bwd: grad at its output')
 around(model.backbone.patch_embed, 'tokens_stacked', None, None, 'video bwd: grad at patch embed')
 around(model.multimodal_backbone, 'forward', 'fusion fwd in', 'fusion fwd out', 'fusion bwd: grad at its output',
-       pick=lambda o: o['t_last_hidden_state'])
+       pick=lambda o: o['last_hidden_state'])
 eng = CloverEngine(model, batch, lr=1e-5, weight_decay=0.005, grad_clip=15.0, max_iters=100000)
 around(eng, 'optimizer_step', 'optimizer in', 'optimizer out')
 eng.step(batch)
