@@ -1083,6 +1083,9 @@ int gn_launch_lean(int epi, hipStream_t st, unsigned grid, const bf16_t* a, cons
 
 // Batched 2-D transposes of bf16 matrices (the W^T shadows): one 64 x 64 tile per workgroup through LDS, 16-byte
 // accesses on both sides.  Entry e: src [rows][cols] -> dst [cols][rows]; tile_begin = prefix sum of tile counts.
+// The tile is stored with its 8-element column groups XOR-swizzled by the row group (element (r, c) at column c ^ (r & 56)):
+// the column-wise 2-byte reads of the second half (8 row groups x 8 neighbouring columns per wave) then fall on 32 distinct
+// banks instead of 2 (rows 8 apart are 32 banks apart at any 16-byte-aligned row pitch).
 struct TrEntry {
     int64_t src_off, dst_off;                                 // element offsets into src_base / dst_base
     int32_t rows, cols, tile_begin, tiles_c;
@@ -1107,11 +1110,12 @@ __global__ void __launch_bounds__(256) transpose_batch_kernel(const bf16_t* __re
         const int r = idx >> 3, c8 = (idx & 7) * 8;
         if (vec) {
             if (r0 + r < e.rows && c0 + c8 < e.cols)
-                *reinterpret_cast<uint4*>(&tile[r][c8]) =
+                *reinterpret_cast<uint4*>(&tile[r][c8 ^ (r & 56)]) =
                     *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * e.cols + c0 + c8);
         } else {
             for (int q = 0; q < 8; ++q)
-                if (r0 + r < e.rows && c0 + c8 + q < e.cols) tile[r][c8 + q] = src[(int64_t)(r0 + r) * e.cols + c0 + c8 + q];
+                if (r0 + r < e.rows && c0 + c8 + q < e.cols)
+                    tile[r][(c8 + q) ^ (r & 56)] = src[(int64_t)(r0 + r) * e.cols + c0 + c8 + q];
         }
     }
     __syncthreads();
@@ -1122,12 +1126,12 @@ __global__ void __launch_bounds__(256) transpose_batch_kernel(const bf16_t* __re
             if (r0 + r8 < e.rows) {
                 u16x8 o;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) o.v[q] = tile[r8 + q][cc];
+                for (int q = 0; q < 8; ++q) o.v[q] = tile[r8 + q][cc ^ r8];
                 *reinterpret_cast<u16x8*>(dst + (int64_t)(c0 + cc) * e.rows + r0 + r8) = o;
             }
         } else {
             for (int q = 0; q < 8; ++q)
-                if (r0 + r8 + q < e.rows) dst[(int64_t)(c0 + cc) * e.rows + r0 + r8 + q] = tile[r8 + q][cc];
+                if (r0 + r8 + q < e.rows) dst[(int64_t)(c0 + cc) * e.rows + r0 + r8 + q] = tile[r8 + q][cc ^ r8];
         }
     }
 }

@@ -237,15 +237,19 @@ __global__ void __launch_bounds__(256) nce_pair_normalize_kernel(NcePair P, int 
     nce_normalize_body(P.e[d][0], P.e[d][1], P.e[d][2], P.e[d][3], P.w[d], G, Dm, ld);
 }
 
-// C[i][j] (ldc) = alpha * sum_k A[i][k] * B[j][k]   — exact-f32 MFMA 16x16x4, one wave per
-// 16x16 tile.  K multiple of 16 is NOT required (tail guarded); rows/cols guarded.
-__global__ void __launch_bounds__(64) sgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+// C[i][j] (ldc) = alpha * sum_k A[i][k] * B[j][k]   — exact-f32 MFMA 16x16x4, one 16x16 tile per workgroup.
+// K multiple of 16 is NOT required (tail guarded); rows/cols guarded.  NW waves split the contraction (partial tiles meet in
+// LDS): the similarity GEMMs have G x G outputs — a handful of tiles — and Dm = 768 to contract: one wave per tile walked 48
+// dependent load rounds (20 us); the gradient GEMMs contract over <= 3 G and keep one wave.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) sgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                       int ldc, int64_t sA, int64_t sB, int64_t sC, float alpha,
                                                       int zb, int64_t s2) {
     // batch index z = z1 * zb + z0: operand offsets (sA, sB, sC) * z0 + s2 * z1 (the pair form: z1 = direction, one work
     // area of s2 floats each)
-    const int lane = threadIdx.x, lg = lane >> 4, lr = lane & 15;
+    __shared__ float red[NW > 1 ? NW - 1 : 1][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4, lr = lane & 15;
     const int z1 = blockIdx.z / zb, z0 = blockIdx.z - z1 * zb;
     A += sA * z0 + s2 * z1;
     B += sB * z0 + s2 * z1;
@@ -254,17 +258,31 @@ __global__ void __launch_bounds__(64) sgemm_nt_kernel(const float* __restrict__ 
     const float* ap = A + (int64_t)(i < M ? i : 0) * lda;
     const float* bp = B + (int64_t)(j < N ? j : 0) * ldb;
     const bool av = i < M, bv = j < N;
+    const int kchunk = ((K + NW * 16 - 1) / (NW * 16)) * 16;       // per wave, a multiple of 16
+    const int kb = wave * kchunk, ke = min(K, kb + kchunk);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int k0 = kb; k0 < ke; k0 += 16) {
         float a[4], b[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + lg * 4 + e;
-            a[e] = (av && k < K) ? ap[k] : 0.f;
-            b[e] = (bv && k < K) ? bp[k] : 0.f;
+            a[e] = (av && k < ke) ? ap[k] : 0.f;
+            b[e] = (bv && k < ke) ? bp[k] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    if (NW > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
     }
     // acc[r] = C[row blockIdx.y*16 + lg*4 + r][col blockIdx.x*16 + lr]
 #pragma unroll
@@ -602,8 +620,13 @@ extern "C" int64_t clv_infonce_work_floats(int32_t G, int32_t Dm) { return nce_w
 static int nce_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                     int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st, int outer = 1,
                     int64_t s2 = 0) {
-    hipLaunchKernelGGL(sgemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16, batch * outer), dim3(64), 0, st, A, B, C, M, N,
-                       K, lda, ldb, ldc, sA, sB, sC, alpha, batch, s2);
+    const dim3 grid((N + 15) / 16, (M + 15) / 16, batch * outer);
+    if (K >= 256 && (int64_t)grid.x * grid.y * batch <= 512)       // few tiles (per evaluation), long contraction: 8 waves share a tile
+        hipLaunchKernelGGL(sgemm_nt_kernel<8>, grid, dim3(512), 0, st, A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha,
+                           batch, s2);
+    else
+        hipLaunchKernelGGL(sgemm_nt_kernel<1>, grid, dim3(64), 0, st, A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha,
+                           batch, s2);
     return clv_check_launch();
 }
 

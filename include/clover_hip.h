@@ -106,7 +106,8 @@ int clv_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
  * optimizer, so a backward pass gathers all its attention blocks at its end. */
 #define CLV_DBIAS_GATHER_MAX 32
 typedef struct ClvDbiasGather {
-    const void* partial;       /* float partial sums inside the work buffer */
+    const void* partial;       /* float partial sums inside the work buffer (16-byte aligned; the batch call CONSUMES them:
+                                  it adds the slices into slice 0 before it gathers) */
     void* dtable;              /* float [rows][nH] */
     const void* index;         /* int32 table of clv_attn_dbias_index() */
     int64_t split_stride;
