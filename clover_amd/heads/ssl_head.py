@@ -5,6 +5,7 @@ nn.LinearFP32) + the HIP LayerNorm/GELU kernels in their fp32-storage form; outp
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..builder import HEADS
 from ..nn import GELU, BatchNorm1d, LayerNorm
 from ..nn import LinearFP32 as Linear
@@ -77,7 +78,7 @@ class NCEHeadForMM(nn.Module):
         passes > 1: the batch stacks that many forward passes of the reference (the recognizer's doubled clean + masked
         pass); a BatchNorm projector then runs per pass (see _per_pass), a LayerNorm one does not care."""
         if self.spatial_type == 'avg':
-            img = img.float().mean(dim=(1, 2, 3) if channels_last else (2, 3, 4))
+            img = ops.token_mean(img) if channels_last else img.float().mean(dim=(2, 3, 4))
         else:
             raise NotImplementedError('spatial_type other than avg')
         if self.dropout is not None:

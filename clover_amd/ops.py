@@ -1521,6 +1521,33 @@ def batch_norm1d(x, weight, bias, running_mean, running_var, training, momentum=
     return _BatchNorm1d.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
 
 
+class _TokenMean(torch.autograd.Function):
+    """Mean over the token dimensions (all but the first and the last) of a channels-last feature map, fp32 out: the spatial
+    average of the vision projection head (ssl_head.py:88-94).  ``x.float().mean(dims)`` writes an fp32 copy of the map (38 MB
+    at B = 8) and its backward an fp32 broadcast of the gradient plus a cast; here the forward is one reduction reading the
+    bf16 map and the backward hands autograd the [N, C] gradient / n as an EXPANDED view — the accumulation with the map's
+    other gradient (it also feeds the fusion encoder) is then one broadcast add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return x.mean(dim=tuple(range(1, x.dim() - 1)), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        n = 1
+        for d in shape[1:-1]:
+            n *= d
+        gs = (g * (1.0 / n)).to(ctx.dtype)
+        return gs.view((shape[0],) + (1,) * (len(shape) - 2) + (shape[-1],)).expand(shape)
+
+
+def token_mean(x):
+    """[N, ..., C] -> fp32 [N, C]: mean over the middle dimensions."""
+    return _TokenMean.apply(x)
+
+
 class _Embedding(torch.autograd.Function):
     """weight[ids] with the gradient scattered straight into the engine's gradient slab (index_add_ of the few
     hundred looked-up rows) instead of a dense [vocab, H] zero-fill + scatter + fp32 add of 94 MB each.
