@@ -464,3 +464,43 @@ def test_grouped_weight_gradient_chunking():
     assert [len(c) for c in ops.fold_chunks([fold(shared), fold(other[0]), fold(shared), fold(other[1])])] == [2, 2]
     assert [len(c) for c in ops.fold_chunks([fold(other[0], w[0]), fold(other[1], w[0]), fold(other[2], w[1])])] == [1, 2]
     assert [len(c) for c in ops.fold_chunks([fold(torch.zeros(2, 2)) for _ in range(130)])] == [64, 64, 2]
+
+
+def test_fusion_text_outputs_and_token_mean_equal_autograd():
+    """ops.fusion_text_outputs (one autograd node for the MLM decoder's input + the two reconstruction heads' CLS rows,
+    multimodal_transformer_pretrain.py:129,148-149,156-157) and ops.token_mean (the vision head's spatial average,
+    ssl_head.py:88-94) against the plain slice / unbind / select / mean expressions they replace: values and gradients, with
+    both consumers, with either one alone (the ablation switches), in fp32 and bf16."""
+    import torch
+    from clover_amd import ops
+    torch.manual_seed(3)
+    B, S, L, D = 3, 11, 4, 8
+    for dtype in (torch.float32, torch.bfloat16):
+        h0 = torch.randn(2 * B, S, D).to(dtype)
+        wt, wc = torch.randn(B, L, D), torch.randn(2, B, D)
+        for use_t, use_c in ((True, True), (True, False), (False, True)):
+            h = h0.clone().requires_grad_()
+            t_last, cls = ops.fusion_text_outputs(h, S - L)
+            assert t_last.is_contiguous() and t_last.dtype == dtype and cls.dtype == torch.float32
+            loss = (t_last.float() * wt).sum() * use_t + (cls * wc).sum() * use_c
+            loss.backward()
+            hr = h0.clone().requires_grad_()
+            t_all = hr[:, S - L:]
+            tl, vf = t_all.unflatten(0, (2, B)).unbind(0)
+            cr = torch.stack([tl[:, 0].float(), vf[:, 0].float()])
+            lr = (tl.float() * wt).sum() * use_t + (cr * wc).sum() * use_c
+            lr.backward()
+            assert torch.equal(t_last, tl) and torch.equal(cls, cr)
+            tol = 0.0 if dtype == torch.float32 else 2e-2       # (bf16: the CLS rows are added in fp32 here, in bf16 there)
+            assert (h.grad.float() - hr.grad.float()).abs().max().item() <= tol * hr.grad.float().abs().max().item() + 1e-6
+    for dtype in (torch.float32, torch.bfloat16):
+        x0 = torch.randn(4, 2, 3, 3, D).to(dtype)
+        w = torch.randn(4, D)
+        x = x0.clone().requires_grad_()
+        y = ops.token_mean(x)
+        ((y * w).sum() + (x.float() ** 2).sum()).backward()     # a second consumer, as the fusion encoder is
+        xr = x0.clone().requires_grad_()
+        yr = xr.float().mean(dim=(1, 2, 3))
+        ((yr * w).sum() + (xr.float() ** 2).sum()).backward()
+        assert y.dtype == torch.float32 and (y - yr).abs().max().item() < 1e-6
+        assert (x.grad.float() - xr.grad.float()).abs().max().item() <= 2e-2 * xr.grad.float().abs().max().item()
