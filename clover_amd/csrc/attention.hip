@@ -1261,15 +1261,19 @@ __global__ void __launch_bounds__(256) dbias_gather_batch_kernel(GatherTable tab
     for (int i = 1; i < tab.n; ++i)
         if ((int)blockIdx.x >= tab.e[i].block_begin) idx = i;
     const ClvDbiasGather& en = tab.e[idx];
+    // one wave = one table row x a group of hg <= 4 heads: the row's index entries are loaded once and the heads' elements
+    // (the same offsets in each head's block) are in flight together
+    const int hg = en.pad > 0 ? en.pad : 1, ngrp = en.nH / hg;
     const int wl = ((int)blockIdx.x - en.block_begin) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wl >= en.nslots * en.nH) return;
-    const int slot = en.slot0 + wl / en.nH, h = wl % en.nH;
+    if (wl >= en.nslots * ngrp) return;
+    const int slot = en.slot0 + wl / ngrp, h0 = (wl % ngrp) * hg;
     const int NK = en.nkt * 16, nqt = (en.N + 15) >> 4;
-    const float* dh = static_cast<const float*>(en.partial) + (int64_t)h * nqt * en.nkt * 256;
+    const int64_t hstride = (int64_t)nqt * en.nkt * 256;
+    const float* dh = static_cast<const float*>(en.partial) + h0 * hstride;
     const int* trow = static_cast<const int*>(en.index) + slot * NK;
     const int nsplit = en.nsplit;
     const int64_t split_stride = en.split_stride;
-    float a = 0.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     // four keys per trip: the four index loads, then the (dependent, scattered) element loads, are in flight together — the
     // kernel is a chain of two dependent loads per key and nothing else
     for (int kb0 = lane; kb0 < NK; kb0 += 256) {
@@ -1277,10 +1281,14 @@ __global__ void __launch_bounds__(256) dbias_gather_batch_kernel(GatherTable tab
 #pragma unroll
         for (int u = 0; u < 4; ++u) off[u] = kb0 + 64 * u < NK ? trow[kb0 + 64 * u] : -1;
         if (nsplit == 1) {
-            float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = off[u] >= 0 ? dh[off[u]] : 0.f;
-            a += (v[0] + v[1]) + (v[2] + v[3]);
+            for (int hh = 0; hh < 4; ++hh) {
+                if (hh >= hg) break;
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = off[u] >= 0 ? dh[hh * hstride + off[u]] : 0.f;
+                a[hh] += (v[0] + v[1]) + (v[2] + v[3]);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1288,14 +1296,18 @@ __global__ void __launch_bounds__(256) dbias_gather_batch_kernel(GatherTable tab
                 const float* pe = dh + off[u];
                 int sp = 0;
                 for (; sp + 4 <= nsplit; sp += 4)
-                    a += (pe[sp * split_stride] + pe[(sp + 1) * split_stride]) +
-                         (pe[(sp + 2) * split_stride] + pe[(sp + 3) * split_stride]);
-                for (; sp < nsplit; ++sp) a += pe[sp * split_stride];
+                    a[0] += (pe[sp * split_stride] + pe[(sp + 1) * split_stride]) +
+                            (pe[(sp + 2) * split_stride] + pe[(sp + 3) * split_stride]);
+                for (; sp < nsplit; ++sp) a[0] += pe[sp * split_stride];
             }
         }
     }
-    a = wave_sum(a);
-    if (lane == 0) static_cast<float*>(en.dtable)[slot * en.nH + h] += a;
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+        if (hh >= hg) break;
+        const float t = wave_sum(a[hh]);
+        if (lane == 0) static_cast<float*>(en.dtable)[slot * en.nH + h0 + hh] += t;
+    }
 }
 
 // ------------------------------------------------------------------------- fp32 parity kernel
@@ -1993,12 +2005,21 @@ extern "C" int clv_attn_dbias_gather_batch(const ClvDbiasGather* entries, int32_
     for (int i = 0; i < n; ++i) {
         ClvDbiasGather en = entries[i];
         if (!en.partial || !en.dtable || !en.index || en.nsplit <= 0 || en.nslots <= 0 || en.nH <= 0) return CLV_ERR_ARG;
-        en.block_begin = blocks;
-        blocks += (en.nslots * en.nH + 3) / 4;
         tab.e[i] = en;
     }
     tab.n = n;
     static const bool presum = !getenv("CLV_DBIAS_PRESUM") || atoi(getenv("CLV_DBIAS_PRESUM")) != 0;
+    static const int hg_max = getenv("CLV_DBIAS_HEADS_PER_WAVE") ? atoi(getenv("CLV_DBIAS_HEADS_PER_WAVE")) : 4;
+    for (int i = 0; i < n; ++i) {                              // heads per wave (field `pad`): only on summed slices
+        ClvDbiasGather& en = tab.e[i];
+        int hg = 1;
+        if (presum || en.nsplit == 1)
+            for (int c = 4; c >= 2; --c)
+                if (c <= hg_max && en.nH % c == 0) { hg = c; break; }
+        en.pad = hg;
+        en.block_begin = blocks;
+        blocks += (en.nslots * (en.nH / hg) + 3) / 4;
+    }
     if (presum) {
         GatherTable st = tab;
         int sblocks = 0;
