@@ -75,6 +75,7 @@ SIGNATURES = {
     'clv_attn_dbias_index_count': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_dbias_index': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p]),
     'clv_attn_dbias_gather_entry': (C.c_int, [C.POINTER(ClvAttnGeom), _p, _p, C.POINTER(ClvDbiasGather)]),
+    'clv_attn_dbias_partial_bytes': (C.c_int64, [_p]),
     'clv_attn_dbias_gather_batch': (C.c_int, [C.POINTER(ClvDbiasGather), _i32, _p]),
     'clv_attn_bwd': (C.c_int, [_p] * 16 + [_i32, C.POINTER(ClvAttnGeom), _p]),
     'clv_softmax_rows_fwd': (C.c_int, [_p] * 5 + [_i64, _i32, _i32, _i32, _f, _f, _p]),

@@ -1799,7 +1799,11 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
                 dq_out, dk_out, dv_out, (bf16_t*)(bias ? work : nullptr), dsum, Gx);
     };
     const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * NKT * 64;
-    float* partial = bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT)) : nullptr;
+    // (the partial sums live behind the scratch, or — so that a caller who gathers later can release the scratch — in the
+    // geometry's own `work` buffer: clv_attn_dbias_partial_bytes)
+    float* partial = !bias ? nullptr
+                     : G.g.work ? reinterpret_cast<float*>(G.g.work)
+                                : reinterpret_cast<float*>(reinterpret_cast<char*>(work) + ds_scratch_bytes(G, NKT));
     // >= 16 groups per slice: the fp32 partial tables cost 2 x 16 B per 4 scores and slice, i.e. as much as the
     // bf16 scratch itself once a slice covers only 4 groups
     const int splits = dbias_splits(G);
@@ -1923,6 +1927,14 @@ extern "C" int64_t clv_attn_bwd_work_bytes(const ClvAttnGeom* geom) {
     return ds_scratch_bytes(G, nkt) + (int64_t)(DBIAS_SPLITS + 1) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;   // + fp32 partials, dense
 }
 
+extern "C" int64_t clv_attn_dbias_partial_bytes(const ClvAttnGeom* geom) {
+    Geom G;
+    if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0) return 0;
+    const int nkt = pick_nkt(G.g.N);
+    if (nkt < 0) return 0;
+    return (int64_t)dbias_splits(G) * G.g.nH * ((G.g.N + 15) / 16) * nkt * 256 * 4;
+}
+
 extern "C" int clv_attn_bwd_one_kernel(const ClvAttnGeom* geom) {
     Geom G;
     if (!make_geom(geom, G) || G.g.mode != 1 || G.tlen == 0 || G.g.hd != 32) return 0;
@@ -1982,7 +1994,7 @@ extern "C" int clv_attn_dbias_gather_entry(const ClvAttnGeom* geom, void* work, 
     const int nkt = pick_nkt(G.g.N);
     if (nkt < 0) return CLV_ERR_UNSUPPORTED;
     const int64_t E = (int64_t)G.g.nH * ((G.g.N + 15) / 16) * nkt * 64;
-    out->partial = reinterpret_cast<char*>(work) + ds_scratch_bytes(G, nkt);
+    out->partial = G.g.work ? reinterpret_cast<char*>(G.g.work) : reinterpret_cast<char*>(work) + ds_scratch_bytes(G, nkt);
     out->dtable = dbias;
     out->index = G.g.dbias_index;
     out->split_stride = E * 4;

@@ -1644,10 +1644,15 @@ class _Attention(torch.autograd.Function):
         if PROF is None and DBIAS_DEFER is not None and sink is not None:
             # nothing reads a table gradient before the optimizer: leave the slices' partial sums in `work` (stage bit 8) and
             # gather every attention block of this backward segment in ONE launch when it closes (flush_dbias_gathers)
+            # The partial sums go to a buffer of their own (ClvAttnGeom.work): only that stays alive until the gather — the dS
+            # scratch in `work` (2.5-10 GB per block at 32 frames) is released with this backward node
+            part = torch.empty(L.clv_attn_dbias_partial_bytes(C.byref(g)), device=qkv.device, dtype=torch.uint8)
+            g.work = part.data_ptr()
             check(L.clv_attn_bwd(*args, 15, C.byref(g), _stream()), 'clv_attn_bwd')
             ent = _lib.ClvDbiasGather()
             check(L.clv_attn_dbias_gather_entry(C.byref(g), _ptr(work), _ptr(dtab), C.byref(ent)), 'clv_attn_dbias_gather_entry')
-            DBIAS_DEFER.append((ent, work, dtab, g.dbias_index))
+            g.work = None
+            DBIAS_DEFER.append((ent, part, dtab, g.dbias_index))
         elif PROF is None:
             check(L.clv_attn_bwd(*args, 0, C.byref(g), _stream()), 'clv_attn_bwd')
         elif tab is not None and L.clv_attn_bwd_one_kernel(C.byref(g)) == 1:

@@ -69,7 +69,12 @@ typedef struct ClvAttnGeom {
                                    cross_transformer.py:89-110): clv_attn_seq_work_bytes() of scratch.  K / V (Q / dO) of one
                                    (sample, head) then exceed the LDS, so the staged tokens are split in two parts, each
                                    with its own workgroups; the parts' results (o + lse; dq; dk / dv) meet in a merge
-                                   kernel.  Not read otherwise. */
+                                   kernel.
+                                   mode 1, backward with a bias table, optional: clv_attn_dbias_partial_bytes() of 16-byte
+                                   aligned memory that receives the slices' fp32 partial sums of the table gradient INSTEAD
+                                   of the tail of clv_attn_bwd's `work` — a caller that gathers later (stage bit 8 +
+                                   clv_attn_dbias_gather_batch) keeps only this and releases the dS scratch (GBs at 32
+                                   frames).  Not read otherwise. */
 } ClvAttnGeom;
 
 /* lse: float [groups][nH][N].  bias: the module's relative_position_bias_table, float [rows][nH], or NULL.  rid: int32 [nW][N] region
@@ -114,6 +119,7 @@ typedef struct ClvDbiasGather {
     int32_t nkt, nH, N, nsplit, slot0, nslots, block_begin, pad;
 } ClvDbiasGather;
 int clv_attn_dbias_gather_entry(const ClvAttnGeom* geom_host, void* work, float* dbias, ClvDbiasGather* out);
+int64_t clv_attn_dbias_partial_bytes(const ClvAttnGeom* geom_host);    /* size of ClvAttnGeom.work in mode 1 (see there) */
 int clv_attn_dbias_gather_batch(const ClvDbiasGather* entries, int32_t n, void* stream);
 
 /* ---- unfused attention for long sequences (N > 448 keys: K/V of one (group, head) no longer fit LDS in the

@@ -218,6 +218,10 @@ def test_window_attention_deferred_table_gradient():
             with ops().defer_folds():
                 body()
                 assert len(ops().DBIAS_DEFER) == 2 * len(inputs)
+                # what stays alive until the gather is the partial-sum buffer alone, not the block's dS scratch
+                # (clv_attn_bwd_work_bytes: GBs per block at 32 frames — 72 GB over config 5's 24 blocks)
+                held = sum(item[1].numel() for item in ops().DBIAS_DEFER)
+                assert held < 40 * 2 ** 20, held
         else:
             body()
         torch.cuda.synchronize()
