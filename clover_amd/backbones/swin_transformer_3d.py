@@ -490,9 +490,11 @@ class SwinTransformer3D(nn.Module):
             self._dp_keep = None
         if not self._dp_mods:
             return
-        if self._dp_keep is None or self._dp_keep.device != device:
-            self._dp_keep = torch.tensor([1.0 - m.drop_prob for m in self._dp_mods], device=device)[:, None]
-        scales = (torch.rand(len(self._dp_mods), B, device=device) < self._dp_keep).float() / self._dp_keep
+        if self._dp_keep is None or self._dp_keep.device != device or self._dp_keep.shape[1] != B:
+            keep = torch.tensor([1.0 - m.drop_prob for m in self._dp_mods], device=device)[:, None]
+            self._dp_keep = keep.expand(len(self._dp_mods), B).contiguous()       # per-element Bernoulli probabilities
+            self._dp_inv = 1.0 / keep
+        scales = torch.bernoulli(self._dp_keep) * self._dp_inv                    # two kernels (was rand, <, cast, /)
         for i, m in enumerate(self._dp_mods):
             m.preset(scales[i])
 

@@ -2071,8 +2071,8 @@ class _FocalCE(torch.autograd.Function):
         dev = lg.device
         row_ce = torch.empty(rows, device=dev, dtype=torch.float32)
         row_lse = torch.empty_like(row_ce)
-        loss = torch.zeros(1, device=dev, dtype=torch.float32)
-        count = torch.zeros(1, device=dev, dtype=torch.float32)
+        acc = torch.zeros(2, device=dev, dtype=torch.float32)          # one fill for the two accumulators
+        loss, count = acc[0:1], acc[1:2]
         check(_lib.lib().clv_focal_ce_fwd_ld(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
                                              _ptr(loss), _ptr(count), rows, V, ld, float(gamma), _stream()),
               'clv_focal_ce_fwd_ld')
