@@ -1303,6 +1303,10 @@ GnPlan gn_plan(int64_t M, int N, int K, bool allow_split) {
             // 48-tile K = 3 072 layers; the MLM decoder's input gradient contracts over 30 528 vocabulary entries)
             int sk = (int)((256 + tiles64 / 2) / tiles64);
             sk = sk < 4 ? 4 : (sk > 16 ? 16 : sk);
+            // few tiles, very long contraction (the decoder: 24 tiles, 477 stages): past 192 units the launch takes a second
+            // round on part of the chip — 6 or 8 slices 32 us, 9-11 slices 44-46 us
+            if (tiles64 <= 32)
+                while (sk > 4 && tiles64 * sk > 192) --sk;
             while (sk > 2 && nst / sk < 12) --sk;
             p.splitk = sk;
         }
