@@ -617,6 +617,12 @@ extern "C" int clv_focal_ce_bwd_ld(const void* logits, int32_t is_bf16, const in
 
 extern "C" int64_t clv_infonce_work_floats(int32_t G, int32_t Dm) { return nce_work_floats(G, Dm); }
 
+// one thread per exclusive row / column (6 G of them): whole waves, at most the kernel's 1024 (a per-rank batch of 8 needs one)
+static int nce_loss_threads(int G) {
+    const int t = (6 * G + 63) / 64 * 64;
+    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
 static int nce_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                     int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st, int outer = 1,
                     int64_t s2 = 0) {
@@ -645,7 +651,7 @@ extern "C" int clv_infonce_fwd(const float* e0, const float* e1, const float* e2
     rc = nce_gemm(W.en, W.en + (int64_t)G * Dm, W.sim, G, G, Dm, Dm, Dm, G, 3, 0, (int64_t)G * Dm, (int64_t)G * G,
                   1.0f / temperature, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(1024), 0, st, W, out, (int)G, margin);
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(nce_loss_threads(G)), 0, st, W, out, (int)G, margin);
     return clv_check_launch();
 }
 
@@ -705,7 +711,7 @@ extern "C" int clv_infonce_pair_fwd(const float* packed, const int32_t* slots, f
     rc = nce_gemm(P.w[0].en, P.w[0].en + (int64_t)G * Dm, P.w[0].sim, G, G, Dm, Dm, Dm, G, 3, 0, (int64_t)G * Dm,
                   (int64_t)G * G, 1.0f / temperature, st, 2, ws);
     if (rc) return rc;
-    hipLaunchKernelGGL(nce_pair_loss_kernel, dim3(2), dim3(1024), 0, st, P, out, (int)G, margin);
+    hipLaunchKernelGGL(nce_pair_loss_kernel, dim3(2), dim3(nce_loss_threads(G)), 0, st, P, out, (int)G, margin);
     return clv_check_launch();
 }
 
