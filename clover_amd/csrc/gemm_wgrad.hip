@@ -1842,10 +1842,22 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
             if (rc) return rc;
         }
     }
+    // Longest workgroups first: a problem's workgroups walk M / splits rows each (1 500 ... 9 000 inside one launch), blocks
+    // are dispatched in index order, and the problems arrive in backward order — stage 0 with the longest slices LAST, where
+    // its ~260 workgroups used to run on alone after everything else had drained.
+    int order[WG_GROUP_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    static const bool lpt = !getenv("CLV_WGRAD_LPT") || atoi(getenv("CLV_WGRAD_LPT")) != 0;
+    if (lpt)
+        std::stable_sort(order, order + n, [&](int a, int b) {
+            return entries[a].M / (entries[a].splits > 0 ? entries[a].splits : 1) >
+                   entries[b].M / (entries[b].splits > 0 ? entries[b].splits : 1);
+        });
     for (int cls = 0; cls < WG_CLASSES; ++cls) {
         WgGroup grp;
         int blocks = 0, rot = 0, cnt = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int oi = 0; oi < n; ++oi) {
+            const int i = order[oi];
             const ClvWgradEntry& e = entries[i];
             const bool in_place = e.work_floats == 0;
             if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7) || e.N <= 0 || e.K <= 0) return CLV_ERR_ARG;
