@@ -40,7 +40,7 @@ class ClvWgradEntry(C.Structure):
                 ('ldy', _i32), ('ldx', _i32), ('want_bias', _i32), ('splits', _i32), ('overwrite', _i32), ('pad', _i32)]
 
 
-WGRAD_GROUP_MAX = 40
+WGRAD_GROUP_MAX = min(80, max(1, int(os.environ.get('CLOVER_WGRAD_GROUP_MAX', '80'))))     # problems per grouped launch
 
 
 class ClvDbiasGather(C.Structure):

@@ -397,7 +397,7 @@ def wgrad_chunks(pending):
 
 
 def flush_wgrads(pending):
-    """The deferred weight gradients as grouped launches (clv_linear_wgrad_batch, <= 40 problems each); returns the
+    """The deferred weight gradients as grouped launches (clv_linear_wgrad_batch, <= 80 problems each); returns the
     fold entries of their partials."""
     folds = []
     L = _lib.lib()

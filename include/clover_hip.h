@@ -277,7 +277,7 @@ typedef struct ClvFoldEntry {
     int32_t overwrite;     /* bit 0: dw = the sum, bit 1: db = the sum (an uninitialised temporary, or the step's first
                               gradient of a weight the engine does not clear), instead of += */
 } ClvFoldEntry;
-/* Grouped launch: the weight gradients of up to 40 Linear layers (a whole backward segment: nothing reads a weight
+/* Grouped launch: the weight gradients of up to 80 Linear layers (a whole backward segment: nothing reads a weight
  * gradient before the optimizer) as ONE grid.  clv_linear_wgrad_batch_plan fills splits and work_floats of every entry
  * (fewer M-slices per problem than a stand-alone launch needs); the caller points `work` at work_floats floats,
  * clv_linear_wgrad_batch writes the fp32 partials [splits][N*K dW | N db] there, and clv_wgrad_fold_batch (entries with

@@ -438,7 +438,7 @@ def test_tools_cli_host_side():
 
 
 def test_grouped_weight_gradient_chunking():
-    """ops.wgrad_chunks: <= 40 problems per launch, and two in-place problems (few rows, or a large 256-divisible output)
+    """ops.wgrad_chunks: <= 80 problems per launch, and two in-place problems (few rows, or a large 256-divisible output)
     with the same dW never in one launch — the in-place kernels add without atomics."""
     import torch
     from clover_amd import ops, _lib
@@ -456,8 +456,8 @@ def test_grouped_weight_gradient_chunking():
     # ... two in-place uses may not; an in-place + a partial-mode use may
     assert [len(c) for c in ops.wgrad_chunks([item(shared, 512), item(other[0], 512), item(shared, 640),
                                               item(shared, 12544), item(other[1], 512)])] == [2, 3]
-    many = [item(torch.zeros(8, 8), 12544) for _ in range(95)]
-    assert [len(c) for c in ops.wgrad_chunks(many)] == [40, 40, 15]
+    many = [item(torch.zeros(8, 8), 12544) for _ in range(175)]
+    assert [len(c) for c in ops.wgrad_chunks(many)] == [80, 80, 15]
     # the folds of two partial-mode uses of ONE dW (or db) never share a launch: the fold kernel adds without atomics
     w = [torch.zeros(4) for _ in range(4)]
     fold = lambda dw, db=None: (torch.zeros(1), dw, db, 2, 2, 4)
