@@ -1544,7 +1544,9 @@ class _TokenMean(torch.autograd.Function):
 
 
 def token_mean(x):
-    """[N, ..., C] -> fp32 [N, C]: mean over the middle dimensions."""
+    """[N, ..., C] -> fp32 [N, C]: mean over the middle dimensions (a [N, C] input has none: returned as fp32)."""
+    if x.dim() < 3:
+        return x.float()
     return _TokenMean.apply(x)
 
 
