@@ -116,7 +116,8 @@ typedef struct ClvDbiasGather {
     void* dtable;              /* float [rows][nH] */
     const void* index;         /* int32 table of clv_attn_dbias_index() */
     int64_t split_stride;
-    int32_t nkt, nH, N, nsplit, slot0, nslots, block_begin, pad;
+    int32_t nkt, nH, N, nsplit, slot0, nslots, block_begin, pad;    /* block_begin, pad: set by the batch call (block range;
+                                                                       heads per wave) — whatever the caller leaves there */
 } ClvDbiasGather;
 int clv_attn_dbias_gather_entry(const ClvAttnGeom* geom_host, void* work, float* dbias, ClvDbiasGather* out);
 int64_t clv_attn_dbias_partial_bytes(const ClvAttnGeom* geom_host);    /* size of ClvAttnGeom.work in mode 1 (see there) */
