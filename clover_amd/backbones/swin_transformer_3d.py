@@ -321,11 +321,14 @@ class BasicLayer(nn.Module):
                 # the reference wraps both halves of a block in checkpoint.checkpoint (:494-503): keep the block's
                 # input, drop its activations, recompute them in the backward.  The DropPath factors are the step's
                 # presets (_draw_drop_paths) and the Swin blocks have no dropout, so the recompute is exact; the
-                # kernel-side gradient sinks see ONE backward per layer as without it.  preserve_rng_state=False: the
-                # recompute draws nothing, and saving / restoring the generator state is illegal inside the engine's
-                # hipGraph capture.
+                # kernel-side gradient sinks see ONE backward per layer as without it.  preserve_rng_state=False when the
+                # block has no dropout (every Clover config: drop_rate 0): the recompute then draws nothing, and saving /
+                # restoring the generator state is illegal inside the engine's hipGraph capture.  With
+                # drop_rate > 0 the block's nn.Dropout layers DO draw: the recompute must see the forward's generator
+                # state or the backward differentiates other masks than the forward applied.
+                draws = blk.mlp.drop.p > 0 or blk.attn.proj_drop.p > 0
                 x, branch, bscale = _checkpoint.checkpoint(blk.forward_pending, x, branch, bscale, use_reentrant=False,
-                                                           preserve_rng_state=False)
+                                                           preserve_rng_state=draws)
             else:
                 x, branch, bscale = blk.forward_pending(x, branch, bscale)
         return x, branch, bscale
@@ -487,14 +490,20 @@ class SwinTransformer3D(nn.Module):
             return
         if getattr(self, '_dp_mods', None) is None:
             self._dp_mods = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0]
-            self._dp_keep = None
+            self._dp_tables = {}
         if not self._dp_mods:
             return
-        if self._dp_keep is None or self._dp_keep.device != device or self._dp_keep.shape[1] != B:
+        # One (keep probabilities [n, B], 1 / keep [n, 1]) pair per (device, B), NEVER evicted: a captured hipGraph bakes the
+        # address of the table its bernoulli launch reads, and the engine keeps one set of graphs per batch geometry
+        # (engine.step -> capture / _activate) — a single slot re-keyed on B freed the table the first geometry's graph
+        # still read when a second per-rank B came along (tests/test_engine_gpu.py::test_graphs_per_batch_geometry
+        # replays the first geometry after capturing a second with another B).
+        key = (str(device), int(B))
+        tab = self._dp_tables.get(key)
+        if tab is None:
             keep = torch.tensor([1.0 - m.drop_prob for m in self._dp_mods], device=device)[:, None]
-            self._dp_keep = keep.expand(len(self._dp_mods), B).contiguous()       # per-element Bernoulli probabilities
-            self._dp_inv = 1.0 / keep
-        scales = torch.bernoulli(self._dp_keep) * self._dp_inv                    # two kernels (was rand, <, cast, /)
+            tab = self._dp_tables[key] = (keep.expand(len(self._dp_mods), B).contiguous(), 1.0 / keep)
+        scales = torch.bernoulli(tab[0]) * tab[1]                                 # two kernels (was rand, <, cast, /)
         for i, m in enumerate(self._dp_mods):
             m.preset(scales[i])
 

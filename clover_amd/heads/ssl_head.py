@@ -27,14 +27,22 @@ def _norm(dim, ln):
     return LayerNorm(dim) if ln else BatchNorm1d(dim)
 
 
-def _per_pass(fn, x, passes, order):
+def _per_pass(fn, x, passes, order, live=None):
     """Apply fn to the row blocks of a batch that stacks `passes` forward passes of the reference, one block at a time in
     the reference's call order: BatchNorm statistics (and their running averages) are per CALL there — the clean and the
-    masked clips, the un-masked and the masked captions each go through the head on their own (:102, :150, :159)."""
+    masked clips, the un-masked and the masked captions each go through the head on their own (:102, :150, :159).
+    live: the blocks the reference really runs under the current ablation switches (None = all).  The others are still
+    computed (their slot of the packed embeddings exists), but with the BatchNorm layers' running statistics frozen: the
+    reference never shows those inputs to the layer."""
+    from ..nn import BatchNorm1d as _BN
     blocks = list(x.chunk(passes, dim=0))
     outs = [None] * passes
     for i in (order if order is not None else range(passes)):
-        outs[i] = fn(blocks[i])
+        if live is not None and i not in live:
+            with _BN.frozen_stats():
+                outs[i] = fn(blocks[i])
+        else:
+            outs[i] = fn(blocks[i])
     return torch.cat(outs, dim=0)
 
 
@@ -73,7 +81,7 @@ class NCEHeadForMM(nn.Module):
     def forward(self, img, text, text_mask=None, token_ids=None):
         return self.forward_vision(img), self.forward_text(text, text_mask, token_ids)
 
-    def forward_vision(self, img, channels_last=False, passes=1, order=None):
+    def forward_vision(self, img, channels_last=False, passes=1, order=None, live=None):
         """img [N,C,T,h,w] (reference layout) or [N,T,h,w,C] with channels_last=True -> [N,vts] fp32.
         passes > 1: the batch stacks that many forward passes of the reference (the recognizer's doubled clean + masked
         pass); a BatchNorm projector then runs per pass (see _per_pass), a LayerNorm one does not care."""
@@ -84,10 +92,10 @@ class NCEHeadForMM(nn.Module):
         if self.dropout is not None:
             img = self.dropout(img)
         if passes > 1 and not self.ln:
-            return _per_pass(self.img_projector, img, passes, order).float()
+            return _per_pass(self.img_projector, img, passes, order, live).float()
         return self.img_projector(img).float()
 
-    def forward_text(self, text, text_mask=None, token_ids=None, passes=1, order=None):
+    def forward_text(self, text, text_mask=None, token_ids=None, passes=1, order=None, live=None):
         if self.text_agg_type == 'avg':
             text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
             text = text[:, 1:].float()
@@ -99,7 +107,7 @@ class NCEHeadForMM(nn.Module):
             text_mask = torch.where(token_ids != 102, text_mask, torch.zeros_like(text_mask))
             text = (text[:, 1:].float() * text_mask[:, 1:].unsqueeze(-1)).max(dim=1)[0]
         if passes > 1 and self.text_bn:
-            return _per_pass(self.text_projector, text, passes, order).float()
+            return _per_pass(self.text_projector, text, passes, order, live).float()
         return self.text_projector(text).float()
 
 

@@ -51,13 +51,33 @@ class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose forward is the HIP kernel; [B, D] rows only
     (the projection heads' use, ssl_head.py:52,56,60,175-186)."""
 
+    _frozen = 0          # > 0 inside BatchNorm1d.frozen_stats(): batch statistics are used, the running ones are not touched
+
+    @classmethod
+    def frozen_stats(cls):
+        """Context: training-mode calls normalise with their batch statistics but leave running_mean / running_var /
+        num_batches_tracked alone — for a pass the reference does not run (the recognizer's doubled clean + masked batch
+        under an ablation switch): its outputs are computed, its inputs never reach the layer's state."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            cls._frozen += 1
+            try:
+                yield
+            finally:
+                cls._frozen -= 1
+        return ctx()
+
     def forward(self, x):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('BatchNorm1d(momentum=None / affine=False / track_running_stats=False)')
-        if self.training:
+        frozen = BatchNorm1d._frozen > 0
+        if self.training and not frozen:
             self.num_batches_tracked.add_(1)
+        # momentum 0: running = 1 * running + 0 * batch — exactly unchanged
         return ops.batch_norm1d(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                self.momentum, self.eps)
+                                0.0 if frozen else self.momentum, self.eps)
 
 
 class GELU(nn.Module):

@@ -125,7 +125,7 @@ def _attn_work(g, backward):
 
 
 def roofline_from_prof(prof, steps):
-    """-> (roofline dict of the dominant instrumented KERNEL, per-kernel table).  Keys are device
+    """-> (roofline dict of the dominant instrumented KERNEL, per-kernel table, roofline dict of the runner-up).  Keys are device
     kernel names (as rocprofv3 --stats prints them); a kernel launched with many shapes is aggregated:
     achieved = sum(algorithmic work) / sum(duration), avg_us = mean launch duration."""
     rows = []
@@ -135,36 +135,48 @@ def roofline_from_prof(prof, steps):
                          total_ms_per_step=sum(ms) / steps, secs=sum(ms) * 1e-3,
                          flops=sum(f for _, _, f, _ in evs), bytes=sum(b for _, _, _, b in evs)))
     rows.sort(key=lambda r: -r['total_ms_per_step'])
-    top = rows[0]
-    n = len(prof[top['kernel']])
-    t_hbm, t_mfma = top['bytes'] / 8.0e12, top['flops'] / 2.5e15
-    if t_hbm >= t_mfma:
-        roof = dict(bound='hbm', achieved=round(top['bytes'] / top['secs'] / 1e9, 1), peak=8000.0, unit='GB/s',
-                    frac=round(top['bytes'] / top['secs'] / 8.0e12, 4), traffic=None)
-    else:
-        roof = dict(bound='mfma', achieved=round(top['flops'] / top['secs'] / 1e12, 2), peak=2500.0, unit='TFLOP/s',
-                    frac=round(top['flops'] / top['secs'] / 2.5e15, 4), traffic=None)
-    roof['kernel'] = top['kernel']
-    roof['avg_us'] = round(top['avg_us'], 2)
-    roof['launches_per_step'] = round(top['launches_per_step'], 2)
-    roof['algorithmic_bytes_per_launch'] = int(top['bytes'] / n)
-    roof['algorithmic_flops_per_launch'] = int(top['flops'] / n)
+
+    def roof_of(top):
+        n = len(prof[top['kernel']])
+        t_hbm, t_mfma = top['bytes'] / 8.0e12, top['flops'] / 2.5e15
+        if t_hbm >= t_mfma:
+            roof = dict(bound='hbm', achieved=round(top['bytes'] / top['secs'] / 1e9, 1), peak=8000.0, unit='GB/s',
+                        frac=round(top['bytes'] / top['secs'] / 8.0e12, 4), traffic=None)
+        else:
+            roof = dict(bound='mfma', achieved=round(top['flops'] / top['secs'] / 1e12, 2), peak=2500.0, unit='TFLOP/s',
+                        frac=round(top['flops'] / top['secs'] / 2.5e15, 4), traffic=None)
+        roof['kernel'] = top['kernel']
+        roof['avg_us'] = round(top['avg_us'], 2)
+        roof['launches_per_step'] = round(top['launches_per_step'], 2)
+        roof['ms_per_step'] = round(top['total_ms_per_step'], 3)
+        roof['algorithmic_bytes_per_launch'] = int(top['bytes'] / n)
+        roof['algorithmic_flops_per_launch'] = int(top['flops'] / n)
+        return roof
+    roof = roof_of(rows[0])
+    # the runner-up too (bench.py prints it as `roofline_2`): the two largest kernels of the step are 2 % apart (the grouped
+    # weight-gradient launch and AdamW), so which one leads flips from box to box — a reader comparing rounds sees both
+    roof2 = roof_of(rows[1]) if len(rows) > 1 else None
     def frac_of(r):       # the same roofline arithmetic for every instrumented kernel: which roof bounds it, what fraction it reaches
         hb, mf = r['bytes'] / 8.0e12, r['flops'] / 2.5e15
         return ('hbm', round(r['bytes'] / r['secs'] / 8.0e12, 4)) if hb >= mf else ('mfma', round(r['flops'] / r['secs'] / 2.5e15, 4))
     table = [dict(kernel=r['kernel'], launches_per_step=round(r['launches_per_step'], 2),
                   avg_us=round(r['avg_us'], 2), ms_per_step=round(r['total_ms_per_step'], 3),
                   bound=frac_of(r)[0], frac=frac_of(r)[1]) for r in rows[:14]]
-    return roof, table
+    return roof, table, roof2
 
 
 # --------------------------------------------------------------------------- Linear
 def _wgrad_custom(M, N, K):
-    """Shapes the split-M kernel takes: token-parallel ones (huge M, small N x K — the library GEMM
-    under-fills the chip) and few-row ones (M <= 1024: one M-slice accumulated straight into the fp32
-    gradient, replacing library GEMM + fp32 add + column sum)."""
+    """Shapes the split-M weight-gradient kernels take: every Linear whose widths are multiples of 8 (16-byte row groups)
+    — token-parallel ones (huge M, small N x K), few-row ones (M <= 1024: one M-slice accumulated straight into the fp32
+    gradient), the 256 x 256-tile class for the large stage-3 / fusion outputs, and (round 6) what used to fall between
+    them: 1024 < M < 2048 rows (Swin stage 3 / the fusion encoder at per-GPU batch 1-4) and M >= 2048 with an output
+    beyond 2^20 elements whose widths are not multiples of 256 — M-slices of >= 256 rows on the 128 x 128 tiles.
+    CLOVER_WGRAD_HOLE=1 restores the rounds-1-5 dispatch (those shapes on the library GEMM) for A/B runs."""
     if N % 8 or K % 8:
         return False
+    if os.environ.get('CLOVER_WGRAD_HOLE', '0') != '1':
+        return True
     if M >= 2048 and N % 256 == 0 and K % 256 == 0 and os.environ.get('CLOVER_WGRAD_WIDE', '1') == '1':
         return True                        # 256 x 256 tiles in the grouped launch: also the large stage-3 / fusion outputs
     return M >= 2048 and N * K <= (1 << 20) or M <= 1024
@@ -300,6 +312,10 @@ class defer_folds:
                 fn()
             flush_ln_reduces(pending_ln or [])
             flush_dbias_gathers(pending_db or [])
+        else:
+            # a backward segment that raised: nothing deferred is launched, but whatever already runs on an auxiliary stream
+            # is joined and its operands released — _AUX_HOLD must not carry entries into the next segment
+            join_aux_streams()
         return False
 
 
@@ -1961,6 +1977,9 @@ def patch_embed_stacked(x, weight, bias, gamma, beta, mask_token, vmask, eps=1e-
 
 
 # --------------------------------------------------------------------------- MLM decoder (vocabulary projection)
+MLM_DECODER_STATS = dict(in_place=0, copied=0)      # which way _MLMDecoder.backward took its gradient (tests read it)
+
+
 class _MLMDecoder(torch.autograd.Function):
     """scores [R, V] = x [R, H] . W[V, H]^T + b — BertLMPredictionHead.decoder (mlm_itm_head.py:38-41; V = 30522) on the
     step's own GEMM kernels.  V is not a multiple of 8, so every operand is used in its PHANTOM-PADDED form (engine:
@@ -1969,52 +1988,80 @@ class _MLMDecoder(torch.autograd.Function):
     same way, padding columns zeroed, so that
         dx  = d scores [R, Vp] . W^T-shadow [H, Vp]^T      (clv_gemm_nt, K slices: the contraction is the vocabulary)
         dW += d scores^T x                                  (the few-row weight-gradient kernel, into the padded slab view)
-    run over Vp with no edge code and no copy.  Engine-managed parameters only (the caller checks)."""
+    run over Vp with no edge code and no copy.  Engine-managed parameters carry the padded views (slab slots with phantom
+    rows); for a model WITHOUT an engine (round 6: the parity tests, tools/test.py) the padded bf16 operands are built per
+    call and the gradients come back to autograd as the [V, H] / [V] slices of padded fp32 temporaries — the same kernels
+    either way, never the library GEMM."""
 
     @staticmethod
     def forward(ctx, x2, weight, bias):
         _need_gpu(x2, weight)
-        Wp, bp = weight._clv_pad_shadow, bias._clv_pad_weight
-        Vp, V = Wp.shape[0], weight.shape[0]
+        V = weight.shape[0]
+        ctx.engine = hasattr(weight, '_clv_pad_shadow')
+        if ctx.engine:
+            Wp, bp = weight._clv_pad_shadow, bias._clv_pad_weight
+        else:
+            Vp_ = V + (-V % 64)
+            Wp = torch.zeros(Vp_, weight.shape[1], device=weight.device, dtype=BF16)
+            Wp[:V].copy_(weight.detach())
+            bp = torch.zeros(Vp_, device=weight.device, dtype=torch.float32)
+            bp[:V].copy_(bias.detach())
+        Vp = Wp.shape[0]
         R = x2.shape[0]
         xb = _c(x2 if x2.dtype == BF16 else x2.to(BF16))
         buf = torch.empty(R, Vp, device=x2.device, dtype=BF16)
         gemm_nt(xb, Wp, bp, epilogue=GEMM_EPI_BIAS, out=buf)
-        ctx.save_for_backward(xb)
+        ctx.save_for_backward(xb, *(() if ctx.engine else (Wp,)))
         ctx.refs = (weight, bias)
+        ctx.Vp = Vp
         return buf[:, :V]
 
     @staticmethod
     def backward(ctx, dy):
-        (xb,) = ctx.saved_tensors
+        xb, *rest = ctx.saved_tensors
         weight, bias = ctx.refs
-        Vp, V = weight._clv_pad_shadow.shape[0], weight.shape[0]
+        Vp, V = ctx.Vp, weight.shape[0]
         R = xb.shape[0]
-        if (dy.dtype == BF16 and dy.stride() == (Vp, 1) and dy.storage_offset() == 0
-                and dy.untyped_storage().nbytes() >= R * Vp * 2):
-            # a [R, V] view of a [R, Vp] buffer (the focal backward writes rows of the scores' stride): contract over it in
-            # place.  Its Vp - V padding columns are cleared HERE, whoever produced the buffer (6 columns: one small fill;
-            # round 4 trusted a global set of data_ptr values for "already zeroed" — a stale entry could have let the GEMM
-            # contract over garbage, ADVICE r4)
-            dyp = dy.as_strided((R, Vp), (Vp, 1))
+        base = getattr(dy, '_base', None)
+        if (dy.dtype == BF16 and dy.stride() == (Vp, 1) and dy.storage_offset() == 0 and base is not None
+                and tuple(base.shape) == (R, Vp) and getattr(base, '_clv_dscores_pad', 0) == Vp):
+            # the [R, V] view of the [R, Vp] gradient buffer the focal backward allocated for THIS purpose (it marks the
+            # buffer: ``_clv_dscores_pad``; ADVICE r5 — any other [R, Vp]-strided view, e.g. one of the live scores buffer,
+            # takes the copy path below and is never written): contract over it in place, padding columns cleared here
+            dyp = base
+            MLM_DECODER_STATS['in_place'] += 1
             if Vp > V:
                 dyp[:, V:].zero_()
         else:
+            MLM_DECODER_STATS['copied'] += 1
             dyp = torch.zeros(R, Vp, device=dy.device, dtype=BF16)
             dyp[:, :V].copy_(dy)
-        dx = gemm_nt(dyp, weight._clv_pad_shadow_t) if ctx.needs_input_grad[0] else None
-        linear_wgrad(dyp, xb, True, weight._clv_pad_grad, bias._clv_pad_grad)
-        weight._clv_ready()
-        bias._clv_ready()
-        return dx, None, None
+        if ctx.engine:
+            dx = gemm_nt(dyp, weight._clv_pad_shadow_t) if ctx.needs_input_grad[0] else None
+            linear_wgrad(dyp, xb, True, weight._clv_pad_grad, bias._clv_pad_grad)
+            weight._clv_ready()
+            bias._clv_ready()
+            return dx, None, None
+        Wp = rest[0]
+        dx = gemm_nt(dyp, Wp.t().contiguous()) if ctx.needs_input_grad[0] else None
+        global WGRAD_DEFER
+        hold, WGRAD_DEFER = WGRAD_DEFER, None            # autograd needs these gradients NOW: never into a deferred group
+        try:
+            dwp, dbp = linear_wgrad(dyp, xb, True)
+        finally:
+            WGRAD_DEFER = hold
+        return dx, dwp[:V].to(weight.dtype), dbp[:V].to(bias.dtype)
 
 
 def mlm_decoder_ok(x, weight, bias):
-    """The own-kernel decoder needs the engine's phantom-padded views of both parameters (and is not the parity path)."""
-    return (not parity.enabled() and x.is_cuda and bias is not None
-            and all(hasattr(weight, a) for a in ('_clv_pad_shadow', '_clv_pad_shadow_t', '_clv_pad_grad'))
-            and hasattr(bias, '_clv_pad_weight') and hasattr(bias, '_clv_pad_grad')
-            and os.environ.get('CLOVER_OWN_DECODER', '1') == '1')
+    """The own-kernel decoder: engine-managed parameters bring their phantom-padded views; without an engine the padded
+    operands are built per call (hidden width a multiple of 64: whole GEMM stages).  Not the parity path."""
+    if parity.enabled() or not x.is_cuda or bias is None or os.environ.get('CLOVER_OWN_DECODER', '1') != '1':
+        return False
+    if all(hasattr(weight, a) for a in ('_clv_pad_shadow', '_clv_pad_shadow_t', '_clv_pad_grad')):
+        return hasattr(bias, '_clv_pad_weight') and hasattr(bias, '_clv_pad_grad')
+    return (not hasattr(weight, '_clv_pad_shadow') and weight.shape[1] % 64 == 0 and weight.shape[1] >= 64
+            and x.shape[-1] == weight.shape[1])
 
 
 def mlm_decoder(x, weight, bias):
@@ -2089,6 +2136,8 @@ class _FocalCE(torch.autograd.Function):
         ld = lg.stride(0)
         dl = _c(dloss.float().reshape(1))
         buf = torch.empty(rows, ld, device=lg.device, dtype=lg.dtype)         # same row stride as the scores
+        if ld > V:
+            buf._clv_dscores_pad = ld          # "a padded d-scores buffer nobody else reads": _MLMDecoder.backward may use it in place
         check(_lib.lib().clv_focal_ce_bwd_ld(_ptr(lg), int(lg.dtype == BF16), _ptr(lab), _ptr(row_ce), _ptr(row_lse),
                                              _ptr(count), _ptr(dl), _ptr(buf), rows, V, ld, ctx.gamma, _stream()),
               'clv_focal_ce_bwd_ld')

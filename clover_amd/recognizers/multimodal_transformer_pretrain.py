@@ -99,6 +99,12 @@ class CloverPretrain(BaseRecognizer):
         #   text   text_out = [masked caption (:110)  ; un-masked caption (:99)]
         # so that row block 0 of the fusion pass is t_fusion = (clean video, masked text) (:119) and row block 1 is
         # v_fusion = (masked video, clean text) (:117) with both inputs used exactly as the encoders produced them.
+        # which block of a doubled projection-head pass the reference itself runs (BatchNorm variants keep the running
+        # statistics of the others frozen): the masked caption only with mlm_ssl_V_head (:147-150), the masked clip only with
+        # symmetry_rank (:155-159)
+        text_live = (1,) + ((0,) if self.mlm_ssl_V_head is not None else ())
+        vis_live = (0,) + ((1,) if self.symmetry_rank else ())
+
         def text_inputs():
             input_ssl_ids = torch.where(mlm_label == -100, token_ids, mlm_label)
             return torch.cat([token_ids, input_ssl_ids], 0), torch.cat([text_input_mask, text_input_mask], 0)
@@ -109,7 +115,7 @@ class CloverPretrain(BaseRecognizer):
             with torch.cuda.stream(side):
                 text_ids2, text_mask2 = text_inputs()        # the text tower's own input glue: off the video encoder's stream
                 text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
-                txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0))   # :150 / :102, also text-only
+                txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0), live=text_live)   # :150 / :102, also text-only
                 fusion_prep = None
                 if os.environ.get('CLOVER_HEADS_SIDE', '1') == '1' and hasattr(self.multimodal_backbone, 'prepare'):
                     # the video-independent part of the fusion encoder's input (text + type embeddings, position table,
@@ -135,7 +141,7 @@ class CloverPretrain(BaseRecognizer):
         else:
             text_ids2, text_mask2 = text_inputs()
             text_out = self._cut(self.text_backbone(text_ids2, text_mask2)['last_hidden_state'], text_cut)
-            txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0))   # (reference order: un-masked :102, masked :150)
+            txt_emb_both = self.ssl_head.forward_text(text_out, passes=2, order=(1, 0), live=text_live)   # (reference order: un-masked :102, masked :150)
             fusion_prep = None
 
         # ---- contrastive projections (:102, :150, :159); unbind of a [2, B, ..] view: its backward is one stack.
@@ -147,9 +153,9 @@ class CloverPretrain(BaseRecognizer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 vis_both.record_stream(side)
-                vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2)
+                vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2, live=vis_live)
         else:
-            vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2)
+            vis_emb_both = self.ssl_head.forward_vision(vis_both, channels_last=True, passes=2, live=vis_live)
         mask_word_emb, text_emb = txt_emb_both.view(2, B, -1).unbind(0)
 
         # ---- fusion: block 0 = t_fusion (clean video, masked text) (:119); block 1 = v_fusion (masked video,

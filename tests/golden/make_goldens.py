@@ -7,8 +7,8 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, dist, inflate, test, finetune, full (benchmark shapes:
-~10 minutes and ~40 GB on 8 cores; not part of the default list).
+Sets: idx, swin, bert_fuse, heads_loss, step, mid (VideoSwin-T stage widths: the HIP GEMMs' shapes), dist, inflate, test, finetune, full (benchmark shapes:
+~10 minutes and ~40 GB on 8 cores; not part of the default list), full8 (config 2 at the benchmark's batch of 8).
 """
 import json
 import os
@@ -44,11 +44,11 @@ def save(fname, out):
     print(f'wrote {fname}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB')
 
 
-def ref_model(drop=0.0):
+def ref_model(drop=0.0, cfg=None):
     H.make_bert_dir(SCRATCH, hidden=cf.TINY_BERT['hidden_size'], layers=cf.TINY_BERT['num_hidden_layers'],
                     heads=cf.TINY_BERT['num_attention_heads'], inter=cf.TINY_BERT['intermediate_size'],
                     vocab=cf.TINY_BERT['vocab_size'], max_pos=cf.TINY_BERT['max_position_embeddings'])
-    cfg = cf.tiny_model_cfg(drop)
+    cfg = cfg if cfg is not None else cf.tiny_model_cfg(drop)
     # the reference classes take bert_config only through **kwargs (ignored); MLMHead has no kwargs
     m = H.build_reference_model(cfg, SCRATCH)
     manifest = {k: list(v.shape) for k, v in m.state_dict().items()}
@@ -265,6 +265,77 @@ def gen_step():
     save('g_step.npz', out)
 
 
+MID_GRAD_KEYS = ['backbone.patch_embed.proj.weight', 'backbone.mask_token',
+                 'backbone.layers.0.blocks.0.attn.qkv.weight', 'backbone.layers.0.blocks.0.attn.proj.weight',
+                 'backbone.layers.0.blocks.1.mlp.fc1.weight', 'backbone.layers.0.blocks.1.mlp.fc2.weight',
+                 'backbone.layers.0.blocks.1.norm2.weight',
+                 'backbone.layers.0.blocks.1.attn.relative_position_bias_table',
+                 'backbone.layers.0.downsample.reduction.weight',
+                 'backbone.layers.1.blocks.0.attn.qkv.weight', 'backbone.layers.1.blocks.1.attn.proj.weight',
+                 'backbone.layers.1.blocks.0.mlp.fc1.weight', 'backbone.layers.1.blocks.1.mlp.fc2.weight',
+                 'backbone.layers.1.blocks.1.mlp.fc2.bias',
+                 'text_backbone.bert.encoder.layer.1.attention.self.query.weight',
+                 'text_backbone.bert.encoder.layer.0.intermediate.dense.weight',
+                 'text_backbone.bert.encoder.layer.1.output.dense.weight',
+                 'multimodal_backbone.fc_in.weight',
+                 'multimodal_backbone.bert_encoder.layer.0.intermediate.dense.weight',
+                 'multimodal_backbone.bert_encoder.layer.1.attention.output.dense.weight',
+                 'mlm_head.predictions.transform.dense.weight', 'mlm_head.predictions.decoder.weight',
+                 'ssl_head.img_projector.0.weight']
+
+
+def gen_mid():
+    """cf.mid_model_cfg (VideoSwin-T's stage-0 / 1 widths + BERT-tiny: every Linear on the HIP GEMM kernels): the
+    reference's backbone activations (per block, clean + masked), its step losses and 23 parameter gradients at B = 2, 4."""
+    m, manifest = ref_model(cfg=cf.mid_model_cfg())
+    m.eval()
+    H.init_dist_single()
+    out = {}
+    with open(os.path.join(HERE, 'manifest_mid.json'), 'w') as f:
+        json.dump(manifest, f, indent=0)
+    bb = m.backbone
+    batch = cf.cf_batch(2, tag='mid.swin')
+    x, vm = batch['imgs'][:, 0], batch['v_token_mask']
+    taps = {}
+    hooks = [bb.patch_embed.register_forward_hook(lambda mod, a, o: taps.__setitem__('patch_embed', o))]
+    for i, layer in enumerate(bb.layers):
+        for j, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(
+                lambda mod, a, o, k=f'layers.{i}.blocks.{j}': taps.__setitem__(k, o)))
+    with torch.no_grad():
+        y = bb(x)
+        for k, v in taps.items():
+            pack(out, 'swin.clean.' + k, v)
+        pack(out, 'swin.clean.out', y)
+        taps.clear()
+        ym, _ = bb(x.clone(), vm)
+        pack(out, 'swin.masked.out', ym)
+    for h in hooks:
+        h.remove()
+    b3 = cf.cf_batch(3, tag='mid.bf')
+    ids, mask = b3['token_ids'][:, 0], b3['input_mask'][:, 0]
+    with torch.no_grad():
+        t = m.text_backbone(ids, mask)['last_hidden_state']
+        full(out, 'bert.last_hidden_state', t)
+        vt = cf.cf_float('mid.bf.vt', (3, 2, 196, 192), 1.0)
+        f = m.multimodal_backbone(visual_token=vt, text_input_mask=mask, text_input_embeds=t)
+        full(out, 'fuse.t_last_hidden_state', f['t_last_hidden_state'])
+        pack(out, 'fuse.v_last_hidden_state', f['v_last_hidden_state'])
+    for B in [2, 4]:
+        batch = cf.cf_batch(B, tag=f'mid.step{B}')
+        m.zero_grad()
+        loss, lv = _step(m, batch)
+        loss.backward()
+        for k, v in lv.items():
+            out[f'B{B}.{k}'] = np.float64(v)
+        named = dict(m.named_parameters())
+        for k in MID_GRAD_KEYS:
+            pack(out, f'B{B}.grad.{k}', named[k].grad)
+        out[f'B{B}.n_unused'] = np.int64(sum(p.grad is None for p in named.values()))
+        print('mid', B, {k: round(float(v), 5) for k, v in lv.items()})
+    save('g_mid.npz', out)
+
+
 def gen_test():
     """forward_test(separate_test=True) of the reference (:194-218): video / text embeddings for retrieval."""
     m, _ = ref_model()
@@ -434,7 +505,7 @@ FULL_GRAD_KEYS = {
 }
 
 
-def gen_full():
+def gen_full(cases=(('T', 8), ('B', 32)), B=2, fname='g_full.npz'):
     """The REAL reference at benchmark shapes: VideoSwin-T + BERT-base, 8 frames (BASELINE config 2)
     and VideoSwin-B + BERT-base, 32 frames (config 5's model and clip length), 224^2, 32 tokens, B = 2 — on exactly the
     weights (seed-4321 init of the registered modules) and batch (bench.synthetic_batch seed 77) that
@@ -448,7 +519,7 @@ def gen_full():
     H.make_bert_dir(SCRATCH + '_base', hidden=768, layers=12, heads=12, inter=3072, vocab=30522, max_pos=512)
     H.init_dist_single()
     out = {}
-    for variant, frames in (('T', 8), ('B', 32)):
+    for variant, frames in cases:
         tag = f'{variant}{frames}'
         cfg = bench.model_cfg(variant, frames)
         torch.manual_seed(4321)
@@ -463,7 +534,7 @@ def gen_full():
         assert all('relative_position_index' in k or 'position_ids' in k for k in missing), missing[:5]
         assert not unexpected, unexpected[:5]
         m.eval()
-        batch = bench.synthetic_batch(2, frames, 32, seed=77)
+        batch = bench.synthetic_batch(B, frames, 32, seed=77)
         torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
         t0 = time.time()
         loss, lv = _step(m, batch)
@@ -477,13 +548,19 @@ def gen_full():
             pack(out, f'{tag}.grad.{k}', named[k].grad)
         print(tag, {k: round(float(v), 6) for k, v in lv.items()}, 'seconds', out[f'{tag}.ref_seconds_fwd_bwd'])
         del m, named, loss
-    save('g_full.npz', out)
+    save(fname, out)
+
+
+def gen_full8():
+    """BASELINE config 2 at the BENCHMARK's batch: VideoSwin-T + BERT-base, 8 clips x 8 frames x 224^2, 32 tokens — the shapes
+    bench.py times (tests/test_step_gpu.py::test_bench_shapes_step_matches_reference; VERDICT r5 item 1)."""
+    gen_full(cases=(('T', 8),), B=8, fname='g_full_b8.npz')
 
 
 SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
-            step=gen_step, dist=gen_dist, inflate=gen_inflate, test=gen_test, finetune=gen_finetune)
+            step=gen_step, mid=gen_mid, dist=gen_dist, inflate=gen_inflate, test=gen_test, finetune=gen_finetune)
 
-HEAVY = dict(full=gen_full)      # only on request
+HEAVY = dict(full=gen_full, full8=gen_full8)      # only on request
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SETS)

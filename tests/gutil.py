@@ -13,8 +13,8 @@ def load(name):
     return np.load(os.path.join(GOLD, name))
 
 
-def manifest():
-    with open(os.path.join(GOLD, 'manifest_tiny.json')) as f:
+def manifest(which='tiny'):
+    with open(os.path.join(GOLD, f'manifest_{which}.json')) as f:
         return json.load(f)
 
 

@@ -329,6 +329,37 @@ def test_graphs_per_batch_geometry():
         assert abs(a - g) < 0.05 * max(1.0, abs(a)), traj
 
 
+def test_drop_path_tables_survive_a_second_batch_size():
+    """in train mode every captured forward graph bakes the address of the DropPath keep-probability
+    table its bernoulli launch reads.  A second batch geometry with ANOTHER per-rank B must not free / replace the table
+    of the first one: tables are kept per (device, B) for the life of the module, the first geometry's graphs replay on
+    the very same memory after the second capture, and its DropPath factors stay in {0, 1 / keep}."""
+    import clover_amd
+    from clover_amd.engine import CloverEngine
+    m = clover_amd.build_model(cf.tiny_model_cfg(drop=0.2))
+    m.load_state_dict(cf.cf_state(gutil.manifest()), strict=False)
+    m = m.to(DEV).train()
+    b2, b3 = batch(2, 'dp2'), batch(3, 'dp3')
+    eng = CloverEngine(m, b2, lr=1e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+    assert eng.capture(b2)
+    bb = m.backbone
+    keys0 = dict(bb._dp_tables)
+    assert len(keys0) == 1                                   # the doubled clean + masked pass: one table for 2B samples
+    (key0, (keep0, inv0)), = keys0.items()
+    ptr0 = keep0.data_ptr()
+    eng.step(b2)
+    eng.step(b3)                                             # captures the second geometry (another B)
+    assert len(eng._captures) == 2 and len(bb._dp_tables) == 2
+    assert bb._dp_tables[key0][0] is keep0 and keep0.data_ptr() == ptr0          # not replaced, not freed
+    expect = keep0.clone()
+    for _ in range(3):
+        lv = eng.step(b2)['log_vars']                        # replays the FIRST geometry's graphs
+        assert all(v == v and abs(v) < 1e4 for v in (float(x) for x in lv.values())), dict(lv)
+        eng.step(b3)
+    torch.cuda.synchronize()
+    assert torch.equal(keep0, expect) and float(keep0.min()) > 0.5        # the table the first graphs read is intact
+
+
 def make_finetune_model():
     import clover_amd
     m = clover_amd.build_model(cf.tiny_finetune_cfg())
@@ -751,6 +782,7 @@ def test_first_touch_slots_across_a_geometry_switch(mode, monkeypatch):
         assert torch.allclose(final['0'][n], final['1'][n], rtol=0, atol=1e-6), n
 
 
+@pytest.mark.usefixtures('strict_own_gemm')
 def test_engine_own_decoder_equals_plain_autograd():
     """BASELINE config 2's model (vocabulary 30522: not a multiple of 8) under the engine: the MLM decoder runs on the own
     GEMM kernels over phantom-padded parameters (engine._Segment, ops.mlm_decoder); losses and the decoder / transform /

@@ -166,6 +166,7 @@ FP8_LOSS_TOL = dict(mlm_loss=1e-2, nce_loss=5e-2, rank_t_tm_loss=1.2e-1, v_nce_l
 FP8_GRAD_TOL = 0.30         # measured <= 17.5 % (e4m3 operands carry 2^-4 relative rounding)
 
 
+@pytest.mark.usefixtures('strict_own_gemm')
 @pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16), ('B', 32)])
 def test_fp8_step_losses_vs_oracle(variant, frames, monkeypatch):
     """The step with fp8 forward GEMMs (Swin stages 0-3, text tower, fusion encoder) against the fp32 oracle, B = 2, eval

@@ -250,3 +250,42 @@ def test_oracle_matches_reference_at_config5_model_and_clip_length():
         _, lv = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
     for k in ('mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss'):
         assert abs(float(lv[k]) - float(g[f'B32.{k}'])) <= 2e-5 * max(1.0, abs(float(g[f'B32.{k}']))), (k, float(lv[k]), float(g[f'B32.{k}']))
+
+
+def test_oracle_matches_reference_at_the_benchmark_batch():
+    """g_full_b8.npz (make_goldens.py full8): the real reference at BASELINE config 2 with the BENCHMARK's batch of 8 clips
+    (the shapes bench.py times; tests/test_step_gpu.py::test_bench_shapes_step_matches_reference compares the HIP step with
+    this file directly).  The oracle's forward reproduces the six losses — the bench's `loss_abs_err_vs_oracle` and the
+    cpu_baseline leg run the oracle at these widths."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    g = gutil.load('g_full_b8.npz')
+    torch.manual_seed(4321)
+    cfg = bench.model_cfg('T', 8)
+    m = clover_amd.build_model(cfg).eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items() if 'relative_position_index' not in k}
+    del m
+    batch = bench.synthetic_batch(8, 8, 32, seed=77)
+    with torch.no_grad():
+        _, lv = om.parse_losses(om.forward_train(P, batch, bench.oracle_cfg(cfg), gather=False))
+    for k in ('mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss'):
+        assert abs(float(lv[k]) - float(g[f'T8.{k}'])) <= 2e-5 * max(1.0, abs(float(g[f'T8.{k}']))), (k, float(lv[k]), float(g[f'T8.{k}']))
+
+
+@pytest.mark.parametrize('B', [2, 4])
+def test_oracle_step_at_mid_widths(B):
+    """g_mid.npz: the reference at VideoSwin-T's stage widths + BERT-tiny (cf.mid_model_cfg) — the oracle reproduces its
+    losses and the 23 stored gradients (the GPU tests compare the HIP kernels with the same file)."""
+    g = gutil.load('g_mid.npz')
+    cfg = cf.mid_model_cfg()
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in cf.cf_state(gutil.manifest('mid')).items()}
+    losses = om.forward_train(P, cf.cf_batch(B, tag=f'mid.step{B}'), cf.oracle_cfg_from(cfg), gather=False)
+    loss, lv = om.parse_losses(losses)
+    for k, v in lv.items():
+        assert abs(float(v) - float(g[f'B{B}.{k}'])) <= 2e-4 * max(1.0, abs(float(g[f'B{B}.{k}']))), (k, float(v))
+    loss.backward()
+    for n in [n[len(f'B{B}.grad.'):-4] for n in g.files if n.startswith(f'B{B}.grad.') and n.endswith('.sub')]:
+        gutil.assert_packed(g, f"B{B}.grad.{n}", P[n].grad, rtol=5e-3, atol=1e-6)

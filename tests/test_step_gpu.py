@@ -230,6 +230,76 @@ def test_forward_train_ablation_switches(model, switch):
     assert all(torch.isfinite(p.grad).all() for p in named.values() if p.grad is not None)
 
 
+# ----------------------------------------------------------------------------- the HIP GEMMs against reference goldens
+@pytest.fixture(scope='module')
+def mid_model():
+    """cf.mid_model_cfg: VideoSwin-T's stage-0 / 1 widths (96 / 192) + BERT-tiny — every Linear on the HIP GEMM kernels."""
+    import clover_amd
+    m = clover_amd.build_model(cf.mid_model_cfg())
+    missing, unexpected = m.load_state_dict(cf.cf_state(gutil.manifest('mid')), strict=False)
+    assert all('relative_position_index' in k for k in missing) and not unexpected
+    return m.to(DEV).eval()
+
+
+@pytest.mark.usefixtures('strict_own_gemm')
+def test_mid_modules_match_reference(mid_model):
+    """Reference-GENERATED activations at widths the HIP GEMMs take (config 1's 48 / 96 widths run their
+    Linear layers on the library): per-block Swin outputs (stage 0 on the fused row-streaming kernels, stage 1 on
+    clv_gemm_nt, the merge), the text tower and the fusion encoder — no library GEMM anywhere (strict_own_gemm)."""
+    g = gutil.load('g_mid.npz')
+    b = cf.cf_batch(2, tag='mid.swin')
+    x, vm = b['imgs'][:, 0].to(DEV), b['v_token_mask'].to(DEV)
+    bb = mid_model.backbone
+    taps = {}
+    hooks = []
+    for i, layer in enumerate(bb.layers):
+        for j, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(lambda mod, a, o, k=f'layers.{i}.blocks.{j}': taps.__setitem__(k, o)))
+    with torch.no_grad():
+        y = bb(x)
+        ym, _ = bb(x.clone(), vm)
+    for h in hooks:
+        h.remove()
+    assert rel_packed(g, 'swin.clean.out', y) < 3e-2 and rel_packed(g, 'swin.masked.out', ym) < 3e-2
+    b3 = cf.cf_batch(3, tag='mid.bf')
+    ids, mask = b3['token_ids'][:, 0].to(DEV), b3['input_mask'][:, 0].to(DEV)
+    with torch.no_grad():
+        t = mid_model.text_backbone(ids, mask)['last_hidden_state']
+        assert rel(t, g['bert.last_hidden_state']) < 2e-2
+        vt = cf.cf_float('mid.bf.vt', (3, 2, 196, 192), 1.0).to(DEV)
+        tt = torch.from_numpy(g['bert.last_hidden_state']).to(DEV)
+        f = mid_model.multimodal_backbone(visual_token=vt, text_input_mask=mask, text_input_embeds=tt)
+    assert rel(f['t_last_hidden_state'], g['fuse.t_last_hidden_state']) < 2e-2
+    assert rel_packed(g, 'fuse.v_last_hidden_state', f['v_last_hidden_state']) < 3e-2
+
+
+@pytest.mark.usefixtures('strict_own_gemm')
+@pytest.mark.parametrize('B', [2, 4])
+def test_mid_step_losses_and_grads(mid_model, B):
+    """The full train_step at the mid widths: six losses and 23 parameter gradients (every Linear family: fused stage-0
+    qkv / proj / fc1 / fc2, stage-1 GEMMs, merge, text tower, fc_in, fusion encoder, MLM transform / decoder, heads) against
+    the REFERENCE's own numbers (g_mid.npz), forward / input-gradient / weight-gradient GEMMs all on the HIP kernels."""
+    g = gutil.load('g_mid.npz')
+    batch = to_dev(cf.cf_batch(B, tag=f'mid.step{B}'))
+    mid_model.zero_grad(set_to_none=True)
+    out = mid_model.train_step(batch, None)
+    lv = out['log_vars']
+    errs = {k: abs(lv[k] - float(g[f'B{B}.{k}'])) for k in LOSS_KEYS}
+    print('mid loss errors', B, errs)
+    for k in LOSS_KEYS:
+        assert errs[k] <= LOSS_TOL[k], (k, lv[k], float(g[f'B{B}.{k}']))
+    out['loss'].backward()
+    named = dict(mid_model.named_parameters())
+    worst = {}
+    for k in [n[len(f'B{B}.grad.'):-4] for n in g.files if n.startswith(f'B{B}.grad.') and n.endswith('.sub')]:
+        worst[k] = rel_packed(g, f'B{B}.grad.{k}', named[k].grad)
+    print('mid grad rel errors', B, worst)
+    for k, e in worst.items():
+        assert e < grad_tol(k), (k, e)
+    assert sum(p.grad is None for p in named.values()) == int(g[f'B{B}.n_unused'])
+    mid_model.zero_grad(set_to_none=True)
+
+
 # ----------------------------------------------------------------------------- retrieval fine-tuning (SURVEY 8f-4)
 @pytest.fixture(scope='module')
 def ft_model():
@@ -315,6 +385,7 @@ FULL_GRAD_KEYS = {
 }
 
 
+@pytest.mark.usefixtures('strict_own_gemm')
 @pytest.mark.parametrize('variant,frames', [('T', 8), ('B', 16), ('B', 32)])
 def test_full_size_step_matches_oracle(variant, frames):
     """BASELINE config 2 (VideoSwin-T, 8 frames), config 4 (VideoSwin-B: embed_dim 128, heads [4,8,16,32], the
@@ -342,6 +413,52 @@ def test_full_size_step_matches_oracle(variant, frames):
         assert e < FULL_GRAD_TOL, (k, e)
 
 
+@pytest.mark.usefixtures('strict_own_gemm')
+@pytest.mark.parametrize('mode', ['graph', 'eager'])
+def test_bench_shapes_step_matches_reference(mode):
+    """BASELINE config 2 at the BENCHMARK's batch (VideoSwin-T + BERT-base + 3-layer fusion, 8 clips x 8 frames x 224^2,
+    32 tokens: the GEMM tile classes, split-K plans and weight-gradient groupings bench.py times — M = 200 704 / 50 176 /
+    12 544 / 3 136 / 3 648 / 512 rows — differ from the B = 2 ones) THROUGH THE ENGINE (slab sinks, first-touch stores,
+    deferred grouped weight gradients, phantom-padded MLM decoder; 'graph': the replayed hipGraphs the bench times),
+    eval mode: six losses and the seven FULL_GRAD_KEYS['T'] gradients against the REAL reference's numbers for the same
+    weights and batch (tests/golden/g_full_b8.npz, written by `make_goldens.py full8`; the oracle is pinned to the same
+    file by tests/test_oracle_golden.py).  Every GEMM on the HIP kernels (strict_own_gemm)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import clover_amd
+    from clover_amd.engine import CloverEngine
+    g = gutil.load('g_full_b8.npz')
+    torch.manual_seed(4321)
+    m = clover_amd.build_model(bench.model_cfg('T', 8)).eval().to(DEV)
+    batch = {k: v.to(DEV) for k, v in bench.synthetic_batch(8, 8, 32, seed=77).items()}
+    eng = CloverEngine(m, batch, lr=1e-4, weight_decay=0.005, grad_clip=15.0, max_iters=10 ** 6)
+    assert eng.first_touch_params > 100e6                       # the first-touch stores are part of what is checked
+    if mode == 'graph':
+        eng.capture(batch)
+        out = eng._graphed_forward_backward(batch)
+    else:
+        eng._ft.done.clear()
+        out = m.train_step(batch, None)
+        eng._backward(lambda: out['loss'].backward())
+    eng.finish_backward()
+    torch.cuda.synchronize()
+    lv = {k: float(out['log_vars'][k]) for k in LOSS_KEYS}
+    errs = {k: abs(lv[k] - float(g[f'T8.{k}'])) for k in LOSS_KEYS}
+    print(f'bench-shape (B = 8, {mode}) loss errors', errs)
+    for k in LOSS_KEYS:
+        assert errs[k] <= LOSS_TOL[k], (k, lv[k], float(g[f'T8.{k}']))
+    named = dict(m.named_parameters())
+    worst = {k: rel_packed(g, f'T8.grad.{k}', named[k].grad) for k in FULL_GRAD_KEYS['T']}
+    print(f'bench-shape (B = 8, {mode}) grad rel errors', worst)
+    for k, e in worst.items():
+        assert e < FULL_GRAD_TOL, (k, e)
+    from clover_amd import ops
+    assert ops.MLM_DECODER_STATS['in_place'] > 0               # the padded d-scores buffer is contracted over in place
+
+
+@pytest.mark.usefixtures('strict_own_gemm')
 def test_train_mode_step_is_finite_and_learns():
     """BASELINE config 2 shapes with model.train(): hidden dropout 0.1, attention-probability dropout 0.1 and DropPath
     0.1 all active inside the HIP kernels.  Twenty optimizer steps on one fixed batch: every loss finite, and the total
@@ -368,6 +485,7 @@ def test_train_mode_step_is_finite_and_learns():
     m.eval()
 
 
+@pytest.mark.usefixtures('strict_own_gemm')
 @pytest.mark.parametrize('frames', [16, 32])
 def test_long_clip_losses_match_oracle(frames):
     """16- and 32-frame clips (BASELINE configs 4 / 5 clip lengths; windows of 392 tokens; fusion sequences of 424 tokens
