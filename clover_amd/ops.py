@@ -521,6 +521,12 @@ def own_gemm_all():
     return os.environ.get('CLOVER_OWN_GEMM_ALL', '1') == '1'
 
 
+# Widest output clv_gemm_nt is handed by the Linear wrappers.  Up to 3072 columns the bias row sits in LDS; wider outputs
+# (VideoSwin-B's stage-3 MLP: 4096; round 6 — they used to fall to the library) read it from global memory in the epilogue,
+# as the MLM decoder's 30 528 columns always did.
+OWN_GEMM_MAX_N = 65536
+
+
 def own_gemm_ok(a, N, K):
     """Shapes that run on clv_gemm_nt (forward: a = x [M, K], N outputs; input gradient: a = dy, contraction = the layer's
     output width).  Device-side durations against the tuned library GEMM: tools/probes/gemm_bench.py (round 2: token-
@@ -528,10 +534,11 @@ def own_gemm_ok(a, N, K):
     long contractions with few tiles)."""
     M = a.shape[0]
     if not (os.environ.get('CLOVER_OWN_GEMM', '1') == '1' and a.is_cuda and a.dtype == BF16 and K % 64 == 0 and K >= 64
-            and 64 <= N <= 3072 and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0):
+            and 64 <= N <= OWN_GEMM_MAX_N and N % 8 == 0 and a.stride(1) == 1 and a.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0):
         return False
     if own_gemm_all():
-        return M >= 64
+        return M >= 1          # (round 6: few-row calls — a 3-caption text batch, 48 rows — used to leave for the library below 64)
     return M >= 8192 and K <= 576
 
 
@@ -540,7 +547,7 @@ def wants_transposed(out_features, in_features):
     (linear_dgrad: the row-streaming GEMM of the stage-0 widths, clv_gemm_nt otherwise)?  Modules flag such weights
     (``_clv_want_t``) and the engine keeps their bf16 transposes fresh."""
     if own_gemm_all():
-        return (out_features % 64 == 0 and 64 <= in_features <= 3072 and in_features % 8 == 0) or \
+        return (out_features % 64 == 0 and 64 <= in_features <= OWN_GEMM_MAX_N and in_features % 8 == 0) or \
                (in_features <= 128 and out_features <= 384)
     return out_features <= 576 or (in_features <= 128 and out_features <= 384)
 

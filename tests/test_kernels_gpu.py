@@ -585,7 +585,9 @@ def test_adamw_device_state_two_option_groups_and_skip():
 
 # ----------------------------------------------------------------------------- LDS-tiled GEMM + epilogues
 @pytest.mark.parametrize('M,N,K', [(12544, 1536, 384), (3136, 768, 3072), (3648, 2304, 768), (50176, 192, 192),
-                                   (1000, 576, 192), (130, 64, 64), (257, 200, 128), (4096, 1152, 384)])
+                                   (1000, 576, 192), (130, 64, 64), (257, 200, 128), (4096, 1152, 384),
+                                   (48, 512, 128), (17, 128, 512), (1, 64, 64),                  # fewer rows than a tile
+                                   (1568, 4096, 1024), (784, 4104, 1024), (1568, 1024, 4096)])   # N > 3072: bias from global memory (Swin-B stage 3)
 def test_gemm_nt_epilogues(M, N, K):
     """clv_gemm_nt against fp32 torch on the same bf16 operands: plain, bias, bias + GELU (pre-activation kept) and
     the GELU-backward epilogue; ragged M / N edges, both tile widths."""
@@ -660,7 +662,8 @@ def test_gemm_nt_split_k_and_rotation(M, N, K, splitk, rot, monkeypatch):
             assert (x.float() - y.float()).abs().max().item() <= 8e-3 * max(1.0, y.float().abs().max().item()), k
 
 
-@pytest.mark.parametrize('M,C,Hd', [(8192, 192, 768), (12544, 384, 1536), (9000, 128, 512)])
+@pytest.mark.usefixtures('strict_own_gemm')
+@pytest.mark.parametrize('M,C,Hd', [(8192, 192, 768), (12544, 384, 1536), (9000, 128, 512), (1568, 1024, 4096)])
 def test_linear_and_mlp_on_the_hip_gemm(M, C, Hd):
     """ops.linear / ops.mlp_gelu on shapes that take clv_gemm_nt (own_gemm_ok): forward, input gradient (through the
     transposed-weight operand) and parameter gradients against fp32 torch on the same bf16 operands."""

@@ -21,6 +21,11 @@ included — the contrastive terms move by a few 1e-3 between boxes / builds bec
     Swin-T 8 f full size, B = 2 (oracle)       8.9e-5   4.4e-3   4.7e-3     7.5e-3   1.3e-3     9.2e-3
     Swin-B 16 f full size, B = 2 (oracle)      1.5e-3   1.7e-3   3.6e-3     1.5e-2   4.8e-4     1.8e-2
     Swin-B 32 f full size, B = 2 (oracle)      2.0e-3   2.2e-3   6.7e-3     1.9e-3   1.9e-3     1.0e-2
+    round 6 (strict own GEMMs everywhere below; the three full-size rows above re-measured: 8.7e-5 .. 1.7e-2, unchanged):
+    Swin-T 8 f, B = 8 = the BENCH shapes,
+      engine + hipGraphs (reference golden)    1.9e-4   5.8e-3   4.1e-3     9.7e-4   6.1e-3     5.1e-3
+    mid widths 96 / 192, B = 2 (golden)        8.5e-4   5.9e-3   2.0e-3     1.4e-2   5.4e-4     6.1e-3
+    mid widths 96 / 192, B = 4 (golden)        1.4e-3   2.1e-3   2.9e-3     1.4e-2   4.5e-3     1.6e-2
     max, all rounds                            3.3e-3   9.6e-3   9.6e-3     1.64e-2  1.1e-2     1.84e-2
     LOSS_TOL = 1.5 x that                      5.0e-3   1.5e-2   1.5e-2     2.5e-2   1.7e-2     2.8e-2
 """
