@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -98,6 +98,9 @@ SIGNATURES = {
     'clv_rowgemm_supported': (C.c_int, [_i32, _i32, _i32]),
     'clv_rowgemm': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _f, _p]),
     'clv_rowgemm_xs': (C.c_int, [_p] * 11 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _f, _p, _i32, _p]),
+    'clv_mlp_fused_supported': (C.c_int, [_i32, _i32]),
+    'clv_mlp_fused_fwd': (C.c_int, [_p] * 10 + [_i64, _i32, _i32, _f, _p, _i32, _p]),
+    'clv_mlp_fused_bwd': (C.c_int, [_p] * 13 + [_i64, _i32, _i32, _p, _i32, _p]),
     'clv_colsum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p]),
     'clv_focal_ce_fwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),
     'clv_focal_ce_bwd': (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _f, _p]),

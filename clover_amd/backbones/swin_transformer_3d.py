@@ -119,6 +119,8 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
         for lin in (self.fc1, self.fc2):                 # engine keeps W^T where the input gradient's kernel takes it
             lin.weight._clv_want_t = ops.wants_transposed(lin.out_features, lin.in_features)
+        if ops.mlp_fused_shape(in_features, hidden_features) and out_features == in_features:
+            self.fc2.weight._clv_want_t = True           # the one-kernel MLP backward contracts d out with W2^T [hidden][C]
 
     def forward(self, x):
         if (type(self.act) is GELU and self.drop.p == 0.0 and self.fc1.bias is not None

@@ -88,9 +88,13 @@ __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned ro
 // 1 rcp + 1 exp + ~10 fma instead of libm's erff — matters where GELU sits in a GEMM epilogue.
 // Phi(x) = 0.5 (1 + erf(x / sqrt2)); with z = |x| / sqrt2:  erf(z) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p z),
 // and exp(-z^2) = exp(-x^2 / 2) is exactly the factor the derivative needs as well.
+// 1 / d as ONE v_rcp_f32 (1 ulp).  __frcp_rn expands to the IEEE division sequence (v_div_scale x 2, v_rcp, v_div_fmas,
+// v_div_fixup and five fma: ~10 VALU instructions) — in a GELU epilogue that was a quarter of the instructions per element.
+__device__ __forceinline__ float fast_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
     ex = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2) as ONE v_exp_f32 (no range fix-ups)
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
@@ -109,6 +113,33 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     gelu_parts(x, cdf, ex);
     return fmaf(x * 0.3989422804014327f, ex, cdf);
 }
+// For bf16 OUTPUTS (the one-kernel MLP, fused_mlp.hip: GELU is its VALU bound — 77 M evaluations per launch):
+// h(u) = 1 - Phi(u) = 0.5 erfc(u / sqrt2), u = min(|x|, 5.5), as exp2 of a degree-6 polynomial fit of log2 h on [0, 5.5]
+// (Chebyshev least squares; evaluated in fp32: |h - exact| <= 2.6e-5, relative 6.5e-5, |u (h - exact)| <= 3.3e-6 — three
+// orders below the bf16 rounding of the result; beyond 5.5 h stays at 1.9e-8).  ONE transcendental and 7 fma where the
+// Abramowitz-Stegun form above takes v_rcp + v_exp + 10: 13 VALU slots per element instead of 20.
+__device__ __forceinline__ float gelu_h(float x) {
+    const float u = fminf(fabsf(x), 5.5f);
+    float p = fmaf(2.641310222e-05f, u, -6.636010571e-04f);
+    p = fmaf(p, u, 7.492294232e-03f);
+    p = fmaf(p, u, -5.193681061e-02f);
+    p = fmaf(p, u, -4.604588278e-01f);
+    p = fmaf(p, u, -1.150443222e+00f);
+    p = fmaf(p, u, -1.000073591e+00f);
+    return __builtin_amdgcn_exp2f(p);
+}
+// GELU(x) = x Phi(x) = max(x, 0) - |x| h   (x >= 0: x (1 - h); x < 0: x h): no compare / select
+__device__ __forceinline__ float gelu_fast(float x) {
+    return fmaf(-fabsf(x), gelu_h(x), __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f));
+}
+// (GELU(x), GELU'(x)):  Phi(x) = 0.5 + copysign(0.5 - h, x),  GELU' = Phi + x phi,  phi = exp(-x^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ void gelu_fast_both(float x, float& act, float& grad) {
+    const float h = gelu_h(x);
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    const float cdf = 0.5f + copysignf(0.5f - h, x);
+    act = x * cdf;
+    grad = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 
 // Two-at-a-time versions on packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of polynomial per
 // instruction; rcp / exp2 / selects stay scalar) for the GELU epilogues of the GEMM kernels, whose VALU work otherwise
@@ -118,7 +149,7 @@ __device__ __forceinline__ void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& ex
     const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
     const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t){0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f},
                                                 (f32x2_t){1.0f, 1.0f});
-    const f32x2_t t = {__frcp_rn(d.x), __frcp_rn(d.y)};
+    const f32x2_t t = {fast_rcp(d.x), fast_rcp(d.y)};
     const f32x2_t xx = x * x * (f32x2_t){-0.72134752044448170f, -0.72134752044448170f};
     ex = (f32x2_t){__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
     f32x2_t poly = __builtin_elementwise_fma((f32x2_t){1.061405429f, 1.061405429f}, t, (f32x2_t){-1.453152027f, -1.453152027f});

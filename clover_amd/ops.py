@@ -937,6 +937,57 @@ def ln_linear(a, r, ln_weight, ln_bias, weight, bias, eps=1e-5, stream_out=False
     return _FusedLNLinear.apply(a, r, ln_weight, ln_bias, weight, bias, eps, stream_out)
 
 
+def mlp_fused_shape(C_, hidden):
+    """Widths of the one-kernel MLP (clv_mlp_fused_*: both weight matrices resident in LDS): VideoSwin-T's stage 0."""
+    return C_ == 96 and hidden == 384
+
+
+def mlp_fused_ok(a2, hidden):
+    """The one-kernel forward / backward of norm2 + Mlp (round 6) for a contiguous bf16 [M, 96] operand; CLOVER_FUSED_MLP=0
+    restores the two-kernel forward (LayerNorm + fc1 + GELU, fc2) that writes the hidden activations."""
+    return (os.environ.get('CLOVER_FUSED_MLP', '1') == '1' and not parity.enabled() and a2.is_cuda and a2.dtype == BF16
+            and a2.dim() == 2 and a2.is_contiguous() and mlp_fused_shape(a2.shape[1], hidden)
+            and a2.data_ptr() % 16 == 0)
+
+
+def mlp_fused_fwd(a2, r2, w1f, b1f, w2b, b2, eps=1e-5, xscale=None, rows_per_sample=1):
+    """Raw launcher of clv_mlp_fused_fwd (no autograd) -> dict(out, sum, mean, rstd)."""
+    _need_gpu(a2, w1f, w2b)
+    M, C_ = a2.shape
+    Hd = w1f.shape[0]
+    assert a2.dtype == BF16 and a2.is_contiguous() and w1f.is_contiguous() and w2b.is_contiguous()
+    assert w1f.shape == (Hd, C_) and w2b.shape == (C_, Hd) and b1f.dtype == torch.float32
+    out = torch.empty_like(a2)
+    ssum = torch.empty_like(a2) if r2 is not None else None
+    mean = torch.empty(M, device=a2.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    b2f = _c(b2.detach().float()) if b2 is not None else None
+    with _Timed('mlp96_fwd_kernel', 4 * M * C_ * Hd, M * C_ * 2 * (4 if r2 is not None else 2) + 8 * M):
+        check(_lib.lib().clv_mlp_fused_fwd(_ptr(a2), _ptr(r2), _ptr(ssum), _ptr(mean), _ptr(rstd), _ptr(w1f), _ptr(b1f),
+                                           _ptr(w2b), _ptr(b2f), _ptr(out), M, C_, Hd, float(eps), _ptr(xscale),
+                                           int(rows_per_sample), _stream()), 'clv_mlp_fused_fwd')
+    return dict(out=out, sum=ssum, mean=mean, rstd=rstd)
+
+
+def mlp_fused_bwd(ts, mean, rstd, do2, ds2, w1f, b1f, w2t, xscale=None, rows_per_sample=1, want_dres=False, want_xhat=True):
+    """Raw launcher of clv_mlp_fused_bwd (no autograd) -> dict(da, dres, act, dpre, xhat)."""
+    _need_gpu(ts, do2, w1f, w2t)
+    M, C_ = ts.shape
+    Hd = w1f.shape[0]
+    assert ts.is_contiguous() and do2.is_contiguous() and w2t.is_contiguous() and w2t.shape == (Hd, C_)
+    da = torch.empty_like(ts)
+    dres = torch.empty_like(ts) if want_dres else None
+    act = torch.empty(M, Hd, device=ts.device, dtype=BF16)
+    dpre = torch.empty_like(act)
+    xhat = torch.empty_like(ts) if want_xhat else None
+    nb = M * C_ * 2 * (3 + (1 if ds2 is not None else 0) + (1 if want_dres else 0) + (1 if want_xhat else 0)) + 2 * M * Hd * 2
+    with _Timed('mlp96_bwd_kernel', 10 * M * C_ * Hd, nb + 8 * M):
+        check(_lib.lib().clv_mlp_fused_bwd(_ptr(ts), _ptr(mean), _ptr(rstd), _ptr(do2), _ptr(ds2), _ptr(w1f), _ptr(b1f),
+                                           _ptr(w2t), _ptr(da), _ptr(dres), _ptr(act), _ptr(dpre), _ptr(xhat), M, C_, Hd,
+                                           _ptr(xscale), int(rows_per_sample), _stream()), 'clv_mlp_fused_bwd')
+    return dict(da=da, dres=dres, act=act, dpre=dpre, xhat=xhat)
+
+
 class _FusedMLP(torch.autograd.Function):
     """(out, s) = (fc2(GELU(fc1(LN(a + r)))),  a + r): kernel 1 = residual add + LayerNorm + fc1 + bias +
     GELU (pre-activation kept), kernel 2 = fc2; backward: fc2 input-gradient GEMM with the GELU
@@ -956,13 +1007,25 @@ class _FusedMLP(torch.autograd.Function):
         assert x_scale is None or r is not None
         xsc = _c(x_scale.detach().float()) if x_scale is not None else None
         rps = a2.shape[0] // a.shape[0]
-        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps, want_xhat=any(ctx.needs_input_grad),
-                     xscale=xsc, rows_per_sample=rps)
         ctx.xsc, ctx.rps = xsc, rps
-        xs = o1['sum'] if r is not None else a2
         w2b = getattr(w2, '_clv_shadow', None)
         if w2b is None:
             w2b = w2.to(BF16)
+        ctx.has_res = r is not None
+        ctx.shape = a.shape
+        ctx.w2ref, ctx.b2ref = w2, b2
+        ctx.prefs = (w1, b1, ln_weight, ln_bias)
+        ctx.one_kernel = mlp_fused_ok(a2, w1.shape[0]) and (r2 is None or (r2.is_contiguous() and r2.data_ptr() % 16 == 0))
+        if ctx.one_kernel:
+            # norm2 + fc1 + GELU + fc2 in ONE kernel, both weight matrices in LDS: the [M, 4C] hidden tensors (activation,
+            # pre-activation) are never written — the backward recomputes them from the residual stream (clv_mlp_fused_bwd)
+            o = mlp_fused_fwd(a2, r2, wt1, bf1, _c(w2b), b2, eps, xsc, rps)
+            xs = o['sum'] if r is not None else a2
+            ctx.save_for_backward(xs, o['mean'], o['rstd'], wt1, bf1, w2b)
+            return o['out'].view(a.shape), (o['sum'].view(a.shape) if r is not None else None)
+        o1 = rowgemm(a2, wt1, bf1, res=r2, standardise=True, epilogue=1, eps=eps, want_xhat=any(ctx.needs_input_grad),
+                     xscale=xsc, rows_per_sample=rps)
+        xs = o1['sum'] if r is not None else a2
         b2b = None
         if b2 is not None:
             b2b = getattr(b2, '_clv_shadow', None)
@@ -976,14 +1039,12 @@ class _FusedMLP(torch.autograd.Function):
             _library_gemm('fused_mlp fc2', (o1['y'].shape[0], w2b.shape[0], w2b.shape[1]))
             out = torch.nn.functional.linear(o1['y'], w2b, b2b)
         ctx.save_for_backward(xs, o1['mean'], o1['rstd'], wt1, o1['pre'], o1['y'], w2b, o1['xhat'])
-        ctx.has_res = r is not None
-        ctx.shape = a.shape
-        ctx.w2ref, ctx.b2ref = w2, b2
-        ctx.prefs = (w1, b1, ln_weight, ln_bias)
         return out.view(a.shape), (o1['sum'].view(a.shape) if r is not None else None)
 
     @staticmethod
     def backward(ctx, dout, ds):
+        if ctx.one_kernel:
+            return _FusedMLP._backward_one_kernel(ctx, dout, ds)
         xs, mean, rstd, wt1, pre, act, w2b, xhat = ctx.saved_tensors
         C_, Hd = w2b.shape                              # fc2: [C, 4C]
         do2 = _c(dout.reshape(-1, C_))
@@ -1021,6 +1082,31 @@ class _FusedMLP(torch.autograd.Function):
             dx = _ln_bwd_noaffine(dxhat, xs, mean, rstd, ds, gamma=gamma).view(ctx.shape)
             dr = dx
         dw1, db1, dg, dbt = _wgrad_folded(dpre, xhat, xs, mean, rstd, w1, b1, gamma, beta)
+        return dx, (dr if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None, None
+
+    @staticmethod
+    def _backward_one_kernel(ctx, dout, ds):
+        """clv_mlp_fused_bwd: recompute of the hidden activations, both input-gradient GEMMs, the GELU backward and the
+        LayerNorm backward (with the stream's gradient and the DropPath factor) in one kernel; it leaves act, d pre and xhat
+        for the (grouped, deferred) weight-gradient launches."""
+        xs, mean, rstd, wt1, bf1, w2b = ctx.saved_tensors
+        C_, Hd = w2b.shape
+        do2 = _c(dout.reshape(-1, C_))
+        if do2.dtype != BF16:
+            do2 = do2.to(BF16)
+        ds2 = None
+        if ds is not None:
+            ds2 = _c(ds).view(-1, C_)
+            if ds2.dtype != BF16:
+                ds2 = ds2.to(BF16)
+        w2, b2 = ctx.w2ref, ctx.b2ref
+        o = mlp_fused_bwd(xs, mean, rstd, do2, ds2, wt1, bf1, _c(_wt(w2, w2b)), ctx.xsc, ctx.rps,
+                          want_dres=ctx.xsc is not None and ctx.has_res)
+        dx = o['da'].view(ctx.shape)
+        dr = o['dres'].view(ctx.shape) if o['dres'] is not None else dx
+        dw2, db2 = _param_grads(do2, o['act'], w2, b2)
+        w1, b1, gamma, beta = ctx.prefs
+        dw1, db1, dg, dbt = _wgrad_folded(o['dpre'], o['xhat'], xs, mean, rstd, w1, b1, gamma, beta)
         return dx, (dr if ctx.has_res else None), dg, dbt, dw1, db1, dw2, db2, None, None
 
 

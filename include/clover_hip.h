@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 13
+#define CLV_ABI_VERSION 14
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -333,6 +333,31 @@ int clv_rowgemm_xs(const void* x, const void* res, void* sum_out, float* mean, f
                    const void* wt, const float* bias, const void* pre_in, void* y, void* pre_out, int64_t M, int32_t N,
                    int32_t K, int32_t ldx, int32_t ldy, int32_t standardise, int32_t epilogue, float eps,
                    const float* xscale, int32_t rows_per_sample, void* stream);
+
+/* ------------------------------------------------------------------ the MLP half of a stage-0 block as one kernel each way
+ * (round 6) norm2 + Mlp + the residual add in front of them — swin_transformer_3d.py:482-483 (norm2, mlp), :262-268
+ * (fc1, GELU, fc2), :498 / :503 (residual, DropPath) — for VideoSwin-T's stage-0 widths, C = 96 and hidden = 384
+ * (clv_mlp_fused_supported): both weight matrices stay in LDS, the [M][hidden] activations never reach HBM.
+ *   forward:  t = xscale[row / rows_per_sample] * a + res (written to sum_out: the new residual stream; res / xscale may be
+ *             NULL), xhat = (t - mean) * rstd (mean, rstd float [M] are outputs, statistics of the fp32 t),
+ *             out = GELU(xhat W1f^T + b1f) W2^T + b2.  a, res, sum_out, out bf16 [M][C] contiguous; w1f bf16 [hidden][C] and
+ *             b1f float [hidden]: fc1 with the norm's affine part folded in (clv_ln_fold_fwd); w2 bf16 [C][hidden], b2 float
+ *             [C] or NULL.
+ *   backward: from tsum (= sum_out, or a when there was no res), mean, rstd, d out and the gradient d sum that arrives on the
+ *             residual stream (bf16 [M][C] or NULL): recomputes xhat, the pre-activation, GELU and GELU'; d act = d out W2
+ *             (w2t = W2^T, bf16 [hidden][C]); d pre = d act GELU'; d xhat = d pre W1f; d t = LayerNorm backward of d xhat
+ *             (+ d sum).  Outputs: da = xscale * d t (gradient of a), dres = d t (gradient of res; NULL: not written — without
+ *             xscale it equals da), and the operands of the weight-gradient GEMMs that follow (clv_linear_wgrad_batch):
+ *             act_out bf16 [M][hidden] (dW2 = d out^T act), dpre_out bf16 [M][hidden] and xhat_out bf16 [M][C] (may be NULL)
+ *             (dW1f = d pre^T xhat, un-folded by clv_ln_fold_bwd). */
+int clv_mlp_fused_supported(int32_t C, int32_t hidden);
+int clv_mlp_fused_fwd(const void* a, const void* res, void* sum_out, float* mean, float* rstd, const void* w1f,
+                      const float* b1f, const void* w2, const float* b2, void* out, int64_t M, int32_t C, int32_t hidden,
+                      float eps, const float* xscale, int32_t rows_per_sample, void* stream);
+int clv_mlp_fused_bwd(const void* tsum, const float* mean, const float* rstd, const void* dout, const void* dsum,
+                      const void* w1f, const float* b1f, const void* w2t, void* da, void* dres, void* act_out,
+                      void* dpre_out, void* xhat_out, int64_t M, int32_t C, int32_t hidden, const float* xscale,
+                      int32_t rows_per_sample, void* stream);
 
 /* db[n] += sum_m dy[m][n] (bf16 dy, row stride ld; N, ld multiples of 8): the bias gradient of the
  * library-GEMM Linear layers (BERT / fusion / MLM head), ACCUMULATED into db. */

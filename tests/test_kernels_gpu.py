@@ -1207,6 +1207,82 @@ def test_fused_mlp_with_drop_path_factor(C):
         assert rel(G[k].grad, Q[k].grad) < 3e-2, (k, rel(G[k].grad, Q[k].grad))
 
 
+@pytest.mark.parametrize('M', [16, 17, 33, 1000, 3001, 25088, 200704 // 4])
+@pytest.mark.parametrize('with_res,with_scale', [(True, True), (True, False), (False, False)])
+def test_mlp_one_kernel_forward_backward(M, with_res, with_scale):
+    """clv_mlp_fused_fwd / _bwd (norm2 + fc1 + GELU + fc2 of a VideoSwin-T stage-0 block in ONE kernel each way, both
+    weight matrices in LDS, hidden activations never written: swin_transformer_3d.py:482-483,262-268,503) through the raw
+    launchers: every output against an fp32 torch composition on the same bf16 operands — out, the residual stream, the
+    statistics; d a, d r, and the act / d pre / xhat operands the backward leaves for the weight-gradient kernels.  Ragged
+    row counts (a half group, a partial tile, fewer tiles than workgroups), with / without residual and DropPath factor."""
+    F_ = torch.nn.functional
+    C, Hd, rps = 96, 384, max(1, M // 4)
+    nb = (M + rps - 1) // rps
+    a, r = rnd(M, C, seed=151).to(BF), rnd(M, C, seed=152).to(BF)
+    w1f, b1f = rnd(Hd, C, scale=0.12, seed=153).to(BF), 0.1 * rnd(Hd, seed=154)
+    w2, b2 = rnd(C, Hd, scale=0.06, seed=155).to(BF), 0.1 * rnd(C, seed=156)
+    sc = (torch.tensor([1.25, 0.0, 1.25, 1.25, 1.25])[:nb] if with_scale else None)
+    do, ds = rnd(M, C, seed=157).to(BF), rnd(M, C, seed=158).to(BF)
+    # fp32 reference on the bf16-rounded quantities the kernels see
+    ar, rr = a.float().requires_grad_(), r.float().requires_grad_()
+    t = ar * (sc.repeat_interleave(rps)[:M, None] if with_scale else 1.0) + (rr if with_res else 0.0)
+    mu = t.mean(1, keepdim=True)
+    var = ((t - mu) ** 2).mean(1, keepdim=True)
+    xhat = (t - mu) * torch.rsqrt(var + 1e-5)
+    pre = F_.linear(xhat, w1f.float(), b1f)
+    act = om.gelu(pre)
+    out = F_.linear(act, w2.float(), b2)
+    out.backward(do.float(), retain_graph=True)
+    da_mlp, dr_mlp = ar.grad.clone(), (rr.grad.clone() if with_res else None)
+    L = ops()
+    o = L.mlp_fused_fwd(a.to(DEV), r.to(DEV) if with_res else None, w1f.to(DEV), b1f.to(DEV), w2.to(DEV), b2.to(DEV), 1e-5,
+                        sc.to(DEV) if with_scale else None, rps)
+    assert rel(o['out'], out.detach()) < 1.5e-2, rel(o['out'], out.detach())
+    assert rel(o['mean'], mu.detach().squeeze(1)) < 1e-4 and rel(o['rstd'], torch.rsqrt(var + 1e-5).detach().squeeze(1)) < 1e-4
+    if with_res:
+        assert rel(o['sum'], t.detach()) < 5e-3
+    ts = o['sum'] if with_res else a.to(DEV)
+    bw = L.mlp_fused_bwd(ts, o['mean'], o['rstd'], do.to(DEV), ds.to(DEV), w1f.to(DEV), b1f.to(DEV),
+                         w2.t().contiguous().to(DEV), sc.to(DEV) if with_scale else None, rps, want_dres=with_scale)
+    assert rel(bw['act'], act.detach()) < 1.5e-2 and rel(bw['xhat'], xhat.detach()) < 1e-2
+    dact = do.float() @ w2.float()
+    x = pre.detach().requires_grad_()
+    om.gelu(x).backward(torch.ones_like(x))
+    assert rel(bw['dpre'], dact * x.grad) < 1.5e-2, rel(bw['dpre'], dact * x.grad)
+    # d t = LN-backward(d pre W1f) + d sum;  d a = factor * d t,  d r = d t
+    fac = sc.repeat_interleave(rps)[:M, None] if with_scale else torch.ones(M, 1)
+    dt_mlp = dr_mlp if with_res else da_mlp                               # = LN-backward part (factor 1 when no residual)
+    dt = dt_mlp + ds.float()
+    assert rel(bw['da'], dt * fac) < 2e-2, rel(bw['da'], dt * fac)
+    if with_scale:
+        assert rel(bw['dres'], dt) < 2e-2
+        if nb > 1 and rps < M:
+            assert float(bw['da'][rps:min(2 * rps, M)].abs().max()) == 0.0         # the dropped sample: no gradient into a
+    torch.cuda.synchronize()
+
+
+def test_mlp_one_kernel_equals_two_kernel_path(monkeypatch):
+    """ops.fused_mlp at C = 96 with CLOVER_FUSED_MLP=1 (one kernel each way) against CLOVER_FUSED_MLP=0 (the round-5 path:
+    LayerNorm + fc1 + GELU kernel, fc2 GEMM, three-kernel backward) on identical operands: outputs and every gradient."""
+    B, rows_per, C, Hd = 4, 1568, 96, 384
+    a, r = rnd(B, rows_per, C, seed=161).to(BF), rnd(B, rows_per, C, seed=162).to(BF)
+    sc = torch.tensor([1.25, 0.0, 1.25, 1.25])
+    P = dict(g=1 + 0.1 * rnd(C, seed=163), b=0.1 * rnd(C, seed=164), w1=rnd(Hd, C, scale=0.1, seed=165),
+             b1=0.1 * rnd(Hd, seed=166), w2=rnd(C, Hd, scale=0.05, seed=167), b2=0.1 * rnd(C, seed=168))
+    dm, ds = rnd(B, rows_per, C, seed=169).to(BF), rnd(B, rows_per, C, seed=170).to(BF)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CLOVER_FUSED_MLP', mode)
+        ag, rg = a.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+        G = {k: v.to(DEV).clone().requires_grad_() for k, v in P.items()}
+        m, s2 = ops().fused_mlp(ag, rg, G['g'], G['b'], G['w1'], G['b1'], G['w2'], G['b2'], x_scale=sc.to(DEV))
+        torch.autograd.backward([m, s2], [dm.to(DEV), ds.to(DEV)])
+        res[mode] = dict(m=m.detach(), s=s2.detach(), da=ag.grad, dr=rg.grad, **{k: v.grad for k, v in G.items()})
+    assert torch.equal(res['1']['s'], res['0']['s'])
+    for k in res['1']:
+        assert rel(res['1'][k], res['0'][k].float().cpu()) < 1.5e-2, (k, rel(res['1'][k], res['0'][k].float().cpu()))
+
+
 def test_gemm_nt_gelu_grad_epilogues():
     """CLV_GEMM_EPI_BIAS_GELU_D (c2 = GELU'(pre)) and CLV_GEMM_EPI_MUL (c = acc * aux): the pair that keeps the GELU
     backward free of transcendentals, against torch fp32."""

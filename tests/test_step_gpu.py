@@ -26,8 +26,10 @@ included — the contrastive terms move by a few 1e-3 between boxes / builds bec
       engine + hipGraphs (reference golden)    1.9e-4   5.8e-3   4.1e-3     9.7e-4   6.1e-3     5.1e-3
     mid widths 96 / 192, B = 2 (golden)        8.5e-4   5.9e-3   2.0e-3     1.4e-2   5.4e-4     6.1e-3
     mid widths 96 / 192, B = 4 (golden)        1.4e-3   2.1e-3   2.9e-3     1.4e-2   4.5e-3     1.6e-2
-    max, all rounds                            3.3e-3   9.6e-3   9.6e-3     1.64e-2  1.1e-2     1.84e-2
-    LOSS_TOL = 1.5 x that                      5.0e-3   1.5e-2   1.5e-2     2.5e-2   1.7e-2     2.8e-2
+    config 1, B = 1 (golden), few-row GEMMs on
+      the HIP kernels (were library below 64)  5.4e-3   0        ...
+    max, all rounds                            5.4e-3   9.6e-3   9.6e-3     1.64e-2  1.1e-2     1.84e-2
+    LOSS_TOL = 1.5 x that                      8.1e-3   1.5e-2   1.5e-2     2.5e-2   1.7e-2     2.8e-2
 """
 import numpy as np
 import pytest
@@ -39,7 +41,7 @@ import gutil
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']
-LOSS_TOL = dict(mlm_loss=5e-3, nce_loss=1.5e-2, rank_t_tm_loss=1.5e-2, v_nce_loss=2.5e-2, rank_v_vm_loss=1.7e-2, loss=2.8e-2)
+LOSS_TOL = dict(mlm_loss=8.1e-3, nce_loss=1.5e-2, rank_t_tm_loss=1.5e-2, v_nce_loss=2.5e-2, rank_v_vm_loss=1.7e-2, loss=2.8e-2)
 
 
 def grad_tol(name):
