@@ -113,13 +113,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     gelu_parts(x, cdf, ex);
     return fmaf(x * 0.3989422804014327f, ex, cdf);
 }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 // For bf16 OUTPUTS (the one-kernel MLP, fused_mlp.hip: GELU is its VALU bound — 77 M evaluations per launch):
 // h(u) = 1 - Phi(u) = 0.5 erfc(u / sqrt2), u = min(|x|, 5.5), as exp2 of a degree-6 polynomial fit of log2 h on [0, 5.5]
 // (Chebyshev least squares; evaluated in fp32: |h - exact| <= 2.6e-5, relative 6.5e-5, |u (h - exact)| <= 3.3e-6 — three
 // orders below the bf16 rounding of the result; beyond 5.5 h stays at 1.9e-8).  ONE transcendental and 7 fma where the
 // Abramowitz-Stegun form above takes v_rcp + v_exp + 10: 13 VALU slots per element instead of 20.
 __device__ __forceinline__ float gelu_h(float x) {
-    const float u = fminf(fabsf(x), 5.5f);
+    const float u = __builtin_amdgcn_fmed3f(fabsf(x), 0.f, 5.5f);     // (one v_med3_f32: fminf canonicalises first — two)
     float p = fmaf(2.641310222e-05f, u, -6.636010571e-04f);
     p = fmaf(p, u, 7.492294232e-03f);
     p = fmaf(p, u, -5.193681061e-02f);
@@ -128,9 +130,30 @@ __device__ __forceinline__ float gelu_h(float x) {
     p = fmaf(p, u, -1.000073591e+00f);
     return __builtin_amdgcn_exp2f(p);
 }
+// two elements at a time: the Horner chain on v_pk_fma_f32 (6 instructions per PAIR)
+__device__ __forceinline__ f32x2_t gelu_h2(f32x2_t x) {
+    const f32x2_t u = {__builtin_amdgcn_fmed3f(fabsf(x.x), 0.f, 5.5f), __builtin_amdgcn_fmed3f(fabsf(x.y), 0.f, 5.5f)};
+#define CLV_PK(c) ((f32x2_t){c, c})
+    f32x2_t p = __builtin_elementwise_fma(CLV_PK(2.641310222e-05f), u, CLV_PK(-6.636010571e-04f));
+    p = __builtin_elementwise_fma(p, u, CLV_PK(7.492294232e-03f));
+    p = __builtin_elementwise_fma(p, u, CLV_PK(-5.193681061e-02f));
+    p = __builtin_elementwise_fma(p, u, CLV_PK(-4.604588278e-01f));
+    p = __builtin_elementwise_fma(p, u, CLV_PK(-1.150443222e+00f));
+    p = __builtin_elementwise_fma(p, u, CLV_PK(-1.000073591e+00f));
+#undef CLV_PK
+    return (f32x2_t){__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+}
 // GELU(x) = x Phi(x) = max(x, 0) - |x| h   (x >= 0: x (1 - h); x < 0: x h): no compare / select
 __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(-fabsf(x), gelu_h(x), __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f));
+}
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
+    const f32x2_t h = gelu_h2(x);
+    // |x| clamped at 5.5 in place of |x|: beyond it h = 1.9e-8 — and the compiler gets a plain packed fma with a negated
+    // operand (an unclamped -|x| needs a v_or per element to set the sign bits: VOP3P has no abs modifier)
+    const f32x2_t u = {__builtin_amdgcn_fmed3f(fabsf(x.x), 0.f, 5.5f), __builtin_amdgcn_fmed3f(fabsf(x.y), 0.f, 5.5f)};
+    const f32x2_t r = {__builtin_amdgcn_fmed3f(x.x, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x.y, 0.f, 3.0e38f)};
+    return __builtin_elementwise_fma(-u, h, r);
 }
 // (GELU(x), GELU'(x)):  Phi(x) = 0.5 + copysign(0.5 - h, x),  GELU' = Phi + x phi,  phi = exp(-x^2 / 2) / sqrt(2 pi)
 __device__ __forceinline__ void gelu_fast_both(float x, float& act, float& grad) {
@@ -140,11 +163,18 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& act, float& grad)
     act = x * cdf;
     grad = fmaf(x * 0.3989422804014327f, e, cdf);
 }
+__device__ __forceinline__ void gelu_fast_both2(f32x2_t x, f32x2_t& act, f32x2_t& grad) {
+    const f32x2_t h = gelu_h2(x);
+    const f32x2_t xx = x * x * (f32x2_t){-0.72134752044448170f, -0.72134752044448170f};
+    const f32x2_t e = {__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
+    const f32x2_t cdf = {0.5f + copysignf(0.5f - h.x, x.x), 0.5f + copysignf(0.5f - h.y, x.y)};
+    act = x * cdf;
+    grad = __builtin_elementwise_fma(x * (f32x2_t){0.3989422804014327f, 0.3989422804014327f}, e, cdf);
+}
 
 // Two-at-a-time versions on packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of polynomial per
 // instruction; rcp / exp2 / selects stay scalar) for the GELU epilogues of the GEMM kernels, whose VALU work otherwise
 // equals their MFMA time at the stage-2 widths.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& ex) {
     const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
     const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t){0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f},

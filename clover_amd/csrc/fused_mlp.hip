@@ -183,8 +183,10 @@ __device__ __forceinline__ void fm_fwd_group(const bf16_t* __restrict__ W1s, con
                     bfr[tt].u[t * 2 + 0] = pack2bf(h[t][tt][0], h[t][tt][1]);
                     bfr[tt].u[t * 2 + 1] = pack2bf(h[t][tt][2], h[t][tt][3]);
                 } else {
-                    bfr[tt].u[t * 2 + 0] = pack2bf(gelu_fast(h[t][tt][0]), gelu_fast(h[t][tt][1]));
-                    bfr[tt].u[t * 2 + 1] = pack2bf(gelu_fast(h[t][tt][2]), gelu_fast(h[t][tt][3]));
+                    const f32x2_t g01 = gelu_fast2((f32x2_t){h[t][tt][0], h[t][tt][1]});
+                    const f32x2_t g23 = gelu_fast2((f32x2_t){h[t][tt][2], h[t][tt][3]});
+                    bfr[tt].u[t * 2 + 0] = pack2bf(g01.x, g01.y);
+                    bfr[tt].u[t * 2 + 1] = pack2bf(g23.x, g23.y);
                 }
             }
         // ---- fc2: out^T [96][tokens] += W2[:, chunk c] act^T
@@ -291,6 +293,7 @@ __device__ __forceinline__ void fm_d_to_rows(float& x, float& y) {
 
 // Backward.  LDS: W1f [384 physical rows][96] (fc1 recompute: plain reads; d xhat: transposing reads) and W2^T [384
 // physical rows][96] (d act).
+template <int ABL>
 __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
     const bf16_t* __restrict__ tsum, const float* __restrict__ mean, const float* __restrict__ rstd,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ dsum, const bf16_t* __restrict__ w1f,
@@ -319,22 +322,39 @@ __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
         const int64_t m0 = rg.row0 + g * 32;
         Frag8 xf[2][FM_KS], df[2][FM_KS];        // xhat and d out as B operands (token lr, channels 32 s + 8 lg .. + 7)
         float mu[2], rs[2];
+        {
+            // ALL loads of the group first, ONE wait: vmcnt retires in order, and the previous group's ~100 act / d pre
+            // stores are still in the queue — every separate load-then-wait pair drained that queue again (the compiler
+            // interleaves them with their consumers to save registers: 12 drains per group, 55 % of the wave cycles in
+            // s_waitcnt)
+            uint4 rt[2][FM_KS];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int64_t row = m0 + tt * 16 + lr;
-            const bool rv = row < rg.row1;
-            mu[tt] = rv ? mean[row] : 0.f;
-            rs[tt] = rv ? rstd[row] : 0.f;
+            for (int tt = 0; tt < 2; ++tt) {
+                const int64_t row = m0 + tt * 16 + lr;
+                const bool rv = row < rg.row1;
+                mu[tt] = rv ? mean[row] : 0.f;
+                rs[tt] = rv ? rstd[row] : 0.f;
 #pragma unroll
-            for (int s = 0; s < FM_KS; ++s) {
-                Frag8 t;
-                t.u4 = rv ? *reinterpret_cast<const uint4*>(tsum + row * FM_C + s * 32 + lg * 8) : make_uint4(0, 0, 0, 0);
-                df[tt][s].u4 = rv ? *reinterpret_cast<const uint4*>(dout + row * FM_C + s * 32 + lg * 8)
-                                  : make_uint4(0, 0, 0, 0);
+                for (int s = 0; s < FM_KS; ++s) {
+                    rt[tt][s] = rv ? *reinterpret_cast<const uint4*>(tsum + row * FM_C + s * 32 + lg * 8) : make_uint4(0, 0, 0, 0);
+                    df[tt][s].u4 = rv ? *reinterpret_cast<const uint4*>(dout + row * FM_C + s * 32 + lg * 8)
+                                      : make_uint4(0, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    xf[tt][s].u[e] = pack2bf((bf2f(t.h[2 * e]) - mu[tt]) * rs[tt], (bf2f(t.h[2 * e + 1]) - mu[tt]) * rs[tt]);
-                if (rv && xhat_out) *reinterpret_cast<uint4*>(xhat_out + row * FM_C + s * 32 + lg * 8) = xf[tt][s].u4;
+            for (int tt = 0; tt < 2; ++tt) {
+                const int64_t row = m0 + tt * 16 + lr;
+                const bool rv = row < rg.row1;
+#pragma unroll
+                for (int s = 0; s < FM_KS; ++s) {
+                    Frag8 t;
+                    t.u4 = rt[tt][s];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        xf[tt][s].u[e] = pack2bf((bf2f(t.h[2 * e]) - mu[tt]) * rs[tt], (bf2f(t.h[2 * e + 1]) - mu[tt]) * rs[tt]);
+                    if (rv && xhat_out) *reinterpret_cast<uint4*>(xhat_out + row * FM_C + s * 32 + lg * 8) = xf[tt][s].u4;
+                }
             }
         }
         f32x4_t gacc[FM_MT][2];                   // d xhat^T [96][32 tokens], standard tile order
@@ -376,12 +396,6 @@ __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
                     da_[t][1] = mfma16(wc[s][t], df[1][s], da_[t][1]);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            Frag8 wt[FM_MT];
-#pragma unroll
-            for (int mt = 0; mt < FM_MT; ++mt) {
-                wt[mt].u2[0] = fm_tr4(W1s, FM_LD1, c * 32 + lg * 4, mt * 16, lr);
-                wt[mt].u2[1] = fm_tr4(W1s, FM_LD1, c * 32 + 16 + lg * 4, mt * 16, lr);
-            }
             {
                 const int cn = c + 1 < FM_CH ? c + 1 : c;          // (the last chunk re-reads its own: no branch in the body)
 #pragma unroll
@@ -399,24 +413,31 @@ __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    float av[4], gv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gelu_fast_both(h[t][tt][r], av[r], gv[r]);
-                    actf[tt].u[t * 2 + 0] = pack2bf(av[0], av[1]);
-                    actf[tt].u[t * 2 + 1] = pack2bf(av[2], av[3]);
-                    pf[tt].u[t * 2 + 0] = pack2bf(da_[t][tt][0] * gv[0], da_[t][tt][1] * gv[1]);
-                    pf[tt].u[t * 2 + 1] = pack2bf(da_[t][tt][2] * gv[2], da_[t][tt][3] * gv[3]);
+                    f32x2_t a01, g01, a23, g23;
+                    gelu_fast_both2((f32x2_t){h[t][tt][0], h[t][tt][1]}, a01, g01);
+                    gelu_fast_both2((f32x2_t){h[t][tt][2], h[t][tt][3]}, a23, g23);
+                    actf[tt].u[t * 2 + 0] = pack2bf(a01.x, a01.y);
+                    actf[tt].u[t * 2 + 1] = pack2bf(a23.x, a23.y);
+                    pf[tt].u[t * 2 + 0] = pack2bf(da_[t][tt][0] * g01.x, da_[t][tt][1] * g01.y);
+                    pf[tt].u[t * 2 + 1] = pack2bf(da_[t][tt][2] * g23.x, da_[t][tt][3] * g23.y);
                 }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int64_t row = m0 + tt * 16 + lr;
-                if (row < rg.row1) {
+                if (row < rg.row1 && !(ABL & 2)) {     // (ABL 2: probe without the act / d pre stores)
                     *reinterpret_cast<uint4*>(act_out + row * FM_H + c * 32 + lg * 8) = actf[tt].u4;
                     *reinterpret_cast<uint4*>(dpre_out + row * FM_H + c * 32 + lg * 8) = pf[tt].u4;
                 }
             }
+            // ---- d xhat^T += W1f^T[:, chunk c] d pre^T: A fragments by transposing reads of the W1f image (rows = hidden),
+            // issued together in front of the MFMAs (their registers are free only now: the GELU temporaries are gone)
+            Frag8 wt[FM_MT];
+#pragma unroll
+            for (int mt = 0; mt < FM_MT; ++mt) {
+                wt[mt].u2[0] = fm_tr4(W1s, FM_LD1, c * 32 + lg * 4, mt * 16, lr);
+                wt[mt].u2[1] = fm_tr4(W1s, FM_LD1, c * 32 + 16 + lg * 4, mt * 16, lr);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- d xhat^T += W1f^T[:, chunk c] d pre^T: A fragments by transposing reads of the W1f image (rows = hidden)
 #pragma unroll
             for (int mt = 0; mt < FM_MT; ++mt) {
                 gacc[mt][0] = mfma16(wt[mt], pf[0], gacc[mt][0]);
@@ -424,6 +445,20 @@ __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
             }
         }
         // ---- LayerNorm backward in the row layout: dt = rstd (g - mean(g) - xhat mean(g xhat)) + d sum
+        // (the six d sum loads of the group at once, in front of the arithmetic: one drain of the store queue, not six)
+        uint4 dsr[2][FM_KS];
+        float xscr[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int64_t row = m0 + tt * 16 + lr;
+            const bool rv = row < rg.row1;
+            xscr[tt] = (xscale && rv) ? xscale[row / rows_per_sample] : 1.f;
+#pragma unroll
+            for (int s = 0; s < FM_KS; ++s)
+                dsr[tt][s] = (dsum && rv) ? *reinterpret_cast<const uint4*>(dsum + row * FM_C + s * 32 + lg * 8)
+                                          : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int64_t row = m0 + tt * 16 + lr;
@@ -448,12 +483,12 @@ __global__ void __launch_bounds__(64 * FM_NW, 1) mlp96_bwd_kernel(
             }
             s1 = grp4_sum(s1) * (1.0f / FM_C);
             s2 = grp4_sum(s2) * (1.0f / FM_C);
-            const float xsc = (xscale && rv) ? xscale[row / rows_per_sample] : 1.f;
+            const float xsc = xscr[tt];
             if (rv) {
 #pragma unroll
                 for (int s = 0; s < FM_KS; ++s) {
                     Frag8 ds;
-                    ds.u4 = dsum ? *reinterpret_cast<const uint4*>(dsum + row * FM_C + s * 32 + lg * 8) : make_uint4(0, 0, 0, 0);
+                    ds.u4 = dsr[tt][s];
                     float dt[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -519,10 +554,12 @@ extern "C" int clv_mlp_fused_bwd(const void* tsum, const float* mean, const floa
     if ((((uintptr_t)tsum) | ((uintptr_t)dout) | ((uintptr_t)dsum) | ((uintptr_t)w1f) | ((uintptr_t)w2t) | ((uintptr_t)da) |
          ((uintptr_t)dres) | ((uintptr_t)act_out) | ((uintptr_t)dpre_out) | ((uintptr_t)xhat_out)) & 15)
         return CLV_ERR_ARG;
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp96_bwd_kernel),
+    static const int abl = getenv("CLV_FMLP_ABL") ? atoi(getenv("CLV_FMLP_ABL")) : 0;      // probe builds (wrong results)
+    auto kern = abl == 2 ? &mlp96_bwd_kernel<2> : &mlp96_bwd_kernel<0>;
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS_BWD) == hipSuccess;
     (void)attr;
-    hipLaunchKernelGGL(mlp96_bwd_kernel, dim3((unsigned)fm_grid(M)), dim3(64 * FM_NW), FM_LDS_BWD, (hipStream_t)stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)fm_grid(M)), dim3(64 * FM_NW), FM_LDS_BWD, (hipStream_t)stream,
                        (const bf16_t*)tsum, mean, rstd, (const bf16_t*)dout, (const bf16_t*)dsum, (const bf16_t*)w1f, b1f,
                        (const bf16_t*)w2t, (bf16_t*)da, (bf16_t*)dres, (bf16_t*)act_out, (bf16_t*)dpre_out,
                        (bf16_t*)xhat_out, M, xscale, rows_per_sample > 0 ? rows_per_sample : 1);
