@@ -8,8 +8,30 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip.so')     # override: A/B of two builds
-ABI_VERSION = 14
+# The 16-bit element type of activations, weight shadows and gradients.  Default (round 6): IEEE fp16 — the reference's own
+# arithmetic type (configs/exp_local/pretrain_webvid_cc3m.py:21 fp16 = dict(loss_scale='dynamic'),
+# mmaction/core/hooks/fp16_utils.py:215-259): three more significand bits than bf16 at the same MFMA rate, which puts the
+# step's losses within ~2e-3 of the fp32 reference (bf16: 1.8e-2) at the same step time; the engine applies a static loss
+# scale.  CLOVER_HALF=bf16 selects the bf16 build of the same kernels (libclover_hip.so; no loss scale needed).  The same
+# sources are compiled twice (csrc/Makefile: -DCLV_HALF_F16); HALF / half_dtype() is the torch dtype every module stores in.
+HALF_F16 = os.environ.get('CLOVER_HALF', 'f16').lower() in ('f16', 'fp16', 'float16', 'half')
+LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_hip_f16.so' if HALF_F16 else 'libclover_hip.so')
+
+
+# Static loss scale of the 16-bit backward (mmcv_Fp16OptimizerHook.py:96-149; the reference's fp16 = dict(loss_scale='dynamic')):
+# fp16 activation gradients of 1e-7 .. 1e-4 would sit in the subnormal range, so the recognizer's _parse_losses multiplies
+# the gradient at the ROOT of every backward by this factor (a power of two: exact) and whoever consumes parameter gradients
+# divides it out — the engine inside its norm / AdamW kernels (their grad_scale factor), plain autograd users through a
+# per-parameter gradient hook the recognizer registers (so `loss.backward()` leaves true-scale .grad tensors either way).
+# bf16 has fp32's exponent range and needs none.
+LOSS_SCALE = float(os.environ.get('CLOVER_LOSS_SCALE', '1024' if HALF_F16 else '1'))
+
+
+def half_dtype():
+    import torch
+    return torch.float16 if HALF_F16 else torch.bfloat16
+
+ABI_VERSION = 15
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -67,6 +89,7 @@ class ClvLnExtra(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol include/clover_hip.h declares
 SIGNATURES = {
     'clv_abi_version': (C.c_int, []),
+    'clv_half_type': (C.c_int, []),
     'clv_attn_fwd': (C.c_int, [_p] * 9 + [C.POINTER(ClvAttnGeom), _p]),
     'clv_attn_seq_work_bytes': (C.c_int64, [C.POINTER(ClvAttnGeom)]),
     'clv_attn_seq_max_keys': (C.c_int, []),
@@ -164,6 +187,9 @@ def lib():
         v = L.clv_abi_version()
         if v != ABI_VERSION:
             raise RuntimeError(f'clover_amd: ABI version mismatch (library {v}, binding {ABI_VERSION}); rebuild')
+        if L.clv_half_type() != int(HALF_F16):
+            raise RuntimeError(f'clover_amd: {LIB_PATH} computes in {"fp16" if L.clv_half_type() else "bf16"} but '
+                               f'CLOVER_HALF asks for {"fp16" if HALF_F16 else "bf16"}')
         _lib = L
     return _lib
 

@@ -28,7 +28,7 @@ from .. import ops
 from ..builder import BACKBONES
 from ..nn import GELU, DropPath, LayerNorm, Linear, trunc_normal_
 
-BF16 = torch.bfloat16
+BF16 = ops.BF16          # the 16-bit storage type: bf16, or fp16 with CLOVER_HALF=f16 (the name is historical)
 
 
 # --------------------------------------------------------------------------- geometry (host, cached)

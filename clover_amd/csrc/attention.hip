@@ -132,7 +132,7 @@ __device__ __forceinline__ void stage(const int* row_s, const bf16_t* base, int 
             uint32_t* w = reinterpret_cast<uint32_t*>(&val);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                w[e] = pack2bf(__uint_as_float(w[e] << 16) * mul, __uint_as_float(w[e] & 0xffff0000u) * mul);
+                w[e] = pack2bf(half_lo(w[e]) * mul, half_hi(w[e]) * mul);
         }
         *reinterpret_cast<uint4*>(rm + n * LDR + c * 8) = val;
     }
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(THREADS, (NKT <= 16 ? 3 : 1)) attn_fwd_kernel(
 
     const int lg = lane >> 4, lr = lane & 15;
     Frag8 onesf;
-    onesf.u[0] = onesf.u[1] = onesf.u[2] = onesf.u[3] = 0x3f803f80u;      // bf16 1.0 pairs
+    onesf.u[0] = onesf.u[1] = onesf.u[2] = onesf.u[3] = CLV_ONE_PAIR;      // 1.0 pairs
     constexpr int UNR = PRE > 1 ? PRE : 1;
 #pragma unroll UNR
     for (int ti = 0; ti < (NKT + WAVES - 1) / WAVES; ++ti) {
@@ -884,9 +884,9 @@ __global__ void __launch_bounds__((ONE_CWAVES(NKT) + ONE_SWAVES(NKT)) * 64, ONE_
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int idx = tid + j * NTHR, n = idx / CH, c = idx - n * CH;
-            auto sc2 = [&](uint32_t w) { return pack2bf(__uint_as_float(w << 16) * qmul, __uint_as_float(w & 0xffff0000u) * qmul); };
+            auto sc2 = [&](uint32_t w) { return pack2bf(half_lo(w) * qmul, half_hi(w) * qmul); };
             auto dot2 = [](uint32_t a, uint32_t b) {
-                return __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+                return half_lo(a) * half_lo(b) + half_hi(a) * half_hi(b);
             };
             float d = (dot2(vd[j].x, vo[j].x) + dot2(vd[j].y, vo[j].y)) + (dot2(vd[j].z, vo[j].z) + dot2(vd[j].w, vo[j].w));
             d += __shfl_xor(d, 1, 64);                       // the CH = 4 pieces of a row sit in adjacent lanes
@@ -1373,7 +1373,8 @@ __global__ void __launch_bounds__(256) attn_f32_fwd_kernel(const float* __restri
             const int j = t * 64 + lane;
             if (j < N) {
                 float e = expf(s[t] - m);
-                if (round_p) e = bf2f(f2bf(e));       // emulate the bf16 P operand of the MFMA kernels
+                if (round_p == 1) e = bf2f(f2bf(e));  // emulate the bf16 P operand of the MFMA kernels
+                else if (round_p == 2) e = (float)(_Float16)e;     // ... or an f16 one (the f16-forward study)
                 s[t] = e;
                 sum += e;
             }

@@ -8,19 +8,44 @@
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;  // MFMA A/B operand (4 VGPRs)
+// ---- the 16-bit element type of activations, weight shadows and gradients.  Default: bf16.  With -DCLV_HALF_F16 the SAME
+// kernels are compiled for IEEE fp16 (libclover_hip_f16.so, CLOVER_HALF=f16): the reference's own arithmetic type
+// (configs/exp_local/pretrain_webvid_cc3m.py:21 fp16 = dict(loss_scale='dynamic')) — three more significand bits at the same
+// MFMA rate (v_mfma_f32_16x16x32_f16), which is what the contrastive losses (cosines / 0.05) need to sit within ~1e-3 of the
+// fp32 reference (tools/f16_forward_study.py).  Everything type-specific is in this block: the raw 16-bit storage type keeps
+// its name (bf16_t), and so do the helpers (bf2f, pack2bf, f2bf, mfma16) — in the f16 build they are the f16 conversions.
+typedef uint16_t bf16_t;  // raw 16-bit element (bf16 bits, or fp16 bits under CLV_HALF_F16)
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;     // 16x16 MFMA accumulator
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;   // 32x32 MFMA accumulator
 
 struct __attribute__((aligned(16))) u16x8 { uint16_t v[8]; };
 struct __attribute__((aligned(8))) u16x4 { uint16_t v[4]; };
-
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-
-// fp32 -> bf16, round-to-nearest-even, in hardware: one v_cvt_pk_bf16_f32 per PAIR (gfx950).
-typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+
+#ifdef CLV_HALF_F16
+#define CLV_HALF_IS_F16 1
+#define CLV_ONE_PAIR 0x3c003c00u          // (1.0, 1.0) as a packed pair
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 bf16x8_t;  // MFMA A/B operand (4 VGPRs)
+typedef _Float16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    union { bf16_t s; _Float16 f; } c;
+    c.s = h;
+    return (float)c.f;
+}
+// the low / high 16-bit element of a packed pair as fp32 (bf16: a shift / a mask; f16: v_cvt_f32_f16 with op_sel)
+__device__ __forceinline__ float half_lo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float half_hi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
+#else
+#define CLV_HALF_IS_F16 0
+#define CLV_ONE_PAIR 0x3f803f80u
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;  // MFMA A/B operand (4 VGPRs)
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float half_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float half_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+
+// fp32 -> 16-bit element, round-to-nearest-even, in hardware: one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 per PAIR (gfx950).
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     const f32x2_hw_t v = {lo, hi};
     union { bf16x2_hw_t b; uint32_t u; } c;
@@ -29,7 +54,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
-union Frag8 {  // 8 bf16 = one MFMA 16x16x32 A/B operand
+union Frag8 {  // 8 elements = one MFMA 16x16x32 A/B operand
     bf16x8_t v;
     uint4 u4;
     uint2 u2[2];
@@ -40,7 +65,11 @@ union Frag8 {  // 8 bf16 = one MFMA 16x16x32 A/B operand
 // D = A(16x32) * B(32x16) + C.  Lane l supplies A[row l&15][k (l>>4)*8..+8] and
 // B[k (l>>4)*8..+8][col l&15]; receives D[row (l>>4)*4+r][col l&15], r = 0..3.
 __device__ __forceinline__ f32x4_t mfma16(const Frag8& a, const Frag8& b, f32x4_t c) {
+#ifdef CLV_HALF_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -27,8 +27,8 @@ __global__ void __launch_bounds__(256) quant_fp8_rows_kernel(const bf16_t* __res
             const uint32_t w[4] = {v[cidx].x, v[cidx].y, v[cidx].z, v[cidx].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                amax = fmaxf(amax, fabsf(__uint_as_float(w[e] << 16)));
-                amax = fmaxf(amax, fabsf(__uint_as_float(w[e] & 0xffff0000u)));
+                amax = fmaxf(amax, fabsf(half_lo(w[e])));
+                amax = fmaxf(amax, fabsf(half_hi(w[e])));
             }
         }
     }
@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(256) quant_fp8_rows_kernel(const bf16_t* __res
             float f[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                f[2 * e] = fminf(fmaxf(__uint_as_float(w[e] << 16) * inv, -448.f), 448.f);
-                f[2 * e + 1] = fminf(fmaxf(__uint_as_float(w[e] & 0xffff0000u) * inv, -448.f), 448.f);
+                f[2 * e] = fminf(fmaxf(half_lo(w[e]) * inv, -448.f), 448.f);
+                f[2 * e + 1] = fminf(fmaxf(half_hi(w[e]) * inv, -448.f), 448.f);
             }
             int lo = 0, hi = 0;
             lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);

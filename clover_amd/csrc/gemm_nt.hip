@@ -184,8 +184,8 @@ enum { GN_EPI_NONE = CLV_GEMM_EPI_NONE, GN_EPI_BIAS = CLV_GEMM_EPI_BIAS, GN_EPI_
        GN_EPI_DGELU = CLV_GEMM_EPI_DGELU, GN_EPI_GELUD = CLV_GEMM_EPI_BIAS_GELU_D, GN_EPI_MUL = CLV_GEMM_EPI_MUL,
        GN_EPI_PARTIAL = 6 };        // split-K slice: fp32 partial sums to the work slab, the epilogue runs in the reduce kernel
 
-__device__ __forceinline__ float gn_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float gn_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float gn_lo(uint32_t u) { return half_lo(u); }
+__device__ __forceinline__ float gn_hi(uint32_t u) { return half_hi(u); }
 
 // ONE persistent 8-wave workgroup per CU (waves as WAVES_M x WAVES_N, two per SIMD); workgroup w lives on XCD w & 7
 // (dispatch order) and walks the tiles of the row blocks mblk = xcd (mod 8) in (mblk, tn) order with stride gridDim / 8,

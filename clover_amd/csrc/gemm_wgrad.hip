@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const bf16_t* __re
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     Frag8 ones;
-    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;      // bf16 1.0 pairs
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = CLV_ONE_PAIR;      // 1.0 pairs
 
     uint4 ry[CHUNKS], rx[CHUNKS];
     fetch_tile(ry, dy, m_begin, m_end, n0, N, ldy, tid);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_dma_kernel(const bf16_t* 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     Frag8 ones;
-    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = CLV_ONE_PAIR;
 
 #pragma unroll
     for (int d = 0; d < RING - 1; ++d) issue(d, m_begin + d * SM);
@@ -485,7 +485,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     Frag8 ones;
-    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = CLV_ONE_PAIR;
 
     // per-lane LDS read addresses inside a stage tensor (bf16 element offsets): transpose-read block of rows
     // lg*4 + (lr>>2) .. , columns c0 + (lr&3)*4 .. with the pair swizzle; the second k-half is + 16 rows = + 2048 elements
@@ -823,7 +823,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
             if (do_bias) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    bsum[i] += __uint_as_float(a[i].u[u] << 16) + __uint_as_float(a[i].u[u] & 0xffff0000u);
+                    bsum[i] += half_lo(a[i].u[u]) + half_hi(a[i].u[u]);
             }
         }
     };
@@ -1117,13 +1117,23 @@ __device__ __forceinline__ void wt_body(unsigned char* smem, const WtProblem& pr
 #endif
         rslot = rslot == R - 1 ? 0 : rslot + 1;
     };
+#if CLV_HALF_IS_F16
+    typedef _Float16 bf2_t __attribute__((ext_vector_type(2)));
+    auto dot_ones = [](unsigned w, float c) {
+        union { unsigned u; bf2_t v; } x, one2;
+        x.u = w;
+        one2.u = 0x3c003c00u;                                 // (1.0, 1.0) in fp16
+        return __builtin_amdgcn_fdot2(x.v, one2.v, c, false);
+    };
+#else
     typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
     auto dot_ones = [](unsigned w, float c) {
         union { unsigned u; bf2_t v; } x, one2;
         x.u = w;
-        one2.u = 0x3f803f80u;
+        one2.u = CLV_ONE_PAIR;
         return __builtin_amdgcn_fdot2_f32_bf16(x.v, one2.v, c, false);
     };
+#endif
     // the bias words of the fragments just multiplied: <= 6 instructions per wave when four waves share a row, issued
     // behind the wave's 36 MFMAs
     auto bias_words = [&]() {

@@ -539,8 +539,8 @@ __global__ void __launch_bounds__(LN_THREADS, LNV_BWD_MINW(GROUP, ITERS, T)) lnv
             }
 #pragma unroll
             for (int g = 0; g < RG; ++g) {
-                auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
-                auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+                auto lo = [](uint32_t w) { return half_lo(w); };
+                auto hi = [](uint32_t w) { return half_hi(w); };
                 const uint32_t* wx = reinterpret_cast<const uint32_t*>(&rx[g]);      // (register views: these are values)
                 float tt[8], dd[8];
                 const uint32_t ux[4] = {rx[g].x, rx[g].y, rx[g].z, rx[g].w}, ur[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};

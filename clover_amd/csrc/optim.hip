@@ -12,8 +12,7 @@ namespace {
 __device__ __forceinline__ float4 load_g4(const float* g, int64_t i) { return reinterpret_cast<const float4*>(g)[i]; }
 __device__ __forceinline__ float4 load_g4(const bf16_t* g, int64_t i) {
     const uint2 u = reinterpret_cast<const uint2*>(g)[i];
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                       __uint_as_float(u.y & 0xffff0000u));
+    return make_float4(half_lo(u.x), half_hi(u.x), half_lo(u.y), half_hi(u.y));
 }
 __device__ __forceinline__ float load_g1(const float* g, int64_t i) { return g[i]; }
 __device__ __forceinline__ float load_g1(const bf16_t* g, int64_t i) { return bf2f(g[i]); }
@@ -196,6 +195,7 @@ int grid_for(int64_t n4, int64_t cap = (1 << 20)) {
 }  // namespace
 
 extern "C" int clv_abi_version(void) { return CLV_ABI_VERSION; }
+extern "C" int clv_half_type(void) { return CLV_HALF_IS_F16; }
 
 extern "C" int clv_sumsq(const float* g, float* acc, int64_t n, void* stream) {
     if (!g || !acc || n < 0) return CLV_ERR_ARG;

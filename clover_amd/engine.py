@@ -124,11 +124,15 @@ class _Segment:
         self.flat_g = torch.zeros(n, device=device, dtype=torch.float32)
         self.exp_avg = torch.zeros(n, device=device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=device, dtype=torch.float32)
-        self.shadow = torch.zeros(n, device=device, dtype=torch.bfloat16)      # bf16 compute copy
+        self.shadow = torch.zeros(n, device=device, dtype=ops.BF16)      # 16-bit compute copy (bf16, or fp16 with CLOVER_HALF=f16)
         for p, off in zip(self.params, self.offsets):
             view = self.flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
+            hook = getattr(p, '_clv_unscale', None)        # (the recognizer's loss-scale hook of a plain-autograd parameter:
+            if hook is not None:                           # under the engine every gradient in the slab stays scaled)
+                hook.remove()
+                p._clv_unscale = None
             p.grad = self.flat_g[off:off + p.numel()].view_as(p)
             p._clv_grad = p.grad                                                   # sink for ops.linear
             p._clv_shadow = self.shadow[off:off + p.numel()].view_as(p)
@@ -158,7 +162,7 @@ class _Segment:
         if not want or not self.flat_p.is_cuda:
             return
         device = self.flat_p.device
-        self.shadow_t = torch.zeros(sum((sh[0] * sh[1] + 7) // 8 * 8 for _, _, sh in want), device=device, dtype=torch.bfloat16)
+        self.shadow_t = torch.zeros(sum((sh[0] * sh[1] + 7) // 8 * 8 for _, _, sh in want), device=device, dtype=ops.BF16)
         entries, toff = [], 0
         for p, off, shape in want:
             n = shape[0] * shape[1]
@@ -202,6 +206,12 @@ class CloverEngine:
                  paramwise_cfg=None, grad_clip=15.0, max_iters=100000, warmup_iters=0, min_lr_ratio=1e-3,
                  warmup_ratio=1e-3, bucket_mb=64):
         self.model = model
+        # Loss scaling (mmcv_Fp16OptimizerHook.py:96-149): the recognizer scales the gradient at the root of every backward by
+        # _lib.LOSS_SCALE (fp16 build: 1024; bf16: 1 — BaseRecognizer._parse_losses); the gradients in the slabs are scaled,
+        # and the norm / AdamW kernels divide the scale out through their grad_scale factor (next to the 1 / world of the
+        # gradient average).  A non-finite norm skips the step on the device as before.
+        from . import _lib as _clv_lib
+        self.loss_scale = float(_clv_lib.LOSS_SCALE)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.base_lr, self.betas, self.eps = lr, betas, eps
@@ -283,7 +293,7 @@ class CloverEngine:
         # of 757 MB per step over xGMI at config 2; accumulation in the backward and the update itself stay fp32
         self.wire = None
         if collectives_active() and os.environ.get('CLOVER_BF16_ALLREDUCE', '1') == '1':
-            self.wire = [torch.zeros_like(seg.flat_g, dtype=torch.bfloat16) for seg in self.segments]
+            self.wire = [torch.zeros_like(seg.flat_g, dtype=ops.BF16) for seg in self.segments]
         self.reducer = BucketedGradReducer([(seg.flat_g, seg.params, seg.offsets) for seg in self.segments],
                                            bucket_bytes=bucket_mb << 20,
                                            split_key=lambda q: self._pclass.get(id(q), 'h'), wire=self.wire)
@@ -803,7 +813,7 @@ class CloverEngine:
                                        'engine.reducer.finish()')
                 torch._foreach_zero_(stale)
         self._stale_cleared = False
-        gscale = 1.0 / self.world                       # DDP averages the summed gradients
+        gscale = 1.0 / (self.world * self.loss_scale)   # DDP averages the summed gradients; the loss scale is divided out
         grads = self.wire if self.wire is not None else [seg.flat_g for seg in self.segments]   # reduced gradients
         for g in grads:
             ops.sumsq_accumulate(g, self.sumsq)

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import ops
 
-BF16 = torch.bfloat16
+BF16 = ops.BF16          # the 16-bit storage type: bf16, or fp16 with CLOVER_HALF=f16 (the name is historical)
 
 
 def to_bf16(t):

@@ -12,7 +12,7 @@ import torch
 from . import _lib, parity
 from ._lib import ClvAttnGeom, check
 
-BF16 = torch.bfloat16
+BF16 = _lib.half_dtype()          # the 16-bit storage type: bf16, or fp16 with CLOVER_HALF=f16 (the name is historical)
 
 
 def _stream():
@@ -52,6 +52,41 @@ def _library_gemm(site, shape):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+ACTIVE_LOSS_SCALE = [1.0]    # the loss scale of the backward pass that is RUNNING (set by _ScaleGrad at its root, reset at its end)
+
+
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by a constant: the loss scale at the root of a 16-bit backward
+    (_lib.LOSS_SCALE).  It also publishes the scale for the duration of that backward pass (ACTIVE_LOSS_SCALE), so that the
+    recognizer's per-parameter hooks divide it out of exactly the gradients that carry it — a backward that does not start
+    from the recognizer's loss (a test differentiating a feature map) is left alone."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = float(s)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ACTIVE_LOSS_SCALE[0] = ctx.s
+        torch.autograd.Variable._execution_engine.queue_callback(_reset_active_scale)
+        return g * ctx.s, None
+
+
+def _reset_active_scale():
+    ACTIVE_LOSS_SCALE[0] = 1.0
+
+
+def unscale_hook(g):
+    """Gradient hook of a plain-autograd parameter: divide the running backward's loss scale out (a power of two: exact)."""
+    s = ACTIVE_LOSS_SCALE[0]
+    return g if s == 1.0 else g * (1.0 / s)
+
+
+def scale_grad(x, s):
+    return _ScaleGrad.apply(x, s) if (s != 1.0 and x.requires_grad) else x
 
 
 # --------------------------------------------------------------------------- in-process kernel timing

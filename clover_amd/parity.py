@@ -37,7 +37,7 @@ def _env_state():
         return None
     kinds = [k for k in os.environ.get('CLOVER_PARITY_ROUND', '').split(',') if k]
     assert all(k in ROUND_KINDS for k in kinds), kinds
-    return dict(round=frozenset(kinds))
+    return dict(round=frozenset(kinds), dtype=BF16)
 
 
 STATE = _env_state()
@@ -48,11 +48,14 @@ def enabled():
 
 
 @contextlib.contextmanager
-def mode(round=()):
-    """Run the enclosed forward passes in parity mode (see module docstring)."""
+def mode(round=(), dtype=BF16):
+    """Run the enclosed forward passes in parity mode (see module docstring).  dtype: what the re-injected rounding sources
+    round TO — bf16 (the training path's storage / operand type) or torch.float16 (round 6: what the step's losses would
+    look like with f16 storage and f16 MFMA operands, the reference's own arithmetic type, without building those kernels)."""
     global STATE
     assert all(k in ROUND_KINDS for k in round), round
-    prev, STATE = STATE, dict(round=frozenset(round))
+    assert dtype in (BF16, torch.float16)
+    prev, STATE = STATE, dict(round=frozenset(round), dtype=dtype)
     try:
         yield
     finally:
@@ -63,7 +66,7 @@ def rnd(kind, t):
     """Re-inject one bf16 rounding source (isolation runs); identity in plain parity mode."""
     if t is None or kind not in STATE['round']:
         return t
-    return t.to(BF16).float()
+    return t.to(STATE.get('dtype', BF16)).float()
 
 
 def _stream():
@@ -166,7 +169,8 @@ def attention(qkv, table, rid, kmask, geom_kw):
     qkv = qkv.float().contiguous()
     if geom_kw.get('dropout_p'):
         raise NotImplementedError('parity mode is an eval-mode pass (no attention dropout)')
-    o = _AttentionP.apply(qkv, table, rid, kmask, geom_kw, 'prob' in STATE['round'])
+    o = _AttentionP.apply(qkv, table, rid, kmask, geom_kw,
+                          (2 if STATE.get('dtype', BF16) == torch.float16 else 1) if 'prob' in STATE['round'] else 0)
     return rnd('act', o)
 
 

@@ -149,6 +149,12 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         loss = stacked.sum() if len(pick) == len(names) else stacked[pick].sum()
         names.append('loss')
         packed = torch.cat([stacked.detach(), loss.detach().reshape(1)])
+        # loss scale of the 16-bit backward (fp16 build: 1024; bf16: 1): applied to the gradient at the root, divided out of
+        # every parameter gradient again — by the engine's optimizer kernels, or by the hooks below for plain autograd
+        from .. import _lib, ops
+        if _lib.LOSS_SCALE != 1.0 and loss.requires_grad:
+            BaseRecognizer._register_unscale_hooks(self, _lib.LOSS_SCALE)     # (unbound: toy recognizers borrow _parse_losses)
+            loss = ops.scale_grad(loss, _lib.LOSS_SCALE)
         if not reduce:                                   # inside a hipGraph capture: the caller averages over the ranks
             return loss, names, packed
         if collectives_active():
@@ -157,6 +163,18 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         if getattr(self, 'lazy_log_vars', True):
             return loss, LazyLogVars(names, packed)
         return loss, OrderedDict(zip(names, packed.cpu().tolist()))
+
+    def _register_unscale_hooks(self, scale):
+        """Parameters whose gradient arrives through autograd (no engine sink) get it divided by the loss scale as it is
+        accumulated, so that ``loss.backward()`` leaves true-scale ``.grad`` tensors.  An engine removes the hook of every
+        parameter it takes over (their gradients live, scaled, in its slabs: engine._Segment)."""
+        if getattr(self, '_clv_unscale_done', None) == scale:
+            return
+        from .. import ops
+        for q in self.parameters():
+            if q.requires_grad and getattr(q, '_clv_unscale', None) is None and getattr(q, '_clv_grad', None) is None:
+                q._clv_unscale = q.register_hook(ops.unscale_hook)     # divides by the scale of the backward that is running
+        object.__setattr__(self, '_clv_unscale_done', scale)
 
     def forward(self, imgs=None, label=None, return_loss=True, **kwargs):
         if kwargs.get('gradcam', False):

@@ -23,12 +23,17 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 14
+#define CLV_ABI_VERSION 15
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
 
 int clv_abi_version(void);
+/* The 16-bit element type this build of the library computes in: 0 = bf16 (libclover_hip.so), 1 = IEEE fp16
+ * (libclover_hip_f16.so: the same sources compiled with -DCLV_HALF_F16 — the reference's own arithmetic type,
+ * configs/exp_local/pretrain_webvid_cc3m.py:21, mmaction/core/hooks/fp16_utils.py:215-259).  Every `bf16` in the comments
+ * below reads "the library's 16-bit element type". */
+int clv_half_type(void);
 
 /* ------------------------------------------------------------------ attention
  * One kernel family serves both attention flavours of the path:

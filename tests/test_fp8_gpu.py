@@ -7,7 +7,12 @@ import sys
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+from clover_amd import _lib as _clv_lib  # noqa: E402
+
+# fp8 forward GEMMs quantise bf16 tensors (BASELINE config 5: "fp8 MFMA QKV / patch-proj path" over the bf16 step): this file
+# runs in the bf16 build of the kernels — in the default (fp16) test process it is skipped and tests/test_bf16_build_gpu.py
+# runs it in a child process with CLOVER_HALF=bf16
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(_clv_lib.HALF_F16, reason='fp8 path: bf16 build (see test_bf16_build_gpu.py)')]
 DEV = 'cuda'
 BF = torch.bfloat16
 F8 = torch.float8_e4m3fn

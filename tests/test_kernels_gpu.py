@@ -11,7 +11,9 @@ from oracle import indexing as ix          # noqa: E402
 from oracle import model as om             # noqa: E402
 
 DEV = 'cuda'
-BF = torch.bfloat16
+from clover_amd import _lib as _clv_lib  # noqa: E402
+
+BF = _clv_lib.half_dtype()          # the library's 16-bit element type (bf16; fp16 under CLOVER_HALF=f16)
 
 
 def rel(a, b):

@@ -162,7 +162,7 @@ def test_parity_isolation_per_rounding_source(model):
     shipped bf16 path cannot meet the north-star bound and the fp32 parity mode exists; (iv) all five together land within
     the bf16 tolerances of the reference, i.e. the emulation accounts for the training path's error."""
     from clover_amd import parity
-    from test_step_gpu import LOSS_TOL
+    from test_step_gpu import LOSS_TOL_BF16 as LOSS_TOL          # the re-injected roundings are bf16 ones
     g = gutil.load('g_step.npz')
     broke = set()
     for B in (2, 4):

@@ -41,7 +41,12 @@ import gutil
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 LOSS_KEYS = ['mlm_loss', 'nce_loss', 'rank_t_tm_loss', 'v_nce_loss', 'rank_v_vm_loss', 'loss']
-LOSS_TOL = dict(mlm_loss=8.1e-3, nce_loss=1.5e-2, rank_t_tm_loss=1.5e-2, v_nce_loss=2.5e-2, rank_v_vm_loss=1.7e-2, loss=2.8e-2)
+# per key, 1.5 x the largest |loss - reference| measured (tables in the module docstring): the bf16 build of the kernels
+# (CLOVER_HALF=bf16) and the default fp16 build (three more significand bits: the reference's own arithmetic type)
+LOSS_TOL_BF16 = dict(mlm_loss=8.1e-3, nce_loss=1.5e-2, rank_t_tm_loss=1.5e-2, v_nce_loss=2.5e-2, rank_v_vm_loss=1.7e-2, loss=2.8e-2)
+LOSS_TOL_F16 = dict(mlm_loss=1e-3, nce_loss=2e-3, rank_t_tm_loss=3.3e-3, v_nce_loss=2.8e-3, rank_v_vm_loss=2.4e-3, loss=4.5e-3)
+from clover_amd import _lib as _clv_lib  # noqa: E402
+LOSS_TOL = LOSS_TOL_F16 if _clv_lib.HALF_F16 else LOSS_TOL_BF16
 
 
 def grad_tol(name):
@@ -457,7 +462,8 @@ def test_bench_shapes_step_matches_reference(mode):
     for k in LOSS_KEYS:
         assert errs[k] <= LOSS_TOL[k], (k, lv[k], float(g[f'T8.{k}']))
     named = dict(m.named_parameters())
-    worst = {k: rel_packed(g, f'T8.grad.{k}', named[k].grad) for k in FULL_GRAD_KEYS['T']}
+    # (the slabs hold the gradients times the loss scale of the 16-bit backward: 1024 in the fp16 build, 1 in the bf16 one)
+    worst = {k: rel_packed(g, f'T8.grad.{k}', named[k].grad / eng.loss_scale) for k in FULL_GRAD_KEYS['T']}
     print(f'bench-shape (B = 8, {mode}) grad rel errors', worst)
     for k, e in worst.items():
         assert e < FULL_GRAD_TOL, (k, e)
