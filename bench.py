@@ -248,8 +248,12 @@ def main():
         del cb
 
     batch = {k: v.to(dev) for k, v in synthetic_batch(args.batch, args.frames, args.tokens, 1000 + rank).items()}
+    # loss scaling as the headline config has it (pretrain_webvid_cc3m.py:21 fp16 = dict(loss_scale='dynamic')): the dynamic
+    # scaler on the device, started at the scale the reference's settles near instead of 2**32 — the first ~20 steps of a
+    # 2**32 start overflow and are skipped, and a skipped step is not a measured step ("steps_skipped" below must be 0)
+    scaler = dict(init_scale=1024.0, mode='dynamic') if args.dtype == 'f16' else None
     engine = CloverEngine(model, batch, lr=5e-5 / 1024 * args.batch * world, weight_decay=0.005, grad_clip=15.0,
-                          max_iters=100000)
+                          max_iters=100000, loss_scale=scaler)
     # GEMMs that left the own kernels BEFORE the measured step exists (the eval-mode loss check above on the un-managed
     # model, the engine's parameter census: both run the MLM decoder before its vocabulary rows are padded in the slab)
     # are reported apart from those of the step itself (eager step, capture, warm-up, timed region)
@@ -276,11 +280,13 @@ def main():
         ops.PROF = {}
     if engine.reducer.active:
         engine.reducer.start_timing()                    # stall of the compute stream on the gradient all-reduces
+    skipped0 = ops.optim_state_read(engine.optim_state)['skipped']
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = engine.step(batch)
     sync()
     dt = time.perf_counter() - t0
+    steps_skipped = ops.optim_state_read(engine.optim_state)['skipped'] - skipped0      # overflow-skipped updates in the timed region
     exposed_comm_ms = engine.reducer.exposed_ms() if engine.reducer.active else None
     prof, ops.PROF = ops.PROF, None
     prof_steps = args.steps
@@ -346,6 +352,7 @@ def main():
             'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
             'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
             'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
+            'loss_scale': engine.loss_scaler_state(), 'steps_skipped': steps_skipped,
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             # data-parallel runs: mean per-step stall of the compute stream on the gradient all-reduces (rank 0), and what
             # travels: bf16 gradients in per-class buckets (null at N = 1: no collective is issued)

@@ -24,14 +24,18 @@ LIB_PATH = os.environ.get('CLOVER_LIB_PATH') or os.path.join(_HERE, 'libclover_h
 # divides it out — the engine inside its norm / AdamW kernels (their grad_scale factor), plain autograd users through a
 # per-parameter gradient hook the recognizer registers (so `loss.backward()` leaves true-scale .grad tensors either way).
 # bf16 has fp32's exponent range and needs none.
-LOSS_SCALE = float(os.environ.get('CLOVER_LOSS_SCALE', '1024' if HALF_F16 else '1'))
+# CLOVER_LOSS_SCALE: a number (static) or 'dynamic' (the reference's LossScaler(mode='dynamic') — engine only: it lives on
+# the device next to the optimizer's scalars; plain autograd then uses the static default).
+_scale_env = os.environ.get('CLOVER_LOSS_SCALE', '1024' if HALF_F16 else '1')
+LOSS_SCALE_SPEC = 'dynamic' if _scale_env.strip().lower() == 'dynamic' else float(_scale_env)
+LOSS_SCALE = (1024.0 if HALF_F16 else 1.0) if LOSS_SCALE_SPEC == 'dynamic' else LOSS_SCALE_SPEC
 
 
 def half_dtype():
     import torch
     return torch.float16 if HALF_F16 else torch.bfloat16
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}

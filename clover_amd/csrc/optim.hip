@@ -107,15 +107,27 @@ struct OptimState {
     int t;             // Adam steps taken so far
     int skipped;       // steps skipped so far
     int pad;
+    // The loss scaler (fp16_utils.py:285-389 LossScaler), also on the device: the backward's root gradient is multiplied by
+    // loss_scale (read from here by the host graph), clv_optim_prep divides it out again and — in dynamic mode — moves it.
+    float loss_scale;      // current scale; 0: no scaler in use (the caller folds any static scale into grad_scale)
+    float scale_factor;    // dynamic: the factor the scale moves by (reference default 2)
+    int scale_window;      // dynamic: overflow-free iterations before the scale grows (reference default 1000)
+    int scale_iter;        // LossScaler.cur_iter
+    int last_overflow;     // LossScaler.last_overflow_iter (host initialises it to -1)
+    int dynamic;           // 1: LossScaler(mode='dynamic'); 0: static
+    int pad2[2];
 };
 
 __global__ void optim_prep_kernel(float* __restrict__ acc, OptimState* __restrict__ st, float beta1, float beta2,
                                   float max_norm, float grad_scale) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float ss = acc[0] * grad_scale * grad_scale;
-    acc[0] = 0.f;                                              // ready for the next step's clv_sumsq calls
     OptimState o = *st;
-    if (!(ss == ss) || ss > 3.0e38f) {
+    if (o.loss_scale > 0.f) grad_scale /= o.loss_scale;        // (a power of two unless the caller chose otherwise: exact)
+    const float raw = acc[0];
+    const float ss = raw * grad_scale * grad_scale;
+    acc[0] = 0.f;                                              // ready for the next step's clv_sumsq calls
+    const bool overflow = !(ss == ss) || ss > 3.0e38f || raw > 3.0e38f;
+    if (overflow) {
         o.skip = 1;
         o.skipped += 1;
         o.norm = ss;
@@ -128,6 +140,15 @@ __global__ void optim_prep_kernel(float* __restrict__ acc, OptimState* __restric
         o.coef = c;
         o.bc1 = (float)(1.0 - pow((double)beta1, (double)o.t));
         o.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)o.t));
+    }
+    if (o.dynamic && o.loss_scale > 0.f) {                     // LossScaler.update_scale (fp16_utils.py:351-362)
+        if (overflow) {
+            o.loss_scale = fmaxf(o.loss_scale / o.scale_factor, 1.f);
+            o.last_overflow = o.scale_iter;
+        } else if (o.scale_window > 0 && (o.scale_iter - o.last_overflow) % o.scale_window == 0) {
+            o.loss_scale *= o.scale_factor;
+        }
+        o.scale_iter += 1;
     }
     *st = o;
 }

@@ -204,14 +204,28 @@ class _Segment:
 class CloverEngine:
     def __init__(self, model, sample_batch, lr=5e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.005,
                  paramwise_cfg=None, grad_clip=15.0, max_iters=100000, warmup_iters=0, min_lr_ratio=1e-3,
-                 warmup_ratio=1e-3, bucket_mb=64):
+                 warmup_ratio=1e-3, bucket_mb=64, loss_scale=None):
         self.model = model
-        # Loss scaling (mmcv_Fp16OptimizerHook.py:96-149): the recognizer scales the gradient at the root of every backward by
-        # _lib.LOSS_SCALE (fp16 build: 1024; bf16: 1 — BaseRecognizer._parse_losses); the gradients in the slabs are scaled,
-        # and the norm / AdamW kernels divide the scale out through their grad_scale factor (next to the 1 / world of the
-        # gradient average).  A non-finite norm skips the step on the device as before.
+        # Loss scaling (mmcv_Fp16OptimizerHook.py:33-50,96-149; `fp16 = dict(loss_scale='dynamic')` in the headline config,
+        # pretrain_webvid_cc3m.py:21).  `loss_scale` takes what the hook takes: a float (static), 'dynamic'
+        # (LossScaler(mode='dynamic'): 2**32, factor 2, window 1000) or a dict of LossScaler arguments; None = the build's
+        # default (_lib.LOSS_SCALE / CLOVER_LOSS_SCALE: static 1024 for fp16, none for bf16).  The scaler lives on the DEVICE
+        # next to the optimizer's scalars (ops.optim_state_set_scaler): the recognizer multiplies the root gradient of every
+        # backward by it (BaseRecognizer._parse_losses reads model._clv_loss_scale_dev), the gradients in the slabs are
+        # scaled, clv_optim_prep divides the scale out of the norm and the update, skips the step on an overflow and moves a
+        # dynamic scale — no host round trip, and a captured step follows the scale without re-capture.
         from . import _lib as _clv_lib
-        self.loss_scale = float(_clv_lib.LOSS_SCALE)
+        if loss_scale is None:
+            loss_scale = _clv_lib.LOSS_SCALE_SPEC
+        if loss_scale == 'dynamic':
+            self.scaler_cfg = dict(init_scale=2.0 ** 32, mode='dynamic', scale_factor=2.0, scale_window=1000)
+        elif isinstance(loss_scale, dict):
+            self.scaler_cfg = dict(dict(init_scale=2.0 ** 32, mode='dynamic', scale_factor=2.0, scale_window=1000), **loss_scale)
+        elif isinstance(loss_scale, (int, float)):
+            self.scaler_cfg = dict(init_scale=float(loss_scale), mode='static', scale_factor=2.0, scale_window=1000)
+        else:
+            raise ValueError(f'loss_scale must be of type float, dict, or "dynamic", got {loss_scale}')
+        assert self.scaler_cfg['mode'] in ('dynamic', 'static'), 'mode can only be dynamic or static'
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.base_lr, self.betas, self.eps = lr, betas, eps
@@ -273,6 +287,11 @@ class CloverEngine:
                          for (wd, lm), members in sorted(classes.items(), key=lambda kv: (-kv[0][0], kv[0][1]))]
         self.sumsq = torch.zeros(1, device=device, dtype=torch.float32)
         self.optim_state = ops.optim_state_new(device)
+        self._scaler_on = self.scaler_cfg['mode'] == 'dynamic' or self.scaler_cfg['init_scale'] != 1.0
+        if self._scaler_on:
+            ops.optim_state_set_scaler(self.optim_state, self.scaler_cfg['init_scale'], self.scaler_cfg['mode'] == 'dynamic',
+                                       self.scaler_cfg['scale_factor'], self.scaler_cfg['scale_window'])
+        object.__setattr__(model, '_clv_loss_scale_dev', self.optim_state.view(torch.float32)[8] if self._scaler_on else False)     # False: an engine without a scaler
         self.num_params = sum(p.numel() for _, p in used)
 
         # ---- gradient buckets (contiguous slices of the flat grad buffers) + readiness hooks
@@ -813,7 +832,7 @@ class CloverEngine:
                                        'engine.reducer.finish()')
                 torch._foreach_zero_(stale)
         self._stale_cleared = False
-        gscale = 1.0 / (self.world * self.loss_scale)   # DDP averages the summed gradients; the loss scale is divided out
+        gscale = 1.0 / self.world      # DDP averages the summed gradients (the loss scale is divided out on the device)
         grads = self.wire if self.wire is not None else [seg.flat_g for seg in self.segments]   # reduced gradients
         for g in grads:
             ops.sumsq_accumulate(g, self.sumsq)
@@ -830,6 +849,7 @@ class CloverEngine:
         """AdamW state for checkpoints: per segment the flat moments + names/offsets, and the step count."""
         st = ops.optim_state_read(self.optim_state)
         return dict(step=st['t'], skipped=st['skipped'], calls=self.step_count, lr_iter=self.lr_iter,
+                    loss_scaler=self.loss_scaler_state(st),
                     segments=[dict(names=list(sg.names), offsets=list(sg.offsets), weight_decay=sg.weight_decay,
                                    lr_mult=sg.lr_mult,
                                    exp_avg=sg.exp_avg.detach().cpu(), exp_avg_sq=sg.exp_avg_sq.detach().cpu())
@@ -841,6 +861,13 @@ class CloverEngine:
         self.optim_state.zero_()
         self.optim_state[5] = int(state['step'])                 # Adam's t (ops.optim_state_read layout)
         self.optim_state[6] = int(state.get('skipped', 0))
+        if self._scaler_on:
+            sc = dict(cur_scale=self.scaler_cfg['init_scale'], cur_iter=0, last_overflow_iter=-1)
+            if self.scaler_cfg['mode'] == 'dynamic':      # (a static scale is configuration, not state)
+                sc.update(state.get('loss_scaler') or {})
+            ops.optim_state_set_scaler(self.optim_state, sc['cur_scale'], self.scaler_cfg['mode'] == 'dynamic',
+                                       self.scaler_cfg['scale_factor'], self.scaler_cfg['scale_window'],
+                                       sc['cur_iter'], sc['last_overflow_iter'])
         assert len(self.segments) == len(state['segments']), 'optimizer state belongs to a different parameter layout'
         for sg, st in zip(self.segments, state['segments']):
             assert list(sg.names) == list(st['names']), 'optimizer state belongs to a different parameter layout'
@@ -873,6 +900,21 @@ class CloverEngine:
         for sg in self.segments:
             sg.shadow.copy_(sg.flat_p)
             sg.refresh_transposed()
+
+    @property
+    def loss_scale(self):
+        """The scale the NEXT backward will use (host sync; 1.0 without a scaler)."""
+        return ops.optim_state_read(self.optim_state)['loss_scale'] if self._scaler_on else 1.0
+
+    def loss_scaler_state(self, st=None):
+        """LossScaler.state_dict() (fp16_utils.py:364-373) — what the reference keeps in runner.meta['fp16']['loss_scaler']
+        (mmcv_Fp16OptimizerHook.py:147-149); None without a scaler."""
+        if not self._scaler_on:
+            return None
+        st = st or ops.optim_state_read(self.optim_state)
+        return dict(cur_scale=st['loss_scale'], cur_iter=st['scale_iter'], mode=self.scaler_cfg['mode'],
+                    last_overflow_iter=st['last_overflow'], scale_factor=st['scale_factor'],
+                    scale_window=st['scale_window'])
 
     def grad_norm(self):
         """Global gradient norm of the last step's (averaged) gradients — host sync, logging only."""

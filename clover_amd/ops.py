@@ -89,6 +89,25 @@ def scale_grad(x, s):
     return _ScaleGrad.apply(x, s) if (s != 1.0 and x.requires_grad) else x
 
 
+class _ScaleGradDev(torch.autograd.Function):
+    """_ScaleGrad with the scale held in DEVICE memory (the engine's loss scaler, clv_optim_prep moves it): the multiply
+    reads it when the kernel runs, so a captured backward follows a dynamic scale without re-capture.  The engine's
+    optimizer kernels divide the same device value out again."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def scale_grad_dev(x, s):
+    return _ScaleGradDev.apply(x, s) if x.requires_grad else x
+
+
 # --------------------------------------------------------------------------- in-process kernel timing
 # bench.py sets PROF = {} for the timed region: every attention launch is then bracketed by HIP
 # events recorded on the launch stream (no synchronisation), and the elapsed times are read after
@@ -2469,7 +2488,7 @@ def adamw_step(p, g, m, v, shadow, sumsq, lr, beta1, beta2, eps, weight_decay, s
           'clv_adamw_step')
 
 
-OPTIM_STATE_BYTES = 32
+OPTIM_STATE_BYTES = 64
 
 
 def optim_state_new(device):
@@ -2478,11 +2497,23 @@ def optim_state_new(device):
 
 
 def optim_state_read(state):
-    """Host copy (syncs): dict(coef, bc1, bc2_sqrt, norm, skip, t, skipped)."""
+    """Host copy (syncs): dict(coef, bc1, bc2_sqrt, norm, skip, t, skipped) + the loss scaler's fields."""
     raw = state.detach().cpu()
     f = raw.view(torch.float32)
     return dict(coef=float(f[0]), bc1=float(f[1]), bc2_sqrt=float(f[2]), norm=float(f[3]), skip=int(raw[4]),
-                t=int(raw[5]), skipped=int(raw[6]))
+                t=int(raw[5]), skipped=int(raw[6]), loss_scale=float(f[8]), scale_factor=float(f[9]),
+                scale_window=int(raw[10]), scale_iter=int(raw[11]), last_overflow=int(raw[12]), dynamic=int(raw[13]))
+
+
+def optim_state_set_scaler(state, init_scale, dynamic, scale_factor=2.0, scale_window=1000, scale_iter=0, last_overflow=-1):
+    """Write the loss scaler's half of the state (LossScaler.__init__ / load_state_dict, fp16_utils.py:314-327,375-385)."""
+    f = state.view(torch.float32)
+    f[8] = float(init_scale)
+    f[9] = float(scale_factor)
+    state[10] = int(scale_window)
+    state[11] = int(scale_iter)
+    state[12] = int(last_overflow)
+    state[13] = 1 if dynamic else 0
 
 
 def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0):

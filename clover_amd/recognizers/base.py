@@ -152,7 +152,12 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         # loss scale of the 16-bit backward (fp16 build: 1024; bf16: 1): applied to the gradient at the root, divided out of
         # every parameter gradient again — by the engine's optimizer kernels, or by the hooks below for plain autograd
         from .. import _lib, ops
-        if _lib.LOSS_SCALE != 1.0 and loss.requires_grad:
+        dev_scale = getattr(self, '_clv_loss_scale_dev', None)      # an engine's device-resident scaler (engine.CloverEngine)
+        if dev_scale is False:
+            pass                                                    # an engine that runs unscaled (loss_scale=1)
+        elif dev_scale is not None and loss.requires_grad:
+            loss = ops.scale_grad_dev(loss, dev_scale)
+        elif _lib.LOSS_SCALE != 1.0 and loss.requires_grad:
             BaseRecognizer._register_unscale_hooks(self, _lib.LOSS_SCALE)     # (unbound: toy recognizers borrow _parse_losses)
             loss = ops.scale_grad(loss, _lib.LOSS_SCALE)
         if not reduce:                                   # inside a hipGraph capture: the caller averages over the ranks

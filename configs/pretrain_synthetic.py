@@ -5,6 +5,7 @@ _base_ = ['_base_default_runtime.py']
 videos_per_gpu = 8
 base_lr = 5e-5 / 1024
 weight_decay = 0.005
+fp16 = dict(loss_scale='dynamic')                       # as the reference (pretrain_webvid_cc3m.py:21): the engine's device-resident scaler
 import bench as _bench                                   # noqa: E402  (repo root is on sys.path under tools/train.py)
 model = _bench.model_cfg('T', 8)
 data = dict(videos_per_gpu=videos_per_gpu,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 15
+#define CLV_ABI_VERSION 16
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -491,13 +491,18 @@ int clv_transpose_batch(const void* src_base, void* dst_base, const void* table,
                         int32_t total_tiles, void* stream);
 
 /* The same step with the optimizer's scalars held on the DEVICE (no host sync, hipGraph-safe):
- * state = CLV_OPTIM_STATE_BYTES bytes {float coef, bc1, bc2_sqrt, norm; int32 skip, t, skipped, pad}, zeroed once by
- * the caller.  clv_optim_prep (one thread, after every segment's clv_sumsq): reads and re-zeroes sumsq, computes the
+ * state = CLV_OPTIM_STATE_BYTES bytes {float coef, bc1, bc2_sqrt, norm; int32 skip, t, skipped, pad; float loss_scale,
+ * scale_factor; int32 scale_window, scale_iter, last_overflow, dynamic, pad, pad}, zeroed once by the caller.  The second
+ * half is the reference's LossScaler (mmaction/core/hooks/fp16_utils.py:285-389) held on the device: with loss_scale > 0
+ * the caller multiplies the root gradient of its backward by state.loss_scale (a device read: it stays inside a hipGraph),
+ * clv_optim_prep divides it out of the norm and the update, and with dynamic = 1 applies update_scale (:351-362): an
+ * overflow (non-finite norm) halves the scale (floor 1) and records the iteration, scale_window overflow-free iterations
+ * since then grow it by scale_factor (the host sets last_overflow = -1, scale_factor and scale_window once).  clv_optim_prep (one thread, after every segment's clv_sumsq): reads and re-zeroes sumsq, computes the
  * clip coefficient (grad_scale * min(1, max_norm/(norm+1e-6)); max_norm <= 0: no clipping); a finite norm advances
  * Adam's step count t and refreshes the bias corrections, a non-finite one sets skip — the reference skips
  * optimizer.step() on overflow (mmcv_Fp16OptimizerHook.py:123-141), so Adam's step count does not advance either.
  * clv_adamw_step_dev: clv_adamw_step with coefficient / bias corrections / skip read from state. */
-#define CLV_OPTIM_STATE_BYTES 32
+#define CLV_OPTIM_STATE_BYTES 64
 int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float max_norm, float grad_scale,
                    void* stream);
 int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow, const void* state, int64_t n,

@@ -7,7 +7,7 @@ this file.  The parity tests (and the GPU box) only ever read the fixtures.
     python tests/golden/make_goldens.py            # all sets
     python tests/golden/make_goldens.py dist       # one set
 
-Sets: idx, swin, bert_fuse, heads_loss, step, mid (VideoSwin-T stage widths: the HIP GEMMs' shapes), dist, inflate, test, finetune, full (benchmark shapes:
+Sets: scaler (LossScaler trajectories), idx, swin, bert_fuse, heads_loss, step, mid (VideoSwin-T stage widths: the HIP GEMMs' shapes), dist, inflate, test, finetune, full (benchmark shapes:
 ~10 minutes and ~40 GB on 8 cores; not part of the default list), full8 (config 2 at the benchmark's batch of 8).
 """
 import json
@@ -557,7 +557,27 @@ def gen_full8():
     gen_full(cases=(('T', 8),), B=8, fname='g_full_b8.npz')
 
 
-SETS = dict(idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
+def gen_scaler():
+    """The reference's LossScaler (core/hooks/fp16_utils.py:285-389) driven by fixed overflow sequences: the scale BEFORE
+    every iteration and the scaler's state_dict at the end."""
+    H.install_shims()
+    from mmaction.core.hooks.fp16_utils import LossScaler
+    out = {}
+    for name, kw, flags in cf.scaler_cases():
+        sc = LossScaler(**kw)
+        scales = []
+        for f in flags:
+            scales.append(float(sc.loss_scale))
+            sc.update_scale(bool(f))
+        st = sc.state_dict()
+        out[name + '.flags'] = np.array(flags, dtype=np.int8)
+        out[name + '.scales'] = np.array(scales, dtype=np.float64)
+        out[name + '.final'] = np.array([st['cur_scale'], st['cur_iter'], st['last_overflow_iter'], st['scale_factor'],
+                                         st['scale_window']], dtype=np.float64)
+    save('g_scaler.npz', out)
+
+
+SETS = dict(scaler=gen_scaler, idx=gen_idx, swin=gen_swin, bert_fuse=gen_bert_fuse, heads_loss=gen_heads_loss,
             step=gen_step, mid=gen_mid, dist=gen_dist, inflate=gen_inflate, test=gen_test, finetune=gen_finetune)
 
 HEAVY = dict(full=gen_full, full8=gen_full8)      # only on request

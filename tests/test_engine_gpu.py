@@ -160,6 +160,74 @@ def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():
     assert s['norm'] > 0 and s['coef'] <= 1.0
 
 
+@pytest.mark.parametrize('mode', ['eager', 'graph'])
+def test_dynamic_loss_scaler_on_the_device_follows_the_reference_rule(mode):
+    """`fp16 = dict(loss_scale='dynamic')` (pretrain_webvid_cc3m.py:21): the engine's loss scaler lives on the device and is
+    moved by clv_optim_prep.  Started far too high (every step overflows until the scale fits), with a short growth window:
+    the scale before every step must equal the reference's LossScaler (oracle/loss_scaler.py, pinned on the reference class)
+    driven by the overflow flags the device reports; a skipped step leaves parameters and Adam's count alone; a captured
+    step follows the moving scale without re-capture; taken steps train (loss falls); the scaler state round-trips through
+    optimizer_state() like runner.meta['fp16']['loss_scaler'] (mmcv_Fp16OptimizerHook.py:74-78,147-149)."""
+    from clover_amd import ops
+    from clover_amd.engine import CloverEngine
+    from oracle.loss_scaler import LossScaler
+    b = batch(2, 'dyn')
+    kw = dict(init_scale=2.0 ** 120, mode='dynamic', scale_factor=2.0 ** 12, scale_window=3)
+    eng = CloverEngine(make_model(), b, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, loss_scale=kw)
+    if mode == 'graph':
+        assert eng.capture(b)
+    ref = LossScaler(**kw)
+    assert eng.loss_scale == ref.loss_scale
+    taken, skipped, losses = 0, 0, []
+    for it in range(26):
+        p0 = [sg.flat_p.clone() for sg in eng.segments]
+        out = eng.step(b)
+        st = ops.optim_state_read(eng.optim_state)
+        ref.update_scale(bool(st['skip']))
+        assert st['loss_scale'] == ref.loss_scale and st['scale_iter'] == ref.cur_iter, (it, st, ref.state_dict())
+        assert st['last_overflow'] == ref.last_overflow_iter
+        same = all(torch.equal(sg.flat_p, q) for sg, q in zip(eng.segments, p0))
+        assert same == bool(st['skip']), (it, st)
+        taken += 0 if st['skip'] else 1
+        skipped += st['skip']
+        if not st['skip']:
+            losses.append(float(out['log_vars']['loss']))
+        assert st['t'] == taken and st['skipped'] == skipped
+    print(mode, 'taken', taken, 'skipped', skipped, 'scale', eng.loss_scale, losses[:2], losses[-2:])
+    assert skipped >= 5 and taken >= 8                        # 2**120 needs >= 9 divisions by 2**12 before anything fits
+    assert losses[-1] < losses[0]
+    # the logged loss is the true (unscaled) one, finite even on skipped steps
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    state = eng.optimizer_state()
+    assert state['loss_scaler'] == dict(ref.state_dict(), cur_scale=float(ref.cur_scale))
+    eng2 = CloverEngine(make_model(), b, lr=2e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, loss_scale=kw)
+    eng2.load_optimizer_state(state)
+    assert eng2.loss_scaler_state() == state['loss_scaler'] and eng2.adam_steps() == taken
+
+
+def test_static_loss_scale_equals_unscaled_update_in_exact_arithmetic():
+    """A static power-of-two scale is exact wherever nothing under- or overflows: two engines that differ only in the scale
+    (256 and 4096) must take (nearly) the same first step — the scale is multiplied in at the root and divided out in
+    clv_optim_prep."""
+    from clover_amd.engine import CloverEngine
+    b = batch(2, 'stat')
+    ps = []
+    for scale in (256.0, 4096.0):
+        eng = CloverEngine(make_model(), b, lr=1e-3, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, loss_scale=scale)
+        assert eng.loss_scale == scale
+        eng.step(b)
+        ps.append((torch.cat([sg.flat_p for sg in eng.segments]).clone(), eng.grad_norm()))
+    (p1, n1), (p2, n2) = ps
+    assert abs(n1 - n2) <= 2e-3 * n1, (n1, n2)
+    # Adam's first step is lr * sign(g): only gradients at rounding-noise level may differ
+    assert float(((p1 - p2).abs() > 1e-4).float().mean()) < 0.02
+    m = make_model()
+    eng = CloverEngine(m, b, lr=1e-3, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9, loss_scale=1.0)
+    assert eng.loss_scale == 1.0 and m._clv_loss_scale_dev is False and eng.loss_scaler_state() is None
+    eng.step(b)
+    assert eng.adam_steps() == 1
+
+
 def test_engine_gradient_slab_equals_plain_autograd():
     """The engine's plumbing — gradient sinks into the flat fp32 slab, bf16 shadow weights, fused Q|K|V slab
     views (clv_fuse_groups) — must leave exactly the gradients plain autograd computes on an identical model."""

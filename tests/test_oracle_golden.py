@@ -289,3 +289,20 @@ def test_oracle_step_at_mid_widths(B):
     loss.backward()
     for n in [n[len(f'B{B}.grad.'):-4] for n in g.files if n.startswith(f'B{B}.grad.') and n.endswith('.sub')]:
         gutil.assert_packed(g, f"B{B}.grad.{n}", P[n].grad, rtol=5e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ loss scaler (exact)
+def test_loss_scaler_matches_reference_trajectories():
+    """oracle/loss_scaler.py against the reference's own LossScaler (fp16_utils.py:285-389) driven by the same overflow
+    flags: the scale before every iteration and the final state_dict, exactly (powers of two)."""
+    from oracle.loss_scaler import LossScaler
+    g = gutil.load('g_scaler.npz')
+    for name, kw, flags in cf.scaler_cases():
+        assert g[name + '.flags'].tolist() == list(flags)
+        sc = LossScaler(**kw)
+        for i, f in enumerate(flags):
+            assert float(sc.loss_scale) == float(g[name + '.scales'][i]), (name, i)
+            sc.update_scale(bool(f))
+        st = sc.state_dict()
+        assert [float(st[k]) for k in ('cur_scale', 'cur_iter', 'last_overflow_iter', 'scale_factor', 'scale_window')] \
+            == g[name + '.final'].tolist(), name

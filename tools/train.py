@@ -88,7 +88,10 @@ def main():
     engine = CloverEngine(model, next(iter(loaders[0])), lr=lr, betas=tuple(opt.get('betas', (0.9, 0.999))),
                           eps=opt.get('eps', 1e-8), weight_decay=opt.get('weight_decay', 0.0),
                           paramwise_cfg=opt.get('paramwise_cfg'),
-                          grad_clip=(cfg.get('optimizer_config', {}).get('grad_clip') or {}).get('max_norm', 0.0))
+                          grad_clip=(cfg.get('optimizer_config', {}).get('grad_clip') or {}).get('max_norm', 0.0),
+                          # `fp16 = dict(loss_scale=...)` of a reference config (pretrain_webvid_cc3m.py:21) -> the engine's
+                          # device-resident loss scaler (fp16 build; the bf16 build keeps its default: none)
+                          loss_scale=(cfg.get('fp16') or {}).get('loss_scale') if clover_amd._lib.HALF_F16 else None)
     if lrc.get('policy', 'CosineAnnealing') != 'CosineAnnealing' or lrc.get('by_epoch', True):
         raise NotImplementedError('lr_config: only CosineAnnealing with by_epoch=False (the reference recipe)')
     if cfg.get('hip_graph', True):                       # static shapes: replay the step as hipGraphs
