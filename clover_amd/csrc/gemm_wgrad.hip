@@ -903,427 +903,6 @@ __global__ void __launch_bounds__(256 * PN * PK) wgrad_big_group_kernel(WgGroup 
                                       pr.want_bias, pr.xcd_rot);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Shape-fitted tiles (class 4: wgrad_tile_group_kernel).  Every Linear of Swin-T and of BERT-base has N and K that are
-// multiples of 96 (96 .. 3072, 30528), so a workgroup tile is (96 a) x (96 b) with a | N / 96, b | K / 96, a b <= 8:
-// eight waves of 96 x 96 outputs each (6 x 6 MFMA 16x16x32 blocks per 32-row stage against 12 transposed fragment reads:
-// 144 accumulator registers, two waves per SIMD, one workgroup per CU).  What this buys over the 128 x 128 class:
-//   * no column overhang at all (N = 96 / 288 / 192 on 128-column tiles multiplied clamped columns);
-//   * 192 x 384 tiles stage HALF the bytes per MFMA (the 128 x 128 loop runs at the CU's L2 -> LDS rate),
-//     and a slice of a stage-2 problem is 2-8 tiles instead of 9-36, so its tiles stay in step on their XCD's L2;
-//   * the token-parallel layers (stage 0 / 1: N x K <= 384 x 96, 192 x 384, ...) are ONE tile per slice: every dY / X
-//     row leaves HBM exactly once, whatever the L2 does.
-// Stage image in LDS: [32 rows][W columns] per operand, linear in 16-byte chunks (what LDS-DMA writes: wave base +
-// lane x 16 B), so a stage is exactly W / 16 pieces of 1 KiB and a full-width tile (W = ld) is one contiguous run of
-// global memory.  Conflict-free transposed reads need the 8 rows a half-wave touches at one column on 8 different
-// 32-byte bank groups: with w = W / 16 groups per row, group u of row r is stored at u ^ ((r >> (3 - t)) & (2^t - 1)),
-// t = min(3, ctz(w)) (w odd: the rows are already spread) — applied on the SOURCE side of the DMA and by the reads.
-constexpr int WT_MAXPW = 5;                                  // pieces per wave and stage: (6 a + 6 b) / 8 waves, a + b <= 6
-constexpr int WT_GROUP_MAX = 34;
-struct WtProblem {
-    const bf16_t* dy;
-    const bf16_t* x;
-    float* work;                                             // partials, or dW itself (in place)
-    float* db;                                               // in place only
-    int64_t M, rows_per_split;
-    int N, K, ldy, ldx;
-    int a, b;                                                // tile = 96 a x 96 b
-    int tilesK, team_size, n_teams, first_team;              // team = the tiles of one slice (in place: <= 32 consecutive tiles)
-    int flags;                                               // 1: bias, 2: in place, 4: overwrite (in place), 8: teams are tile groups
-    int tiles;
-    unsigned short qbase[8];                                 // first queue position of this problem's blocks on XCD x
-};
-struct WtGroup {
-    WtProblem p[WT_GROUP_MAX];
-    int n;
-};
-static_assert(sizeof(WtGroup) <= 4064, "kernel-argument budget");
-
-#ifdef WT_TRACE
-// -DWT_TRACE (tools/probes/bin variant only): wave 0 (group A) and wave 4 (group B) of every workgroup add their s_memtime
-// deltas per phase — A: [0] MFMA phase, [1] wait + barrier, [2] fragment reads, [3] DMA issue, [4] second barrier;
-// B: [8..12] reads, issue, wait + barrier, MFMA, second barrier; [5] prologue, [6] whole loop (wave 0), [7] stages — to
-// g_wt_trace; clv_wt_trace_read() returns and clears the sums.
-__device__ unsigned long long g_wt_trace[16];
-#define WT_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#else
-#define WT_T(var)
-#endif
-// ring depth for a stage of P KiB: as deep as 144 KiB allow, at most 8 (a 96 x 96 tile streams 12 KiB stages: with 4 slots
-// a CU would have 36 KiB in flight, with 8 it has 72)
-__host__ __device__ __forceinline__ int wt_ring(int P) {
-    const int r = 144 / P;
-    return r > 8 ? 8 : r;
-}
-
-// Schedule.  The eight waves are two groups: A = waves 0-3, B = waves 4-7 (wave w and w + 4 share a SIMD).  A stage s takes
-// two half-steps, each closed by ONE s_barrier:
-//     h = 2 s     : A multiplies stage s from the fragments it holds in registers | B reads its fragments of stage s, then
-//                   issues its LDS-DMA pieces of stage s + R - 1; both wait until their pieces of stage s + 1 have landed
-//     h = 2 s + 1 : B multiplies stage s | A reads its fragments of stage s + 1, then issues stage s + R - 1
-// so on every SIMD one wave feeds the matrix pipe from registers while its partner is blocked on the vector-memory path
-// (a piece blocks its wave ~100 cycles) and on LDS latency — the first version (all waves: wait, barrier, issue, read,
-// multiply) measured 250 / 550 / 450 / 1 450 cycles for those phases with the matrix pipe idle in the first three
-// (-DWT_TRACE).  A fragment set lives in registers from its read phase to its multiply phase: no double buffering.
-// (A wave issues one ds_read_b64_tr_b16 per ~16 cycles whatever the other waves do — tools/probes/lds_tr_rate.cpp — so its
-// 24 reads of a stage are ~400 cycles of its own time, its 4-5 DMA pieces ~100 each when the memory system is busy.)
-__device__ __forceinline__ void wt_body(unsigned char* smem, const WtProblem& pr, const int split, const int tile) {
-    constexpr int A = 6;
-    WT_T(t_entry);
-    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, lr = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool grpB = wave >= 4;
-    const int a = pr.a, b = pr.b, N = pr.N, K = pr.K, ldy = pr.ldy, ldx = pr.ldx;
-    const int tn = tile / pr.tilesK, tk = tile - tn * pr.tilesK;
-    const int n0 = tn * 96 * a, k0 = tk * 96 * b;
-    const int wy = 6 * a, wx = 6 * b, P = wy + wx;           // 32-byte groups per stage row = 1-KiB pieces per stage
-    const int R = wt_ring(P);
-    const int ty = __builtin_ctz(wy | 8), tx = __builtin_ctz(wx | 8);
-    const unsigned slot_bytes = (unsigned)P * 1024u;
-    const bool active = wave < a * b;
-    const int wa = wave / b, wb = wave - wa * b;             // this wave's 96 x 96 block of the tile (inactive waves: DMA only)
-    const int64_t m_begin = (int64_t)split * pr.rows_per_split;
-    int64_t m_end = m_begin + pr.rows_per_split;
-    if (m_end > pr.M) m_end = pr.M;
-    // db = column sums of dY on the VALU (one v_dot2c_f32_bf16 against (1, 1) per pair of rows; a lane's
-    // dY fragment of block i is 8 rows of ONE column = 4 pair words).  Such an instruction costs ~10 cycles of the matrix
-    // pipe's cover (MI355X_MICROARCH.md, filler prices: 24 of them lengthened a 600-cycle multiply phase to 850), so the b
-    // waves of a tile row — they hold the SAME dY fragments — share the 4 words: bias words [bw0, bw1) of every fragment
-    // are this wave's; the rows meet in LDS after the loop.
-    const bool tile_bias = (pr.flags & 1) && tk == 0;
-    int bw0 = 0, bw1 = 0;
-    if (tile_bias && active) {
-        if (b == 1) bw0 = 0, bw1 = 4;
-        else if (b == 2) bw0 = 2 * wb, bw1 = 2 * wb + 2;
-        else if (wb < 4) bw0 = wb, bw1 = wb + 1;             // b = 3: waves 0, 1, 2 take a word each and wave 0 also the last one
-        if (b == 3 && wb == 0) bw1 = 1;
-    }
-    const int bmode = bw1 - bw0 == 4 ? 7 : bw1 - bw0 == 2 ? 5 + (bw0 >> 1) : bw1 - bw0 == 1 ? 1 + bw0 : 0;
-    const bool b3_extra = tile_bias && active && b == 3 && wb == 0;   // (b = 3: word 3 has no fourth wave — wave 0 adds it after the MFMAs)
-    const int rows = (int)(m_end - m_begin);
-    const int nst = (rows + SM - 1) / SM, nfull = rows / SM;
-
-    // this wave's pieces of a stage: q = wave, wave + 8, ... < P; piece q < wy belongs to dY, the rest to X; piece q holds
-    // the 64 chunks [64 q', 64 q' + 64) of its operand's linear [32][2 w] chunk image
-    const int pv = (P - wave + 7) >> 3;                      // waves with wave < P % 8 issue one piece more
-    unsigned voff[WT_MAXPW];
-    unsigned rowpack = 0;                                    // 6 bits per piece: its stage row (63: no such piece)
-#pragma unroll
-    for (int e = 0; e < WT_MAXPW; ++e) {
-        const int q = wave + 8 * e;
-        if (q >= P) {
-            voff[e] = 0;
-            continue;
-        }
-        const bool isx = q >= wy;
-        const int w = isx ? wx : wy, t = isx ? tx : ty;
-        const int c = (isx ? q - wy : q) * 64 + lane;
-        const int row = c / (2 * w), ch = c - row * 2 * w;
-        const int u = (ch >> 1) ^ ((row >> (3 - t)) & ((1 << t) - 1));
-        const int col = (isx ? k0 : n0) + u * 16 + (ch & 1) * 8;
-        rowpack |= (unsigned)row << (6 * e);
-        voff[e] = (unsigned)((row * (isx ? ldx : ldy) + col) * 2);
-    }
-    const bf16_t* by = pr.dy + m_begin * ldy;
-    const bf16_t* bx = pr.x + m_begin * ldx;
-    const int64_t step_y = (int64_t)SM * ldy, step_x = (int64_t)SM * ldx;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
-    int issued = 0, islot = 0;                               // next stage this wave issues, and its slot (= issued % R)
-    auto issue = [&]() {
-        if (issued < nst) {
-            const unsigned sb = lds0 + (unsigned)islot * slot_bytes + (unsigned)wave * 1024u;
-            if (issued < nfull) {
-#pragma unroll
-                for (int e = 0; e < WT_MAXPW; ++e)
-                    if (e < pv) dma1(sb + (unsigned)e * 8192u, voff[e], (wave + 8 * e >= wy) ? bx : by);
-            } else {                                         // the ragged last stage of the slice: rows past m_end read zeros
-#pragma unroll
-                for (int e = 0; e < WT_MAXPW; ++e)
-                    if (e < pv) {
-                        const char* base = reinterpret_cast<const char*>((wave + 8 * e >= wy) ? bx : by);
-                        const bool in = issued * SM + (int)((rowpack >> (6 * e)) & 63u) < rows;
-                        dma16(in ? reinterpret_cast<const bf16_t*>(base + voff[e]) : zero, sb + (unsigned)e * 8192u);
-                    }
-            }
-            by += step_y;
-            bx += step_x;
-        }
-        ++issued;
-        islot = islot == R - 1 ? 0 : islot + 1;
-    };
-    // pieces of this wave still allowed in flight when stage `need` must have landed: those of the real stages after it
-    // (s_waitcnt takes an immediate: the count is rounded DOWN to one of five — waiting for a few pieces more than needed is
-    // always correct; a 25-way switch on the exact count cost more scalar branches than the wait saved)
-    auto wait_landed = [&](int need) {
-        int last = issued - 1;
-        if (last > nst - 1) last = nst - 1;
-        const int n = (last - need) * pv;
-        if (n >= 12) wait_vm<12>();
-        else if (n >= 10) wait_vm<10>();
-        else if (n >= 8) wait_vm<8>();
-        else if (n >= 4) wait_vm<4>();
-        else wait_vm<0>();
-    };
-
-    f32x4_t acc[A][A];
-    float bsum[A];
-#pragma unroll
-    for (int i = 0; i < A; ++i) {
-        bsum[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < A; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    // transposed-read offsets (bf16 elements from the slot base): rows r, r + 16 of 16-column group 6 wa + i (dY) /
-    // 6 wb + j (X, behind the dY image)
-    unsigned ryx[A];                                         // ry | rx << 16 (both < 36 Ki elements... < 65536)
-    {
-        const int r = lg * 4 + (lr >> 2);
-        const int sy = (r >> (3 - ty)) & ((1 << ty) - 1), sx = (r >> (3 - tx)) & ((1 << tx) - 1);
-#pragma unroll
-        for (int i = 0; i < A; ++i) {
-            const int ry = (r * wy + ((6 * wa + i) ^ sy)) * 16 + (lr & 3) * 4;
-            const int rx = wy * 512 + (r * wx + ((6 * wb + i) ^ sx)) * 16 + (lr & 3) * 4;
-            ryx[i] = (unsigned)ry | ((unsigned)rx << 16);
-        }
-    }
-    const int hy = 16 * wy * 16, hx = 16 * wx * 16;          // rows + 16
-    auto tr = [](const bf16_t* p) {
-        const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
-        union { v4s_t v; uint2 u; } cv;
-        cv.v = v;
-        return cv.u;
-    };
-    Frag8 fa[A], fb[A];
-    int rslot = 0;                                           // slot of the next stage this wave reads (= stage % R)
-    auto read_frags = [&]() {
-#ifndef WT_ABL_NOREAD
-        const bf16_t* S = reinterpret_cast<const bf16_t*>(smem + (unsigned)rslot * slot_bytes);
-#pragma unroll
-        for (int i = 0; i < A; ++i) {
-            const int ry = (int)(ryx[i] & 0xffffu), rx = (int)(ryx[i] >> 16);
-            fa[i].u2[0] = tr(S + ry);
-            fa[i].u2[1] = tr(S + ry + hy);
-            fb[i].u2[0] = tr(S + rx);
-            fb[i].u2[1] = tr(S + rx + hx);
-        }
-#else
-#pragma unroll
-        for (int i = 0; i < A; ++i) {
-            fa[i].u4 = make_uint4(ryx[i], hy, lane, rslot);
-            fb[i].u4 = make_uint4(ryx[i] >> 16, hx, lane, rslot);
-        }
-#endif
-        rslot = rslot == R - 1 ? 0 : rslot + 1;
-    };
-#if CLV_HALF_IS_F16
-    typedef _Float16 bf2_t __attribute__((ext_vector_type(2)));
-    auto dot_ones = [](unsigned w, float c) {
-        union { unsigned u; bf2_t v; } x, one2;
-        x.u = w;
-        one2.u = 0x3c003c00u;                                 // (1.0, 1.0) in fp16
-        return __builtin_amdgcn_fdot2(x.v, one2.v, c, false);
-    };
-#else
-    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-    auto dot_ones = [](unsigned w, float c) {
-        union { unsigned u; bf2_t v; } x, one2;
-        x.u = w;
-        one2.u = CLV_ONE_PAIR;
-        return __builtin_amdgcn_fdot2_f32_bf16(x.v, one2.v, c, false);
-    };
-#endif
-    // the bias words of the fragments just multiplied: <= 6 instructions per wave when four waves share a row, issued
-    // behind the wave's 36 MFMAs
-    auto bias_words = [&]() {
-        if (bmode == 0) return;
-#define WT_BW(W0_, W1_)                                                              \
-    _Pragma("unroll") for (int i = 0; i < A; ++i)                                    \
-        _Pragma("unroll") for (int w = W0_; w < W1_; ++w) bsum[i] = dot_ones(fa[i].u[w], bsum[i]);
-        switch (bmode) {
-            case 1: WT_BW(0, 1) break;
-            case 2: WT_BW(1, 2) break;
-            case 3: WT_BW(2, 3) break;
-            case 4: WT_BW(3, 4) break;
-            case 5: WT_BW(0, 2) break;
-            case 6: WT_BW(2, 4) break;
-            default: WT_BW(0, 4) break;
-        }
-        if (b3_extra) { WT_BW(3, 4) }
-#undef WT_BW
-    };
-    auto multiply = [&]() {
-#ifndef WT_ABL_NOMFMA
-#pragma unroll
-        for (int i = 0; i < A; ++i)
-#pragma unroll
-            for (int j = 0; j < A; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: 4 consecutive k per lane
-#else
-#pragma unroll
-        for (int i = 0; i < A; ++i)
-#pragma unroll
-            for (int j = 0; j < A; ++j)
-                acc[i][j][0] += __uint_as_float(fb[j].u[0] ^ fa[i].u[1]) + __uint_as_float(fb[j].u[2] ^ fa[i].u[3]);
-#endif
-    };
-#ifdef WT_TRACE
-    unsigned long long tp[5] = {0, 0, 0, 0, 0};
-#define WT_ACC(i_, a_, b_) tp[i_] += (b_) - (a_)
-#else
-#define WT_ACC(i_, a_, b_)
-#endif
-
-    // Both groups run R - 1 stages ahead; A refills the slot of stage s - 1 in h = 2 s + 1 (B read it in h = 2 s - 2), B the
-    // slot of stage s - 1 in h = 2 s — never a slot whose fragment reads may still be in flight (A refilling the slot of
-    // stage s right behind the barrier that B's reads of it were only ISSUED before would need B to wait for them).
-    if (!grpB) {
-        for (int d = 0; d < R - 1; ++d) issue();
-        wait_landed(0);
-        __builtin_amdgcn_s_barrier();
-        if (active) read_frags();                            // stage 0
-        __builtin_amdgcn_s_barrier();
-        WT_T(t_loop0);
-        for (int s = 0; s < nst; ++s) {
-            WT_T(t0);
-#ifndef WT_ABL_NOCOMPUTE
-            if (active) {                                    // h = 2 s
-                multiply();
-                bias_words();
-            }
-#endif
-            WT_T(t1);
-            wait_landed(s + 1);
-            __builtin_amdgcn_s_barrier();
-            WT_T(t2);
-#ifndef WT_ABL_NOCOMPUTE
-            if (active && s + 1 < nst) read_frags();         // h = 2 s + 1: stage s + 1 (its latency passes under the issue below)
-#endif
-            WT_T(t3);
-#ifndef WT_ABL_NODMA
-            issue();                                         // stage s + R - 1 into the slot of stage s - 1
-#else
-            ++issued;
-#endif
-            WT_T(t4);
-            __builtin_amdgcn_s_barrier();
-            WT_T(t5);
-            WT_ACC(0, t0, t1); WT_ACC(1, t1, t2); WT_ACC(2, t2, t3); WT_ACC(3, t3, t4); WT_ACC(4, t4, t5);
-        }
-#ifdef WT_TRACE
-        if (tid == 0) {
-            const unsigned long long t_end = __builtin_readcyclecounter();
-            for (int i = 0; i < 5; ++i) atomicAdd(&g_wt_trace[i], tp[i]);
-            atomicAdd(&g_wt_trace[5], t_loop0 - t_entry);
-            atomicAdd(&g_wt_trace[6], t_end - t_loop0);
-            atomicAdd(&g_wt_trace[7], (unsigned long long)nst);
-        }
-#endif
-    } else {
-        for (int d = 0; d < R - 1; ++d) issue();
-        wait_landed(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        for (int s = 0; s < nst; ++s) {
-            WT_T(t0);
-#ifndef WT_ABL_NOCOMPUTE
-            if (active) read_frags();                        // h = 2 s: stage s
-#endif
-            WT_T(t1);
-#ifndef WT_ABL_NODMA
-            issue();                                         // stage s + R - 1 into the slot of stage s - 1
-#else
-            ++issued;
-#endif
-            WT_T(t2);
-            wait_landed(s + 1);
-            __builtin_amdgcn_s_barrier();
-            WT_T(t3);
-#ifndef WT_ABL_NOCOMPUTE
-            if (active) {                                    // h = 2 s + 1
-                multiply();
-                bias_words();
-            }
-#endif
-            WT_T(t4);
-            __builtin_amdgcn_s_barrier();
-            WT_T(t5);
-            WT_ACC(0, t0, t1); WT_ACC(1, t1, t2); WT_ACC(2, t2, t3); WT_ACC(3, t3, t4); WT_ACC(4, t4, t5);
-        }
-#ifdef WT_TRACE
-        if (tid == 256)
-            for (int i = 0; i < 5; ++i) atomicAdd(&g_wt_trace[8 + i], tp[i]);
-#endif
-    }
-#undef WT_ACC
-    wait_vm<0>();
-    if (tile_bias && b > 1) {
-        // the b waves of a tile row each summed some of the pair words: meet in LDS (the ring is drained), wave wb = 0 keeps the total
-        float* red = reinterpret_cast<float*>(smem);
-        __builtin_amdgcn_s_barrier();                        // everybody is through with the ring
-        if (active && wb > 0) {
-#pragma unroll
-            for (int i = 0; i < A; ++i) red[(wave * A + i) * 64 + lane] = bsum[i];
-        }
-        __syncthreads();
-        if (active && wb == 0) {
-            for (int w = 1; w < b; ++w)
-#pragma unroll
-                for (int i = 0; i < A; ++i) bsum[i] += red[((wave + w) * A + i) * 64 + lane];
-        }
-    }
-    const bool do_bias = tile_bias && active && wb == 0;
-    if (!active) return;
-    const bool in_place = pr.flags & 2, overwrite = pr.flags & 4;
-    float* pw = in_place ? pr.work : pr.work + (int64_t)split * ((int64_t)N * K + N);
-    float* pb = in_place ? pr.db : pw + (int64_t)N * K;
-#pragma unroll
-    for (int i = 0; i < A; ++i) {
-        const int n = n0 + wa * 96 + i * 16 + lr;
-        float4 v[A];
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            v[j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (in_place && !overwrite) {
-                const float4 o = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k0 + wb * 96 + j * 16 + lg * 4]);
-                v[j] = make_float4(v[j].x + o.x, v[j].y + o.y, v[j].z + o.z, v[j].w + o.w);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < A; ++j)
-            *reinterpret_cast<float4*>(&pw[(int64_t)n * K + k0 + wb * 96 + j * 16 + lg * 4]) = v[j];
-        if (do_bias) {
-            const float bs = grp4_sum(bsum[i]);
-            if (lg == 0) {
-                if (in_place) pb[n] += bs;
-                else pb[n] = bs;
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(512, 2) wgrad_tile_group_kernel(WtGroup grp) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char wt_smem[];
-    // block -> (XCD queue, position): the host laid the teams (the tiles of one M-slice) out per XCD, so that they sit on
-    // consecutive slots of ONE XCD and no queue has holes
-    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
-    int idx = 0;
-    for (int i = 1; i < grp.n; ++i)
-        if (pos >= (int)grp.p[i].qbase[xcd]) idx = i;
-    const WtProblem& pr = grp.p[idx];
-    const int local = pos - (int)pr.qbase[xcd];
-    const int tl = local / pr.team_size, member = local - tl * pr.team_size;
-    const int team = ((xcd - pr.first_team) & 7) + 8 * tl;   // teams are dealt to the XCDs round-robin, first_team = G mod 8
-    if (team >= pr.n_teams) return;                          // past the end of the last problem's queue
-    if (pr.flags & 8) {                                      // in place: one slice, team = a group of consecutive tiles
-        const int tile = team * pr.team_size + member;
-        if (tile >= pr.tiles) return;
-        wt_body(wt_smem, pr, 0, tile);
-    } else {
-        wt_body(wt_smem, pr, team, member);
-    }
-}
-
 // dw[e] += sum_s partial[s][e] (e < NK), db[e - NK] += ... (NK <= e < NK + N): a thread owns 4 consecutive e (16-byte
 // loads, every wave load 1 KiB contiguous) for every SG-th slice, 4 loads in flight; the SG (1, 4 or 16) slice-lanes of
 // an element group are 64 threads apart and meet in LDS.  SG grows as the matrix shrinks, so that the launch has enough
@@ -1619,43 +1198,7 @@ static int group_splits(int64_t M, int tiles, int n, int cls = 0) {
 // for outputs that such tiles cover without overhang; everything else keeps 128 x 128 tiles — with overhang the wide
 // tiles spend 30-80 % more MFMA / LDS time on clamped columns, and the compute side alone (479 us of the 760 us launch)
 // then exceeds what the DMA side saves (measured: 813 us with every shape that staged >= 20 % fewer bytes on wide tiles).
-// Shape-fitted tile of class 4 (wgrad_tile_group_kernel): (96 a) x (96 b) with a | N / 96, b | K / 96, a b <= 8 waves and
-// a + b <= 6 (a stage is 6 (a + b) KiB, ring of 4 within 160 KiB) that moves the fewest operand bytes from L2 into LDS:
-// per row of a slice every dY panel is read by (K / 96 b) tiles and every X panel by (N / 96 a).
-static bool wt_tile(int N, int K, int* pa, int* pb) {
-    if (N <= 0 || K <= 0 || N % 96 || K % 96) return false;
-    const int nn = N / 96, kk = K / 96;
-    double best = 1e300;
-    int ba = 0, bb = 0;
-    for (int a = 1; a <= 5; ++a)
-        for (int b = 1; a * b <= 8 && a + b <= 6; ++b) {
-            if (nn % a || kk % b) continue;
-            const double cost = (double)(kk / b) * N + (double)(nn / a) * K - 1e-3 * a * b;
-            if (cost < best) best = cost, ba = a, bb = b;
-        }
-    if (!ba) return false;
-    *pa = ba;
-    *pb = bb;
-    return true;
-}
-// CLV_WGRAD_TILE: 0 (default) = class 4 off, 1 = for the token-parallel problems only (M > 1024), 2 = every N, K % 96 == 0.
-// Off by default: round 5 measured it (profiles/r05_wgrad_tile_class.txt) — it fetches 1.39 x the algorithmic bytes where
-// the fixed-tile classes fetch 2.23 x, and is faster on the HBM-bound stage-1 set (169 vs 205 us), but loses on the
-// stage-2 set (491 vs 410 us: 308 items on 256 CUs run as two rounds) and costs the step +0.15..0.25 ms: an item's fixed
-// costs (argument scan, ring fill, two barriers per stage, the tile's store) are ~15-19 us, and one wave issues a
-// transposing LDS read only every ~16 cycles, so its 24 reads + 36 MFMAs + 4-5 DMA pieces per stage are ~1 450 cycles of
-// serial work beside a partner doing the same.
-static int wt_mode() {
-    static const int m = getenv("CLV_WGRAD_TILE") ? atoi(getenv("CLV_WGRAD_TILE")) : 0;
-    return m;
-}
-
 static int wg_class(int N, int K, int64_t M = 1 << 20) {
-    {
-        int a, b;
-        const int mode = wt_mode();
-        if (mode && (mode >= 2 || M > 1024) && wt_tile(N, K, &a, &b)) return 4;
-    }
     static const int big = getenv("CLV_WGRAD_BIG") ? atoi(getenv("CLV_WGRAD_BIG")) : 1;
     static const int small_m = getenv("CLV_WGRAD_BIG_SMALLM") ? atoi(getenv("CLV_WGRAD_BIG_SMALLM")) : 0;   // few-row problems: 128 x 128 tiles (A/B: 0.05 ms better)
     static const int rect = getenv("CLV_WGRAD_RECT") ? atoi(getenv("CLV_WGRAD_RECT")) : 0;   // probe: 128 x 256 / 256 x 128 classes (+0.25 ms on the step: two more launches, one 8-wave workgroup per CU)
@@ -1666,7 +1209,7 @@ static int wg_class(int N, int K, int64_t M = 1 << 20) {
     if (rect && N % 256 == 0 && K % 128 == 0) return 3;      // 256 x 128
     return 0;
 }
-constexpr int WG_CLASSES = 4;                               // the fixed-tile classes; class 4 (shape-fitted tiles) is planned apart
+constexpr int WG_CLASSES = 4;                               // the fixed-tile classes
 static const int wg_tn[WG_CLASSES] = {128, 256, 128, 256}, wg_tk[WG_CLASSES] = {128, 256, 256, 128};
 // One M-slice accumulated straight into dW / db (no partials, no fold): few rows, or an output so large that every extra
 // slice costs more partial traffic (write + fold read of N x K floats) than it saves in workgroup length.
@@ -1679,75 +1222,17 @@ static int wg_tiles(int N, int K, int cls) {
     return ((N + wg_tn[cls] - 1) / wg_tn[cls]) * ((K + wg_tk[cls] - 1) / wg_tk[cls]);
 }
 
-// Cost model of a class-4 tile, cycles per 32-row stage on one CU: 36 MFMA 16x16x32 per wave (two waves per SIMD when more
-// than four are active) against the stage's bytes at a CU's share of the HBM rate (~9 B / clk).
-struct WtShape {
-    int a, b, tiles, tilesK, P;
-    double cyc_stage;
-};
-static WtShape wt_shape(int N, int K) {
-    WtShape sh = {};
-    wt_tile(N, K, &sh.a, &sh.b);
-    sh.tilesK = K / (96 * sh.b);
-    sh.tiles = (N / (96 * sh.a)) * sh.tilesK;
-    sh.P = 6 * (sh.a + sh.b);
-    const double mfma = 36.0 * 16.0 * ((sh.a * sh.b + 3) / 4) * 1.15, hbm = sh.P * 1024.0 / 9.0;
-    sh.cyc_stage = mfma > hbm ? mfma : hbm;
-    return sh;
-}
-// M-slices of the class-4 problems of one call.  Items (one tile of one slice) are dispatched longest first, so an item may
-// last up to ~30 % of the launch's makespan (CLV_WT_FRAC) without leaving a tail; beyond that a problem is cut into
-// slices — but no finer than 256 rows, and not so fine that the fp32 partials (written, then read by the fold) exceed
-// ~10 % of the slice's operand bytes each way (CLV_WT_PARTIAL).
-static void wt_plan(ClvWgradEntry* entries, int32_t n) {
-    static const double frac = getenv("CLV_WT_FRAC") ? atof(getenv("CLV_WT_FRAC")) : 0.3;
-    static const double pfrac = getenv("CLV_WT_PARTIAL") ? atof(getenv("CLV_WT_PARTIAL")) : 0.1;
-    static const int fixed = getenv("CLV_WT_SPLITS") ? atoi(getenv("CLV_WT_SPLITS")) : 0;
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const ClvWgradEntry& e = entries[i];
-        if (wg_class(e.N, e.K, e.M) != 4) continue;
-        const WtShape sh = wt_shape(e.N, e.K);
-        total += (double)sh.tiles * (double)((e.M + SM - 1) / SM) * sh.cyc_stage;
-    }
-    const double t_max = frac * total / 256.0;
-    for (int i = 0; i < n; ++i) {
-        ClvWgradEntry& e = entries[i];
-        if (wg_class(e.N, e.K, e.M) != 4) continue;
-        if (wg_in_place(e.M, e.N, e.K)) {
-            e.splits = 1;
-            e.work_floats = 0;
-            continue;
-        }
-        const WtShape sh = wt_shape(e.N, e.K);
-        const double cyc_tile = (double)((e.M + SM - 1) / SM) * sh.cyc_stage;
-        int64_t s = (int64_t)(cyc_tile / (t_max > 1.0 ? t_max : 1.0)) + 1;
-        const double operand = (double)e.M * (e.N + e.K) * 2.0, out = ((double)e.N * e.K + e.N) * 4.0;
-        int64_t cap = (int64_t)(pfrac * operand / out);
-        if (cap < 1) cap = 1;
-        if (s > cap) s = cap;
-        const int64_t max_by_rows = (e.M + 255) / 256;
-        if (s > max_by_rows) s = max_by_rows;
-        if (fixed > 0) s = fixed < max_by_rows ? fixed : max_by_rows;
-        if (s < 1) s = 1;
-        e.splits = (int)s;
-        e.work_floats = (int64_t)e.splits * ((int64_t)e.N * e.K + e.N);
-    }
-}
-
 extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
-    int ncls[WG_CLASSES + 1] = {0, 0, 0, 0, 0};
+    int ncls[WG_CLASSES] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         const ClvWgradEntry& e = entries[i];
         if (e.M <= 0 || e.N <= 0 || e.K <= 0 || (e.N & 7) || (e.K & 7)) return CLV_ERR_ARG;
         ++ncls[wg_class(e.N, e.K, e.M)];
     }
-    if (ncls[4]) wt_plan(entries, n);
     for (int i = 0; i < n; ++i) {
         ClvWgradEntry& e = entries[i];
         const int cls = wg_class(e.N, e.K, e.M);
-        if (cls == 4) continue;
         if (wg_in_place(e.M, e.N, e.K)) {
             e.splits = 1;
             e.work_floats = 0;
@@ -1759,99 +1244,9 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
     return CLV_OK;
 }
 
-// The class-4 problems of a call as launches of <= WT_GROUP_MAX problems: longest items first; the teams (the tiles of one
-// M-slice; the single tiles of an in-place problem) are dealt round-robin to eight per-XCD queues — block b runs on XCD
-// b % 8 (observed, speed only) at queue position b / 8 — so a slice's tiles occupy consecutive slots of one XCD, start
-// together and share their dY / X rows through that L2.
-static int wt_launch(const ClvWgradEntry* entries, int32_t n, hipStream_t st) {
-    int order[WG_GROUP_MAX], cnt = 0;
-    double cyc[WG_GROUP_MAX];
-    for (int i = 0; i < n; ++i) {
-        const ClvWgradEntry& e = entries[i];
-        if (wg_class(e.N, e.K, e.M) != 4) continue;
-        const WtShape sh = wt_shape(e.N, e.K);
-        cyc[i] = (double)((e.M + e.splits - 1) / e.splits / SM + 1) * sh.cyc_stage;
-        int j = cnt++;
-        for (; j > 0 && cyc[order[j - 1]] < cyc[i]; --j) order[j] = order[j - 1];
-        order[j] = i;
-    }
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_group_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 145 * 1024) == hipSuccess;
-    (void)attr;
-    for (int c0 = 0; c0 < cnt; c0 += WT_GROUP_MAX) {
-        WtGroup grp;
-        int qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0}, G = 0, maxP = 0;
-        const int m = cnt - c0 < WT_GROUP_MAX ? cnt - c0 : WT_GROUP_MAX;
-        for (int c = 0; c < m; ++c) {
-            const ClvWgradEntry& e = entries[order[c0 + c]];
-            const bool in_place = e.work_floats == 0;
-            const WtShape sh = wt_shape(e.N, e.K);
-            WtProblem& p = grp.p[c];
-            p.dy = (const bf16_t*)e.dy;
-            p.x = (const bf16_t*)e.x;
-            p.work = in_place ? e.dw : (float*)e.work;
-            p.db = in_place ? e.db : nullptr;
-            p.M = e.M;
-            const int64_t rows = (e.M + e.splits - 1) / e.splits;
-            p.rows_per_split = (rows + SM - 1) / SM * SM;
-            p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
-            p.a = sh.a; p.b = sh.b;
-            p.tilesK = sh.tilesK;
-            // One slice (in place): ALL its tiles on one XCD when they fit its 32 CUs (groups of 32 otherwise) — they share
-            // every X panel and, pairwise, the dY panels: spread over the XCDs each of them fetched X again from the fabric
-            // (stage-3 / fusion problems: 2.6 x their unique bytes, and the launch ran at the fabric rate).
-            const bool spread = in_place;
-            p.tiles = sh.tiles;
-            p.team_size = spread ? (sh.tiles < 32 ? sh.tiles : 32) : sh.tiles;
-            p.n_teams = spread ? (sh.tiles + p.team_size - 1) / p.team_size : e.splits;
-            p.first_team = G & 7;
-            p.flags = (e.want_bias ? 1 : 0) | (in_place ? 2 : 0) | ((in_place && (e.overwrite & 1)) ? 4 : 0) | (spread ? 8 : 0);
-            for (int x = 0; x < 8; ++x) {
-                if (qlen[x] > 65535) return CLV_ERR_UNSUPPORTED;
-                p.qbase[x] = (unsigned short)qlen[x];
-                const int off = (x - p.first_team) & 7;
-                const int teams_x = p.n_teams > off ? (p.n_teams - off + 7) / 8 : 0;
-                qlen[x] += teams_x * p.team_size;
-            }
-            G += p.n_teams;
-            if (wt_ring(sh.P) * sh.P > maxP) maxP = wt_ring(sh.P) * sh.P;
-        }
-        grp.n = m;
-        int qmax = 0;
-        for (int x = 0; x < 8; ++x) qmax = qlen[x] > qmax ? qlen[x] : qmax;
-        hipLaunchKernelGGL(wgrad_tile_group_kernel, dim3((unsigned)(8 * qmax)), dim3(512), (size_t)maxP * 1024, st,
-                           grp);
-        const int rc = clv_check_launch();
-        if (rc) return rc;
-    }
-    return CLV_OK;
-}
-
-#ifdef WT_TRACE
-extern "C" int clv_wt_trace_read(unsigned long long* out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wt_trace), sizeof(unsigned long long) * 16) != hipSuccess) return CLV_ERR_LAUNCH;
-    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_wt_trace), z, sizeof(z)) == hipSuccess ? CLV_OK : CLV_ERR_LAUNCH;
-}
-#endif
-
 extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
     static_assert(sizeof(WgGroup) <= 8000, "kernel-argument budget");
-    {
-        bool any = false;
-        for (int i = 0; i < n; ++i) {
-            const ClvWgradEntry& e = entries[i];
-            const bool in_place = e.work_floats == 0;
-            if (!e.dy || !e.x || e.splits <= 0 || (e.ldy & 7) || (e.ldx & 7) || e.N <= 0 || e.K <= 0) return CLV_ERR_ARG;
-            if (in_place ? (!e.dw || e.splits != 1 || (e.want_bias && !e.db)) : !e.work) return CLV_ERR_ARG;
-            any |= wg_class(e.N, e.K, e.M) == 4;
-        }
-        if (any) {
-            const int rc = wt_launch(entries, n, (hipStream_t)stream);
-            if (rc) return rc;
-        }
-    }
     // Longest workgroups first: a problem's workgroups walk M / splits rows each (1 500 ... 9 000 inside one launch), blocks
     // are dispatched in index order, and the problems arrive in backward order — stage 0 with the longest slices LAST, where
     // its ~260 workgroups used to run on alone after everything else had drained.

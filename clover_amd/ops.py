@@ -496,8 +496,7 @@ def flush_wgrads(pending):
             check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
         else:                                        # one event pair per device kernel: the tile classes one by one
             for cls, kname in ((0, 'wgrad_dma2_group_kernel'), (1, 'wgrad_big_group_kernel<2, 2>'),
-                               (2, 'wgrad_big_group_kernel<1, 2>'), (3, 'wgrad_big_group_kernel<2, 1>'),
-                               (4, 'wgrad_tile_group_kernel')):
+                               (2, 'wgrad_big_group_kernel<1, 2>'), (3, 'wgrad_big_group_kernel<2, 1>')):
                 sub = [e for e in arr if L.clv_linear_wgrad_class(e.M, e.N, e.K) == cls]
                 if not sub:
                     continue

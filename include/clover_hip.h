@@ -304,9 +304,10 @@ int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n);
  * problems with the SAME dw must not share a clv_linear_wgrad_batch call. */
 int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K);
 /* Tile class clv_linear_wgrad_batch gives the problem: 0 = wgrad_dma2_group_kernel (128 x 128 tiles), 1 =
- * wgrad_big_group_kernel<2, 2> (256 x 256), 4 = wgrad_tile_group_kernel (shape-fitted (96 a) x (96 b) tiles, N and K
- * multiples of 96: every Linear of Swin-T / BERT-base — swin_transformer_3d.py:257-259,361-363,518); one launch per class
- * present in the call. */
+ * wgrad_big_group_kernel<2, 2> (256 x 256; N and K multiples of 256, M > 1024) — the Linears of swin_transformer_3d.py:257-259,
+ * 361-363,518; one launch per class present in the call.  (Round 5's opt-in class 4, shape-fitted (96 a) x (96 b) tiles,
+ * moved 1.39 x the algorithmic bytes instead of 2.23 x but cost the step +0.15..0.25 ms and was removed in round 6:
+ * profiles/r05_wgrad_tile_class.txt.) */
 int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream);
 int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);

@@ -26,9 +26,9 @@ SH = [(50176, 576, 192, 'qkv s1'), (50176, 192, 192, 'proj s1'), (50176, 768, 19
 only = sys.argv[1] if len(sys.argv) > 1 else ''
 for (M, N, K, name) in SH:
     if only and only not in name: continue
-    x = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
-    b = torch.randn(N, device='cuda'); bb = b.to(torch.bfloat16)
-    pre = torch.randn(M, N, device='cuda').to(torch.bfloat16)
+    x = torch.randn(M, K, device='cuda').to(ops.BF16); w = (torch.randn(N, K, device='cuda') * 0.05).to(ops.BF16)
+    b = torch.randn(N, device='cuda'); bb = b.to(ops.BF16)
+    pre = torch.randn(M, N, device='cuda').to(ops.BF16)
     t_lib = timeit(lambda: F.linear(x, w, bb))
     t_own = timeit(lambda: ops.gemm_nt(x, w, b, epilogue=1))
     def lib_gelu():

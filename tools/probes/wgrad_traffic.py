@@ -70,19 +70,6 @@ for name in ORDER:
         t = s.elapsed_time(e) / TIMED * 1e-3
         del g
         line += f' us {t * 1e6:.1f} alg_TBps {by / t / 1e12:.2f} TFLOPs {fl / t / 1e12:.1f}'
-    if os.environ.get('WT_TRACE'):
-        import ctypes
-        from clover_amd import _lib
-        buf = (ctypes.c_ulonglong * 16)()
-        L = ctypes.CDLL(_lib.LIB_PATH)
-        L.clv_wt_trace_read(buf)                            # clear
-        ops.flush_wgrads(pend)
-        torch.cuda.synchronize()
-        L.clv_wt_trace_read(buf)
-        st = max(1, buf[7])
-        line += (' | cycles per stage, wave 0 (group A): mfma %.0f wait+barrier %.0f reads %.0f issue %.0f barrier2 %.0f'
-                 ' | wave 4 (group B): reads %.0f issue %.0f wait+barrier %.0f mfma %.0f barrier2 %.0f | loop %.0f prologue/stage %.0f stages %d'
-                 % tuple([buf[i] / st for i in range(5)] + [buf[8 + i] / st for i in range(5)] + [buf[6] / st, buf[5] / st, st]))
     print(line, flush=True)
     del pend
     torch.cuda.empty_cache()
