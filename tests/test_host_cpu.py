@@ -101,10 +101,19 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'clover_hip.h')).read()
     declared = set(re.findall(r'\b(clv_[a-z0-9_]+)\s*\(', hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    so = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(so, name), name
+    # both builds of the one ABI (fp16 element type = the default, bf16): every declared symbol, the same version, and each
+    # says which element type it computes in (no compute call: there is no GPU here)
+    pkg = os.path.dirname(_lib.LIB_PATH)
+    for fname, half in (('libclover_hip_f16.so', 1), ('libclover_hip.so', 0)):
+        so = ctypes.CDLL(os.path.join(pkg, fname))
+        for name in declared:
+            assert hasattr(so, name), (fname, name)
+        assert so.clv_abi_version() == _lib.ABI_VERSION, fname
+        assert so.clv_half_type() == half, fname
+    assert os.path.basename(_lib.LIB_PATH) == ('libclover_hip_f16.so' if _lib.HALF_F16 else 'libclover_hip.so')
     assert _lib.lib().clv_abi_version() == _lib.ABI_VERSION
+    from clover_amd import ops
+    assert ops.OPTIM_STATE_BYTES == int(re.search(r'#define CLV_OPTIM_STATE_BYTES (\d+)', hdr).group(1))
     assert ctypes.sizeof(_lib.ClvAttnGeom) == 23 * 4 + 4 + 8 + 8  # 21 int32 + scale + dropout_p, padding, dbias_index + work pointers
     assert ctypes.sizeof(_lib.ClvWgradEntry) == 88                # ... + overwrite / pad (first-touch gradient sinks)
     assert ctypes.sizeof(_lib.ClvLnExtra) == 80                   # ... + q8 / qscale pointers (round 3)
