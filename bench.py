@@ -243,7 +243,7 @@ def main():
             fast = {k: float(v) for k, v in model.train_step(cb, None)['log_vars'].items()}
             with parity.mode():
                 par = {k: float(v) for k, v in model.train_step(cb, None)['log_vars'].items()}
-        own_losses = dict(bf16=fast, parity=par)
+        own_losses = {args.dtype: fast, 'parity': par}      # the timed build's kernels | the fp32 instantiation of the path
         model.train()
         del cb
 
@@ -350,7 +350,7 @@ def main():
                        'params_M': round(engine.num_params / 1e6, 1),
                        'first_touch_params_M': round(getattr(engine, 'first_touch_params', 0) / 1e6, 1)},
             'step_tflops': round(pairs_s * gf / 1e3, 2) if gf else None,
-            'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,
+            'frac_bf16_mfma_peak': round(pairs_s * gf / 1e3 / (2500.0 * world), 4) if gf else None,      # (fp16 MFMA: the same dense peak)
             'losses': {k: round(v, 4) for k, v in log_vars.items()}, 'grad_norm': round(gnorm, 4),
             'loss_scale': engine.loss_scaler_state(), 'steps_skipped': steps_skipped,
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
@@ -449,11 +449,11 @@ def main():
                     mode: {k: round(abs(v - ref[k]), 7) for k, v in lv.items() if k in ref}
                     for mode, lv in own_losses.items()}
                 res['loss_abs_err_vs_oracle']['sample'] = 'B=2 synthetic batch (seed 999), eval mode, seed-1234 init'
-                # what each row is: "bf16" = the shipped training path (MFMA kernels, bf16 storage); "parity" = the fp32
-                # instantiation of the path (clover_amd/parity.py: fp32 GEMM / attention kernels through the same index logic)
-                # — a check of structure and index logic at the north-star 1e-3, not a bound on the bf16 kernels
-                res['loss_abs_err_vs_oracle']['note'] = ('bf16 = shipped path; parity = fp32 storage + arithmetic variant '
-                                                         '(structure / index-logic check, not the bf16 kernels)')
+                # what each row is: the dtype's name = the TIMED training path (MFMA kernels, 16-bit storage of that build);
+                # "parity" = the fp32 instantiation of the path (clover_amd/parity.py: fp32 GEMM / attention kernels through the
+                # same index logic) — a check of structure and index logic at the north-star 1e-3, not a bound on the 16-bit kernels
+                res['loss_abs_err_vs_oracle']['note'] = (f'{args.dtype} = the timed path; parity = fp32 storage + arithmetic '
+                                                         'variant (structure / index-logic check, not the 16-bit kernels)')
         if with_copy_ms is not None:
             res['ms_per_step_with_input_copy'] = round(with_copy_ms, 3)
     if dist.is_initialized():
