@@ -23,7 +23,7 @@ if order == 'bigfirst':
     P.sort(key=lambda p: -p[0])
 pend = []
 for (M, N, K) in P:
-    dy = torch.randn(M, N, device='cuda').to(torch.bfloat16); x = torch.randn(M, K, device='cuda').to(torch.bfloat16)
+    dy = torch.randn(M, N, device='cuda').to(ops.BF16); x = torch.randn(M, K, device='cuda').to(ops.BF16)
     pend.append((dy, x, torch.zeros(N, K, device='cuda'), torch.zeros(N, device='cuda'), M, N, K))
 def run():
     return ops.flush_wgrads(pend)
