@@ -35,7 +35,7 @@ def half_dtype():
     import torch
     return torch.float16 if HALF_F16 else torch.bfloat16
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ERRORS = {-1: 'CLV_ERR_ARG (bad argument)', -2: 'CLV_ERR_UNSUPPORTED (shape not supported by the kernels)',
           -3: 'CLV_ERR_LAUNCH (HIP launch failed)'}
@@ -154,8 +154,12 @@ SIGNATURES = {
     'clv_linear_wgrad_class': (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     'clv_linear_wgrad_batch_plan': (C.c_int, [_p, _i32]),
     'clv_linear_wgrad_batch': (C.c_int, [_p, _i32, _p]),
+    'clv_linear_wgrad_batch_ss': (C.c_int, [_p, _i32, _p, _p]),
     'clv_linear_wgrad_splits': (C.c_int, [_i64, _i32, _i32]),
     'clv_wgrad_fold_batch': (C.c_int, [_p, _i32, _p]),
+    'clv_wgrad_fold_batch_ss': (C.c_int, [_p, _i32, _p, _p]),
+    'clv_optim_prep_slots': (C.c_int, [_p, _p, _p] + [_f] * 4 + [_p]),
+    'clv_sumsq_ranges': (C.c_int, [_p, _p, _i32, _p, _p]),
     'clv_optim_prep': (C.c_int, [_p, _p] + [_f] * 4 + [_p]),
     'clv_adamw_step_dev': (C.c_int, [_p] * 6 + [_i64] + [_f] * 5 + [_p]),
     'clv_quant_fp8_rows': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i64, _p]),

@@ -341,13 +341,23 @@ __device__ __forceinline__ void dma4(unsigned lds_wave_base, unsigned voff_y0, u
         : "memory", "scc");
 }
 
+// Gradient-norm partial sums from the kernels that WRITE a first-touch weight gradient (overwrite bit 2; round 6): the sum of
+// squares of what a workgroup stores goes, one atomic per wave, to one of CLV_SUMSQ_SLOTS accumulator slots 64 bytes apart
+// (blockIdx picks the slot: ~300 atomics per slot and step instead of ~20 000 on one address); clv_optim_prep_slots adds the
+// slots to the norm.  The engine's separate sumsq pass then covers only what these kernels do not write.
+__device__ __forceinline__ void ssq_commit(float* ssq, float q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((threadIdx.x & 63) == 0 && q != 0.f) atomicAdd(ssq + (blockIdx.x & (CLV_SUMSQ_SLOTS - 1)) * 16, q);
+}
+
 template <bool ACCUM, bool RMW = false>
 __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], const int bid,
                                                 const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                 float* __restrict__ out, float* __restrict__ out_b, int64_t M, int N, int K,
                                                 int ldy, int ldx, int tiles, int tilesK, int nsplits,
                                                 int64_t rows_per_split, int want_bias, int xcd_rot = 0,
-                                                int overwrite = 0) {
+                                                int overwrite = 0, float* __restrict__ ssq = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, lr = lane & 15;
     int split, tile;
     if (nsplits > 0 && xcd_rot >= 0) {                                       // see wgrad_dma_kernel
@@ -587,6 +597,7 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
         // launches that share a parameter), so "+=" is a 16-byte load / add / store per lane in the swapped layout —
         // 2 x 4 B of traffic per element instead of a memory-side atomic each (~190 G/s: 12 us for a 768 x 3072 matrix).
         // overwrite: the step's FIRST gradient of this weight — dW is stale (the engine did not clear it): store, no load
+        float ssq_q = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn + i * 16 + lr;
@@ -596,18 +607,21 @@ __device__ __forceinline__ void wgrad_dma2_body(bf16_t (&ring)[RING][2][STAGE], 
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + wk + j * 16 + lg * 4;
                 old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && !overwrite) old[j] = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k]);
+                if (k < K && !(overwrite & 1)) old[j] = *reinterpret_cast<const float4*>(&pw[(int64_t)n * K + k]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + wk + j * 16 + lg * 4;
-                if (k < K)
-                    *reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]) =
-                        make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2],
-                                    old[j].w + acc[i][j][3]);
+                if (k < K) {
+                    const float4 v = make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2],
+                                                 old[j].w + acc[i][j][3]);
+                    *reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]) = v;
+                    ssq_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
             }
             if (do_bias && lg == 0) pb[n] += bacc[i][0];
         }
+        if (ssq && (overwrite & 4)) ssq_commit(ssq, ssq_q);       // (wave-uniform condition)
     } else if (ACCUM) {
         // acc[i][j][r] = dW[n0 + wn + i*16 + lg*4 + r][k0 + wk + j*16 + lr]: this workgroup is the only writer of the
         // element; the no-return L2 atomic is a fire-and-forget "+=", one instruction = 4 rows x 64 contiguous bytes
@@ -668,11 +682,12 @@ struct WgProblem {
     float* db;                                               // in_place only
     int64_t M, rows_per_split;
     int N, K, ldy, ldx, tiles, tilesK, nsplits, want_bias, block_begin, xcd_rot, in_place;
-    int overwrite;                                           // in_place only: dW = (store), the step's first gradient of the weight
+    int overwrite;                                           // in_place only; bit 0: dW = (store), the step's first gradient of the weight; bit 2: add its sum of squares to the group's norm slots
 };
 struct WgGroup {
     WgProblem p[WG_GROUP_MAX];
     int n;
+    float* ssq;                                              // norm slots (ssq_commit) or nullptr
 };
 __global__ void __launch_bounds__(WG_THREADS + 64, 2) wgrad_dma2_group_kernel(WgGroup grp) {
     __shared__ __attribute__((aligned(1024))) bf16_t ring[RING][2][STAGE];
@@ -683,7 +698,7 @@ __global__ void __launch_bounds__(WG_THREADS + 64, 2) wgrad_dma2_group_kernel(Wg
     if (pr.in_place)                                         // few-row problems: one slice, dW += in place
         wgrad_dma2_body<true, true>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N, pr.K,
                                     pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
-                                    pr.xcd_rot, pr.overwrite);
+                                    pr.xcd_rot, pr.overwrite, grp.ssq);
     else
         wgrad_dma2_body<false>(ring, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M, pr.N, pr.K,
                                pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split, pr.want_bias,
@@ -712,7 +727,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
                                                const bf16_t* __restrict__ x, float* __restrict__ out,
                                                float* __restrict__ out_b, int64_t M, int N, int K, int ldy, int ldx,
                                                int tiles, int tilesK, int nsplits, int64_t rows_per_split, int want_bias,
-                                               int xcd_rot, int overwrite = 0) {
+                                               int xcd_rot, int overwrite = 0, float* __restrict__ ssq = nullptr) {
     constexpr int P = PN + PK, W = 4 * PN * PK, IPW = 8 * P / W, GB = 2 * PK, R = BIG_RING;
     // LDS image: [panel][slot][8 KiB] — a wave's transpose reads of all slots then lie within the 64 KiB reach of the
     // ds immediate offset from ONE address register (slot-major order needed a register set per slot: spills)
@@ -860,6 +875,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
     wait_vm<0>();
     float* pw = ACCUM ? out : out + (int64_t)split * ((int64_t)N * K + N);
     float* pb = ACCUM ? out_b : pw + (int64_t)N * K;
+    float ssq_q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn + i * 16 + lr;
@@ -870,11 +886,12 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
             if (k >= K) continue;
             float4* dst = reinterpret_cast<float4*>(&pw[(int64_t)n * K + k]);
             float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (ACCUM && !overwrite) {
+            if (ACCUM && !(overwrite & 1)) {
                 const float4 o = *dst;
                 v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
             }
             *dst = v;
+            ssq_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
         if (do_bias) {
             const float bs = grp4_sum(bsum[i]);
@@ -884,6 +901,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* smem, const int bi
             }
         }
     }
+    if (ACCUM && ssq && (overwrite & 4)) ssq_commit(ssq, ssq_q);
 }
 
 template <int PN, int PK>
@@ -896,7 +914,7 @@ __global__ void __launch_bounds__(256 * PN * PK) wgrad_big_group_kernel(WgGroup 
     if (pr.in_place)
         wgrad_big_body<PN, PK, true>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, pr.db, pr.M, pr.N,
                                      pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
-                                     pr.want_bias, pr.xcd_rot, pr.overwrite);
+                                     pr.want_bias, pr.xcd_rot, pr.overwrite, grp.ssq);
     else
         wgrad_big_body<PN, PK, false>(big_smem, (int)blockIdx.x - pr.block_begin, pr.dy, pr.x, pr.work, nullptr, pr.M,
                                       pr.N, pr.K, pr.ldy, pr.ldx, pr.tiles, pr.tilesK, pr.nsplits, pr.rows_per_split,
@@ -959,6 +977,7 @@ __global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restr
 struct FoldTable {
     ClvFoldEntry e[CLV_FOLD_MAX];
     int n;
+    float* ssq;                                              // norm slots (ssq_commit) or nullptr
 };
 
 __global__ void __launch_bounds__(256) fold_batch_kernel(FoldTable tab) {
@@ -994,23 +1013,30 @@ __global__ void __launch_bounds__(256) fold_batch_kernel(FoldTable tab) {
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     }
+    bool writer = in;
     if (SG > 1) {                                             // block-uniform
         sh[threadIdx.x] = a;
         __syncthreads();
-        if (sg != 0) return;
-        for (int k = 1; k < SG; ++k) {
-            const float4 v = sh[k * EG + el];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+        writer = in && sg == 0;
+        if (writer)
+            for (int k = 1; k < SG; ++k) {
+                const float4 v = sh[k * EG + el];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
     }
-    if (!in) return;
-    float* dst = e < NK ? dw + e : db + (e - NK);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    // overwrite (bit 0: dW, bit 1: db): the target is a fresh temporary, or the step's first gradient of the weight —
-    // never read (nor zeroed)
-    if (!(en.overwrite & (e < NK ? 1 : 2))) o = *reinterpret_cast<const float4*>(dst);
-    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-    *reinterpret_cast<float4*>(dst) = o;
+    float q = 0.f;
+    if (writer) {
+        float* dst = e < NK ? dw + e : db + (e - NK);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        // overwrite (bit 0: dW, bit 1: db): the target is a fresh temporary, or the step's first gradient of the weight —
+        // never read (nor zeroed)
+        if (!(en.overwrite & (e < NK ? 1 : 2))) o = *reinterpret_cast<const float4*>(dst);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        *reinterpret_cast<float4*>(dst) = o;
+        if (e < NK) q = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+    }
+    // bit 2: the sum of squares of the dW this block wrote joins the gradient norm (one atomic per wave that wrote)
+    if (tab.ssq && (en.overwrite & 4)) ssq_commit(tab.ssq, q);
 }
 
 // db[n] += sum_m dy[m][n] for the library-GEMM layers (M of a few hundred..thousand rows): block = 64
@@ -1157,6 +1183,10 @@ extern "C" int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K) {
 }
 
 extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream) {
+    return clv_wgrad_fold_batch_ss(entries, n, nullptr, stream);
+}
+
+extern "C" int clv_wgrad_fold_batch_ss(const ClvFoldEntry* entries, int32_t n, float* sumsq_slots, void* stream) {
     if (!entries || n <= 0 || n > CLV_FOLD_MAX) return CLV_ERR_ARG;
     static_assert(sizeof(ClvFoldEntry) == 56, "ClvFoldEntry layout is part of the ABI");
     FoldTable tab;
@@ -1171,6 +1201,7 @@ extern "C" int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void
         tab.e[i] = en;
     }
     tab.n = n;
+    tab.ssq = sumsq_slots;
     hipLaunchKernelGGL(fold_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab);
     return clv_check_launch();
 }
@@ -1245,6 +1276,10 @@ extern "C" int clv_linear_wgrad_batch_plan(ClvWgradEntry* entries, int32_t n) {
 }
 
 extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream) {
+    return clv_linear_wgrad_batch_ss(entries, n, nullptr, stream);
+}
+
+extern "C" int clv_linear_wgrad_batch_ss(const ClvWgradEntry* entries, int32_t n, float* sumsq_slots, void* stream) {
     if (!entries || n <= 0 || n > WG_GROUP_MAX) return CLV_ERR_ARG;
     static_assert(sizeof(WgGroup) <= 8000, "kernel-argument budget");
     // Longest workgroups first: a problem's workgroups walk M / splits rows each (1 500 ... 9 000 inside one launch), blocks
@@ -1275,7 +1310,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
             p.work = in_place ? e.dw : (float*)e.work;
             p.db = in_place ? e.db : nullptr;
             p.in_place = in_place;
-            p.overwrite = in_place ? (e.overwrite & 1) : 0;
+            p.overwrite = in_place ? (e.overwrite & 5) : 0;
             p.M = e.M;
             p.N = e.N; p.K = e.K; p.ldy = e.ldy; p.ldx = e.ldx;
             p.tiles = tilesN * tilesK;
@@ -1297,6 +1332,7 @@ extern "C" int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, v
         }
         if (!cnt) continue;
         grp.n = cnt;
+        grp.ssq = sumsq_slots;
         if (cls == 0) {
             hipLaunchKernelGGL(wgrad_dma2_group_kernel, dim3((unsigned)blocks), dim3(wg_threads()), 0, (hipStream_t)stream,
                                grp);

@@ -37,6 +37,34 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const GT* __restrict__ g, fl
     if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Sum of squares over a LIST of ranges of one fp32 buffer (round 6: what is left of the gradient slabs once the kernels that
+// write the first-touch weight gradients have contributed their own sums — clv_linear_wgrad_batch_ss): the table holds one
+// {int64 offset, int64 count} pair per BLOCK (the host cuts every range into chunks of <= CLV_SUMSQ_CHUNK floats; offsets
+// and counts are multiples of 4 except a range's tail), 16-byte loads, one atomic per block.
+__global__ void __launch_bounds__(256) sumsq_ranges_kernel(const float* __restrict__ base, const int64_t* __restrict__ table,
+                                                           float* __restrict__ acc) {
+    __shared__ float sh[4];
+    const int64_t off = table[2 * blockIdx.x], n = table[2 * blockIdx.x + 1];
+    const float* g = base + off;
+    const int64_t n4 = n / 4;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (threadIdx.x < (n - n4 * 4)) {
+        const float v = g[n4 * 4 + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (t != 0.f) atomicAdd(acc, t);
+    }
+}
+
 struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, max_norm, grad_scale;
 };
@@ -119,11 +147,19 @@ struct OptimState {
 };
 
 __global__ void optim_prep_kernel(float* __restrict__ acc, OptimState* __restrict__ st, float beta1, float beta2,
-                                  float max_norm, float grad_scale) {
+                                  float max_norm, float grad_scale, float* __restrict__ slots) {
+    // slots (clv_optim_prep_slots): the CLV_SUMSQ_SLOTS partial sums the weight-gradient kernels left (ssq_commit), one per
+    // lane of this single wave; read, re-zeroed and added to acc[0]
+    float extra = 0.f;
+    if (slots) {
+        extra = slots[threadIdx.x * 16];
+        slots[threadIdx.x * 16] = 0.f;
+        extra = wave_sum(extra);
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     OptimState o = *st;
     if (o.loss_scale > 0.f) grad_scale /= o.loss_scale;        // (a power of two unless the caller chose otherwise: exact)
-    const float raw = acc[0];
+    const float raw = acc[0] + extra;
     const float ss = raw * grad_scale * grad_scale;
     acc[0] = 0.f;                                              // ready for the next step's clv_sumsq calls
     const bool overflow = !(ss == ss) || ss > 3.0e38f || raw > 3.0e38f;
@@ -259,10 +295,24 @@ extern "C" int clv_adamw_step(float* p, const float* g, float* m, float* v, void
 
 extern "C" int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float max_norm, float grad_scale,
                               void* stream) {
+    return clv_optim_prep_slots(sumsq, nullptr, state, beta1, beta2, max_norm, grad_scale, stream);
+}
+
+extern "C" int clv_optim_prep_slots(float* sumsq, float* sumsq_slots, void* state, float beta1, float beta2,
+                                    float max_norm, float grad_scale, void* stream) {
     if (!sumsq || !state || (((uintptr_t)state) & 3)) return CLV_ERR_ARG;
     static_assert(sizeof(OptimState) == CLV_OPTIM_STATE_BYTES, "OptimState layout is part of the ABI");
+    static_assert(CLV_SUMSQ_SLOTS == 64, "one slot per lane of the prep kernel's wave");
     hipLaunchKernelGGL(optim_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, (OptimState*)state, beta1,
-                       beta2, max_norm, grad_scale);
+                       beta2, max_norm, grad_scale, sumsq_slots);
+    return clv_check_launch();
+}
+
+extern "C" int clv_sumsq_ranges(const float* base, const void* table, int32_t n_blocks, float* acc, void* stream) {
+    if (!base || !table || !acc || n_blocks < 0 || (((uintptr_t)base) & 15) || (((uintptr_t)table) & 7)) return CLV_ERR_ARG;
+    if (n_blocks == 0) return CLV_OK;
+    hipLaunchKernelGGL(sumsq_ranges_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, base,
+                       (const int64_t*)table, acc);
     return clv_check_launch();
 }
 

@@ -285,7 +285,10 @@ class CloverEngine:
             classes.setdefault(opt_map[n], []).append((n, p_))
         self.segments = [_Segment(members, wd, device, lr_mult=lm)
                          for (wd, lm), members in sorted(classes.items(), key=lambda kv: (-kv[0][0], kv[0][1]))]
-        self.sumsq = torch.zeros(1, device=device, dtype=torch.float32)
+        # gradient-norm accumulator: [0] the sum of squares the norm kernels add to; from float 16 on, the CLV_SUMSQ_SLOTS
+        # partial sums (64 bytes apart) that the weight-gradient kernels fill in fused-norm mode (_setup_fused_norm)
+        self.sumsq = torch.zeros(16 + 16 * ops.SUMSQ_SLOTS, device=device, dtype=torch.float32)
+        self._norm_tables = None               # per segment (table, blocks) of what the norm pass still reads; None: whole slabs
         self.optim_state = ops.optim_state_new(device)
         self._scaler_on = self.scaler_cfg['mode'] == 'dynamic' or self.scaler_cfg['init_scale'] != 1.0
         if self._scaler_on:
@@ -328,6 +331,34 @@ class CloverEngine:
         self._stale_views = []
         self._prepacked = frozenset()
         self._setup_first_touch(sample_batch)
+        self._setup_fused_norm()
+
+    def _setup_fused_norm(self):
+        """One-rank jobs: the first-touch weight gradients (most of the parameters: each is written by exactly one launch per
+        step) deliver their sum of squares from the kernel that writes them (ops.linear_wgrad: flag bit 2 of the grouped /
+        fold launches, an explicit pass on any other path), so the norm pass before the clip reads only the REST of the
+        slabs — `clv_sumsq_ranges` over the complement — instead of all 0.76 GB.  Not in data-parallel jobs: their norm is
+        that of the REDUCED gradients (mmcv_Fp16OptimizerHook.py:119-131).  CLOVER_FUSED_NORM=0 switches it off."""
+        fresh = getattr(self, '_fresh_sinks', None)
+        if (not fresh or self.reducer.active or self.wire is not None or os.environ.get('CLOVER_FUSED_NORM', '1') != '1'
+                or not self.segments[0].flat_g.is_cuda):
+            return
+        slots = self.sumsq[16:]
+        tables = []
+        for si, seg in enumerate(self.segments):
+            spans = sorted((off, off + n) for _, sj, off, n in fresh.values() if sj == si)
+            ranges, pos = [], 0
+            for a, b in spans:
+                if a > pos:
+                    ranges.append((pos, a))
+                pos = max(pos, b)
+            if pos < seg.flat_g.numel():
+                ranges.append((pos, seg.flat_g.numel()))
+            tables.append(ops.sumsq_range_table(ranges, seg.flat_g.device))
+        self._norm_state = ops.FusedNormState()
+        for sk, _, _, _ in fresh.values():
+            sk._clv_ssq = (self.sumsq, slots, self._norm_state)
+        self._norm_tables = tables
 
     # ------------------------------------------------------------------ gradient clearing
     def _setup_first_touch(self, sample_batch):
@@ -445,6 +476,8 @@ class CloverEngine:
                 seg.flat_g.zero_()
             return
         views = self._zero_views + self._stale_views
+        if self._norm_tables is not None:
+            views = views + [self.sumsq]       # a backward without an optimizer step (dry run, warm-up) left partial sums
         if views:
             torch._foreach_zero_(views)
 
@@ -482,6 +515,9 @@ class CloverEngine:
         self._stale_cleared = False
         for seg in self.segments:
             seg.flat_g.zero_()
+        self.sumsq.zero_()
+        if self._norm_tables is not None:
+            self._norm_state.dirty = False
         self._ft.done.clear()
         return out
 
@@ -716,6 +752,9 @@ class CloverEngine:
         del emb, mlm, vcuts, tcuts
         for seg in self.segments:
             seg.flat_g.zero_()
+        self.sumsq.zero_()                    # (the warm-up backwards left norm partial sums: fused-norm mode)
+        if self._norm_tables is not None:
+            self._norm_state.dirty = False
         self._ft.done.clear()                 # the captured backward holds the first-touch stores of a fresh step
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -761,6 +800,10 @@ class CloverEngine:
         self._stale_views = self._stale_sinks()    # first-touch slots this geometry's backward never writes
         for seg in self.segments:
             seg.flat_g.zero_()                     # a capture pass does not execute kernels; be explicit
+        self.sumsq.zero_()
+        if self._norm_tables is not None and self._norm_state.dirty:
+            raise RuntimeError('fused gradient norm: the captured backward gives a first-touch sink two gradients; build the '
+                               'engine with CLOVER_FUSED_NORM=0')
         self._ft.done.clear()
         self.graph, self.graph_bwd, self.graph_bwd_video, self.graph_bwd_text = gf, gb, gb2, gb3
         self._static_emb, self._static_mlm = emb, mlm
@@ -834,10 +877,23 @@ class CloverEngine:
         self._stale_cleared = False
         gscale = 1.0 / self.world      # DDP averages the summed gradients (the loss scale is divided out on the device)
         grads = self.wire if self.wire is not None else [seg.flat_g for seg in self.segments]   # reduced gradients
-        for g in grads:
-            ops.sumsq_accumulate(g, self.sumsq)
+        fused = self._norm_tables is not None
+        if fused and self._norm_state.dirty:   # a sink got a second gradient this step (ops.linear_wgrad): recompute it all
+            if self.graph is not None:
+                raise RuntimeError('fused gradient norm: a first-touch sink received two gradients inside a captured step; '
+                                   'build the engine with CLOVER_FUSED_NORM=0')
+            self._norm_state.dirty = False
+            self.sumsq.zero_()
+            fused = False
+        if fused:                              # the first-touch slots' sums sit in the norm slots already
+            for seg, (tab, nblk) in zip(self.segments, self._norm_tables):
+                ops.sumsq_ranges(seg.flat_g, tab, nblk, self.sumsq)
+        else:
+            for g in grads:
+                ops.sumsq_accumulate(g, self.sumsq)
         ops.optim_prep(self.sumsq, self.optim_state, self.betas[0], self.betas[1],
-                       self.grad_clip if self.grad_clip else 0.0, gscale)
+                       self.grad_clip if self.grad_clip else 0.0, gscale,
+                       slots=self.sumsq[16:] if self._norm_tables is not None else None)
         for seg, g in zip(self.segments, grads):
             ops.adamw_step_dev(seg.flat_p, g, seg.exp_avg, seg.exp_avg_sq, seg.shadow, self.optim_state,
                                lr * seg.lr_mult, self.betas[0], self.betas[1], self.eps, seg.weight_decay)

@@ -239,6 +239,13 @@ def _wgrad_custom(M, N, K):
 FRESH_LOG = None            # census (engine set-up): {data_ptr: [calls, numel]} of every sink linear_wgrad writes
 
 
+class FusedNormState:
+    """Shared by the sinks of one engine's fused gradient norm: dirty = the norm slots do not describe the slabs this step."""
+
+    def __init__(self):
+        self.dirty = False
+
+
 class FirstTouch:
     """State of an engine's first-touch gradient sinks (engine._setup_first_touch): ``on`` and the set of sinks already
     written since the engine last "cleared" the gradients.  The sink tensors (``param._clv_grad``) carry it as
@@ -278,6 +285,14 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
     K = x2.shape[1]
     sink = dw_out is not None
     ow = first_touch(dw_out)
+    # fused gradient norm (engine, one rank): this sink's sum of squares is delivered by whoever WRITES it — the grouped /
+    # fold kernels through their norm slots (flag bit 2), every other path by an explicit pass over the sink right here
+    ssq = getattr(dw_out, '_clv_ssq', None) if sink else None
+    if ssq is not None and not ow:
+        # a SECOND gradient for a sink whose sum of squares rode on its first one (a caller running two backward passes
+        # between optimizer steps): the fused sums no longer describe the slab — the engine recomputes the whole norm
+        ssq[2].dirty = True
+        ssq = None
     if xstats is not None and not _wgrad_custom(M, N, K):
         x2 = ((x2.float() - xstats[0][:, None]) * xstats[1][:, None]).to(BF16)
         xstats = None
@@ -286,8 +301,8 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
         if WGRAD_DEFER is not None and sink and xstats is None:
             # nothing reads a weight gradient before the optimizer: this launch joins the grouped one that closes the
             # backward segment (dy2 / x2 stay alive in the list until then)
-            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K, 1 if ow else 0,
-                                torch.cuda.current_stream().cuda_stream))
+            WGRAD_DEFER.append((dy2, x2, dw_out, db_out if want_bias else None, M, N, K,
+                                (1 if ow else 0) | (4 if ssq is not None else 0), torch.cuda.current_stream().cuda_stream))
             return None, None
         if ow:
             dw_out.zero_()                     # the stand-alone launches only accumulate
@@ -302,14 +317,18 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
             if FOLD_DEFER is not None and sink and needs_fold:
                 # partial kernel now, its fold in the ONE batched launch that closes this backward segment
                 check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
-                FOLD_DEFER.append((work, dw, db, N, K, slices))
+                FOLD_DEFER.append((work, dw, db, N, K, slices, 4 if ssq is not None else 0))   # (dw was zeroed above: += is =)
             else:
                 check(L.clv_linear_wgrad(*args, 0, _stream()), 'clv_linear_wgrad')
+                if ssq is not None:
+                    sumsq_accumulate(dw, ssq[0])
         else:                                  # one event pair per device kernel
             kname = 'wgrad_kernel' if xstats else f"wgrad_dma2_kernel<{'true' if slices == 1 else 'false'}>"
             with _Timed(kname, 2 * M * N * K, M * (N + K) * 2):
                 check(L.clv_linear_wgrad(*args, 1, _stream()), 'clv_linear_wgrad')
             check(L.clv_linear_wgrad(*args, 2, _stream()), 'clv_linear_wgrad')
+            if ssq is not None:
+                sumsq_accumulate(dw, ssq[0])
         return (None, None) if sink else (dw, db)
     # library GEMM with fp32 output: accumulated in place into the gradient slab view (beta = 1) — no bf16 rounding
     # of dW and no separate fp32 add
@@ -326,6 +345,8 @@ def linear_wgrad(dy2, x2, want_bias, dw_out=None, db_out=None, xstats=None):
             torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
         else:
             torch.addmm(dw_out, dy2.t(), x2, out_dtype=torch.float32, out=dw_out)
+        if ssq is not None:
+            sumsq_accumulate(dw_out.reshape(-1), ssq[0])
         return None, None
     return torch.mm(dy2.t(), x2, out_dtype=torch.float32), db
 
@@ -482,18 +503,21 @@ def flush_wgrads(pending):
         check(L.clv_linear_wgrad_batch_plan(arr, len(chunk)), 'clv_linear_wgrad_batch_plan')
         work = torch.empty(max(1, sum(e.work_floats for e in arr)), device=chunk[0][0].device, dtype=torch.float32)
         off = 0
+        slots = None                                 # norm slots of the sinks whose sum of squares the kernels deliver (bit 2)
         for e, (dy2, x2, dw, db, M, N, K, *ow) in zip(arr, chunk):
             flags = int(ow[0]) if ow else 0          # bit 0: dW is stored (first touch / temporary), bit 1: db too
+            if flags & 4:
+                slots = dw._clv_ssq[1]
             if e.work_floats == 0:                   # few-row problem: accumulated in place, nothing to fold
                 e.dw, e.db = dw.data_ptr(), (db.data_ptr() if db is not None else None)
-                e.overwrite = flags & 1
+                e.overwrite = flags & 5
                 continue
             w = work[off:off + e.work_floats]
             e.work = w.data_ptr()
             folds.append((w, dw, db, N, K, e.splits, flags))
             off += e.work_floats
         if PROF is None:
-            check(L.clv_linear_wgrad_batch(arr, len(chunk), _stream()), 'clv_linear_wgrad_batch')
+            check(L.clv_linear_wgrad_batch_ss(arr, len(chunk), _ptr(slots), _stream()), 'clv_linear_wgrad_batch')
         else:                                        # one event pair per device kernel: the tile classes one by one
             for cls, kname in ((0, 'wgrad_dma2_group_kernel'), (1, 'wgrad_big_group_kernel<2, 2>'),
                                (2, 'wgrad_big_group_kernel<1, 2>'), (3, 'wgrad_big_group_kernel<2, 1>')):
@@ -502,7 +526,7 @@ def flush_wgrads(pending):
                     continue
                 sarr = (_lib.ClvWgradEntry * len(sub))(*sub)
                 with _Timed(kname, sum(2 * e.M * e.N * e.K for e in sub), sum(e.M * (e.N + e.K) * 2 for e in sub)):
-                    check(L.clv_linear_wgrad_batch(sarr, len(sub), _stream()), 'clv_linear_wgrad_batch')
+                    check(L.clv_linear_wgrad_batch_ss(sarr, len(sub), _ptr(slots), _stream()), 'clv_linear_wgrad_batch')
     return folds
 
 
@@ -527,11 +551,14 @@ def fold_chunks(pending):
 def flush_folds(pending):
     for chunk in fold_chunks(pending):
         arr = (_lib.ClvFoldEntry * len(chunk))()
+        slots = None
         for e, (work, dw, db, N, K, slices, *ow) in zip(arr, chunk):
             e.partial, e.dw, e.db = work.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
             e.nk, e.e2, e.splits = N * K, N * K + N, slices
             e.overwrite = int(ow[0]) if ow else 0
-        check(_lib.lib().clv_wgrad_fold_batch(arr, len(chunk), _stream()), 'clv_wgrad_fold_batch')
+            if e.overwrite & 4:                      # the fold delivers this sink's sum of squares (fused gradient norm)
+                slots = dw._clv_ssq[1]
+        check(_lib.lib().clv_wgrad_fold_batch_ss(arr, len(chunk), _ptr(slots), _stream()), 'clv_wgrad_fold_batch')
 
 
 def flush_dbias_gathers(pending):
@@ -2515,10 +2542,35 @@ def optim_state_set_scaler(state, init_scale, dynamic, scale_factor=2.0, scale_w
     state[13] = 1 if dynamic else 0
 
 
-def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0):
+def optim_prep(sumsq, state, beta1, beta2, max_norm, grad_scale=1.0, slots=None):
+    """slots: the CLV_SUMSQ_SLOTS norm slots the weight-gradient kernels filled (fused gradient norm): added in and re-zeroed."""
     _need_gpu(sumsq, state)
-    check(_lib.lib().clv_optim_prep(_ptr(sumsq), _ptr(state), float(beta1), float(beta2), float(max_norm),
-                                    float(grad_scale), _stream()), 'clv_optim_prep')
+    check(_lib.lib().clv_optim_prep_slots(_ptr(sumsq), _ptr(slots), _ptr(state), float(beta1), float(beta2), float(max_norm),
+                                          float(grad_scale), _stream()), 'clv_optim_prep')
+
+
+SUMSQ_SLOTS, SUMSQ_CHUNK = 64, 16384         # include/clover_hip.h: CLV_SUMSQ_SLOTS, CLV_SUMSQ_CHUNK
+
+
+def sumsq_range_table(ranges, device):
+    """Device table for clv_sumsq_ranges: the (start, end) element ranges of one fp32 buffer cut into blocks of <= SUMSQ_CHUNK
+    floats (starts must be multiples of 4: slab slots are 8-element aligned).  -> (int64 tensor [blocks][2], blocks)."""
+    rows = []
+    for a, b in ranges:
+        assert a % 4 == 0 and b >= a
+        while a < b:
+            n = min(SUMSQ_CHUNK, b - a)
+            rows.append((a, n))
+            a += n
+    t = torch.tensor(rows if rows else [(0, 0)], dtype=torch.int64, device=device)
+    return t, len(rows)
+
+
+def sumsq_ranges(base, table, n_blocks, acc):
+    """acc[0] += sum of squares of base over the table's ranges, one launch."""
+    _need_gpu(base, acc)
+    if n_blocks:
+        check(_lib.lib().clv_sumsq_ranges(_ptr(base), _ptr(table), int(n_blocks), _ptr(acc), _stream()), 'clv_sumsq_ranges')
 
 
 def adamw_step_dev(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay):

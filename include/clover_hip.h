@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLV_ABI_VERSION 16
+#define CLV_ABI_VERSION 17
 #define CLV_ERR_ARG (-1)
 #define CLV_ERR_UNSUPPORTED (-2)
 #define CLV_ERR_LAUNCH (-3)
@@ -310,6 +310,16 @@ int clv_linear_wgrad_in_place(int64_t M, int32_t N, int32_t K);
  * profiles/r05_wgrad_tile_class.txt.) */
 int clv_linear_wgrad_class(int64_t M, int32_t N, int32_t K);
 int clv_linear_wgrad_batch(const ClvWgradEntry* entries, int32_t n, void* stream);
+/* Gradient-norm partial sums from the kernels that write a weight gradient (round 6; the optimizer's norm pass of
+ * mmcv_Fp16OptimizerHook.py:126-131 `clip_grads` without re-reading those gradients).  sumsq_slots: CLV_SUMSQ_SLOTS
+ * accumulators, 16 floats (64 bytes) apart, zero before the backward.  An entry with overwrite bit 2 (value 4) set — in-place
+ * entries of clv_linear_wgrad_batch_ss, any entry of clv_wgrad_fold_batch_ss — adds the sum of squares of the dW it STORES
+ * (the final value: stored or accumulated) to a slot picked by its block index; clv_optim_prep_slots adds the slots to the
+ * norm.  The caller's own clv_sumsq pass must then skip those tensors (clv_sumsq_ranges).  sumsq_slots = NULL: the plain
+ * entry points. */
+#define CLV_SUMSQ_SLOTS 64
+int clv_linear_wgrad_batch_ss(const ClvWgradEntry* entries, int32_t n, float* sumsq_slots, void* stream);
+int clv_wgrad_fold_batch_ss(const ClvFoldEntry* entries, int32_t n, float* sumsq_slots, void* stream);
 int clv_linear_wgrad_splits(int64_t M, int32_t N, int32_t K);
 int clv_wgrad_fold_batch(const ClvFoldEntry* entries, int32_t n, void* stream);
 
@@ -506,6 +516,14 @@ int clv_transpose_batch(const void* src_base, void* dst_base, const void* table,
 #define CLV_OPTIM_STATE_BYTES 64
 int clv_optim_prep(float* sumsq, void* state, float beta1, float beta2, float max_norm, float grad_scale,
                    void* stream);
+/* clv_optim_prep with the norm slots of clv_linear_wgrad_batch_ss / clv_wgrad_fold_batch_ss: the CLV_SUMSQ_SLOTS partial sums
+ * are added to sumsq[0] and re-zeroed.  clv_sumsq_ranges: sumsq over a list of ranges of ONE buffer in one launch — table
+ * (device) = n_blocks x {int64 offset, int64 count} in floats from base, one entry per 256-thread block (the host cuts the
+ * ranges into chunks of <= CLV_SUMSQ_CHUNK floats; offsets are multiples of 4): acc[0] += sum g^2. */
+#define CLV_SUMSQ_CHUNK 16384
+int clv_optim_prep_slots(float* sumsq, float* sumsq_slots, void* state, float beta1, float beta2, float max_norm,
+                         float grad_scale, void* stream);
+int clv_sumsq_ranges(const float* base, const void* table, int32_t n_blocks, float* acc, void* stream);
 int clv_adamw_step_dev(float* p, const float* g, float* m, float* v, void* shadow, const void* state, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 

@@ -140,7 +140,9 @@ def test_skipped_step_keeps_adam_count_and_dry_step_has_no_side_effects():
     assert eng.last_lr == lr0 and eng.adam_steps() == 1                     # the first step uses schedule index 0
     snap = [(sg.flat_p.clone(), sg.exp_avg.clone()) for sg in eng.segments]
     eng.model.train_step(b, None)['loss'].backward()
-    eng.segments[0].flat_g[7] = float('nan')
+    # (a slot the norm pass reads: with the fused norm the first-touch weight gradients deliver their sums from the kernels
+    # that write them, so a value poked into one of THOSE afterwards is invisible — as it should be)
+    (eng._zero_views[0] if eng._zero_views else eng.segments[0].flat_g)[7] = float('nan')
     eng.reducer.finish()
     eng.optimizer_step()
     for sg, (p0, m0) in zip(eng.segments, snap):
@@ -226,6 +228,69 @@ def test_static_loss_scale_equals_unscaled_update_in_exact_arithmetic():
     assert eng.loss_scale == 1.0 and m._clv_loss_scale_dev is False and eng.loss_scaler_state() is None
     eng.step(b)
     assert eng.adam_steps() == 1
+
+
+@pytest.mark.parametrize('mode', ['eager', 'graph'])
+def test_fused_gradient_norm_equals_the_norm_of_the_slabs(mode, monkeypatch):
+    """One-rank engines take the norm's sum of squares of the first-touch weight gradients from the kernels that write them
+    (clv_linear_wgrad_batch_ss / clv_wgrad_fold_batch_ss norm slots) and read only the rest of the slabs
+    (clv_sumsq_ranges): the norm the optimizer used must equal the norm of what is in the slabs — computed here from a copy of
+    the gradients taken before the optimizer step — and the engine with CLOVER_FUSED_NORM=0; also after a dry step and a
+    skipped backward (stale partial sums must not leak into the next step)."""
+    from clover_amd import ops
+    from clover_amd.engine import CloverEngine
+    b = batch(2, 'norm')
+    eng = CloverEngine(make_model(), b, lr=1e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+    assert eng._norm_tables is not None and eng.first_touch_params > 0.5 * eng.num_params
+    covered = sum(int(t[:n, 1].sum()) for t, n in eng._norm_tables)
+    assert covered + eng.first_touch_params == sum(sg.flat_g.numel() for sg in eng.segments)
+    eng.dry_step(b)                                          # leaves no partial sums behind
+    assert float(eng.sumsq.abs().max()) == 0.0
+    if mode == 'graph':
+        assert eng.capture(b)
+        assert float(eng.sumsq.abs().max()) == 0.0
+    for it in range(3):
+        # the gradients of this step, copied between the backward and the optimizer
+        eng.reducer.begin_step()
+        if mode == 'graph':
+            eng._graphed_forward_backward(b)
+        else:
+            eng._ft.done.clear()
+            out = eng.model.train_step(b, None)
+            eng._backward(lambda: out['loss'].backward())
+        eng.finish_backward()
+        ref = torch.cat([sg.flat_g.double().reshape(-1) for sg in eng.segments]).norm().item() / eng.loss_scale
+        eng.optimizer_step()
+        got = eng.grad_norm()
+        assert abs(got - ref) <= 2e-5 * ref, (it, got, ref)
+        assert float(eng.sumsq.abs().max()) == 0.0           # prep re-zeroed the accumulator and the slots
+    monkeypatch.setenv('CLOVER_FUSED_NORM', '0')
+    eng0 = CloverEngine(make_model(), b, lr=1e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+    assert eng0._norm_tables is None
+    eng1 = CloverEngine(make_model(), b, lr=1e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+    monkeypatch.delenv('CLOVER_FUSED_NORM')
+    eng0.step(b)
+    n0 = eng0.grad_norm()
+    eng2 = CloverEngine(make_model(), b, lr=1e-4, weight_decay=0.0, grad_clip=15.0, max_iters=10 ** 9)
+    eng2.step(b)
+    assert abs(eng2.grad_norm() - n0) <= 1e-4 * n0, (eng2.grad_norm(), n0)
+    del eng1
+
+
+def test_sumsq_ranges_kernel():
+    """clv_sumsq_ranges against torch on ragged ranges (tails that are not multiples of 4, ranges longer than a chunk, an
+    empty table)."""
+    from clover_amd import ops
+    g = torch.randn(300000, device=DEV)
+    ranges = [(0, 7), (8, 8), (16, 40000), (40004, 40005), (100000, 300000)]
+    tab, nblk = ops.sumsq_range_table(ranges, g.device)
+    acc = torch.zeros(4, device=DEV)
+    ops.sumsq_ranges(g, tab, nblk, acc)
+    ref = sum(float((g[a:b].double() ** 2).sum()) for a, b in ranges)
+    assert abs(float(acc[0]) - ref) <= 1e-5 * ref and float(acc[1:].abs().max()) == 0.0
+    tab0, n0 = ops.sumsq_range_table([], g.device)
+    ops.sumsq_ranges(g, tab0, n0, acc)
+    assert abs(float(acc[0]) - ref) <= 1e-5 * ref
 
 
 def test_engine_gradient_slab_equals_plain_autograd():
