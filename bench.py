@@ -182,6 +182,7 @@ def main():
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--tokens', type=int, default=32)
     ap.add_argument('--variant', default='T', choices=['T', 'B'])
+    ap.add_argument('--loss-scale', default=None, help="probe: 'dynamic', a number (static) or 'none'; default: dynamic from 1024 for f16, none for bf16")
     ap.add_argument('--dtype', default=os.environ.get('CLOVER_BENCH_DTYPE', 'f16'), choices=['f16', 'bf16', 'fp8'],
                     help='f16 (default): activations, weight shadows and gradients in IEEE fp16 with a static loss scale — the '
                          'reference trains in fp16 (pretrain_webvid_cc3m.py:21); bf16: the same kernels compiled for bf16 '
@@ -252,6 +253,9 @@ def main():
     # scaler on the device, started at the scale the reference's settles near instead of 2**32 — the first ~20 steps of a
     # 2**32 start overflow and are skipped, and a skipped step is not a measured step ("steps_skipped" below must be 0)
     scaler = dict(init_scale=1024.0, mode='dynamic') if args.dtype == 'f16' else None
+    if args.loss_scale is not None:            # probe: 'dynamic' (as above), a number (static), 'none' (1.0: no scaler at all)
+        scaler = (dict(init_scale=1024.0, mode='dynamic') if args.loss_scale == 'dynamic'
+                  else 1.0 if args.loss_scale == 'none' else float(args.loss_scale))
     engine = CloverEngine(model, batch, lr=5e-5 / 1024 * args.batch * world, weight_decay=0.005, grad_clip=15.0,
                           max_iters=100000, loss_scale=scaler)
     # GEMMs that left the own kernels BEFORE the measured step exists (the eval-mode loss check above on the un-managed

@@ -571,6 +571,25 @@ class CloverEngine:
     # ------------------------------------------------------------------ hipGraph mode
     _one = None
 
+    def _parse_root_scaled(self, losses, **kw):
+        """model._parse_losses for a backward the engine starts itself: the loss scale is handed to autograd as the ROOT
+        gradient (_root_gradient) instead of through the recognizer's scaling node — one dependent launch less on the
+        step's serial chain (same-box 10.29-10.31 -> see DESIGN §5)."""
+        object.__setattr__(self.model, '_clv_root_scaled', True)
+        try:
+            return self.model._parse_losses(losses, **kw)
+        finally:
+            object.__setattr__(self.model, '_clv_root_scaled', False)
+
+    def _root_gradient(self, loss):
+        """d loss / d loss of an engine-started backward: the device-resident loss scale (a 0-dim view of the optimizer
+        record: read when the kernels run, so a captured section follows a moving scale), or a cached 1."""
+        if self._scaler_on:
+            return self.model._clv_loss_scale_dev
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)
+        return self._one
+
     _CAPTURE_FIELDS = ('graph', 'graph_bwd', 'graph_bwd_video', 'graph_bwd_text', '_static_batch', '_static_emb',
                        '_static_mlm', '_static_demb', '_static_dmlm', '_static_cuts', 'graph_loss', '_loss_io',
                        '_stale_views', '_prepacked')
@@ -626,10 +645,8 @@ class CloverEngine:
             emb = self._static_emb.detach().requires_grad_()
             mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
             losses = self.model.contrastive_losses(emb, mlm)
-            loss, log_vars = self.model._parse_losses(losses)
-            if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
-                self._one = torch.ones_like(loss)
-            loss.backward(gradient=self._one)       # (a cached root gradient: no ones_like fill per step)
+            loss, log_vars = self._parse_root_scaled(losses)
+            loss.backward(gradient=self._root_gradient(loss))
             self._static_demb.copy_(emb.grad)
             if mlm is not None:
                 self._static_dmlm.copy_(mlm.grad)
@@ -834,8 +851,8 @@ class CloverEngine:
             g = g_static.detach().requires_grad_()
             mlm = self._static_mlm.detach().requires_grad_() if self._static_mlm is not None else None
             losses = model.contrastive_losses(None, mlm, gathered=g)
-            loss, names, packed = model._parse_losses(losses, reduce=False)
-            loss.backward()
+            loss, names, packed = self._parse_root_scaled(losses, reduce=False)
+            loss.backward(gradient=self._root_gradient(loss))
             self._static_demb.copy_(g.grad[self.rank * B:(self.rank + 1) * B])
             if mlm is not None:
                 self._static_dmlm.copy_(mlm.grad)

@@ -153,8 +153,8 @@ class BaseRecognizer(nn.Module, metaclass=ABCMeta):
         # every parameter gradient again — by the engine's optimizer kernels, or by the hooks below for plain autograd
         from .. import _lib, ops
         dev_scale = getattr(self, '_clv_loss_scale_dev', None)      # an engine's device-resident scaler (engine.CloverEngine)
-        if dev_scale is False:
-            pass                                                    # an engine that runs unscaled (loss_scale=1)
+        if dev_scale is False or getattr(self, '_clv_root_scaled', False):
+            pass          # an engine that runs unscaled (loss_scale=1), or one that passes the scale as the root gradient
         elif dev_scale is not None and loss.requires_grad:
             loss = ops.scale_grad_dev(loss, dev_scale)
         elif _lib.LOSS_SCALE != 1.0 and loss.requires_grad:
