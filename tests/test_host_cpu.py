@@ -513,3 +513,25 @@ def test_fusion_text_outputs_and_token_mean_equal_autograd():
         ((yr * w).sum() + (xr.float() ** 2).sum()).backward()
         assert y.dtype == torch.float32 and (y - yr).abs().max().item() < 1e-6
         assert (x.grad.float() - xr.grad.float()).abs().max().item() <= 2e-2 * xr.grad.float().abs().max().item()
+
+
+def test_sumsq_range_table_host_logic():
+    """ops.sumsq_range_table (the block table of clv_sumsq_ranges): ranges are cut into blocks of <= CLV_SUMSQ_CHUNK floats,
+    nothing is lost or counted twice, an empty list gives zero blocks."""
+    from clover_amd import ops
+    hdr = open(os.path.join(ROOT, 'include', 'clover_hip.h')).read()
+    assert ops.SUMSQ_CHUNK == int(re.search(r'#define CLV_SUMSQ_CHUNK (\d+)', hdr).group(1))
+    assert ops.SUMSQ_SLOTS == int(re.search(r'#define CLV_SUMSQ_SLOTS (\d+)', hdr).group(1))
+    ranges = [(0, 7), (8, 8), (16, 40000), (40004, 40005), (100000, 300000)]
+    tab, n = ops.sumsq_range_table(ranges, 'cpu')
+    assert tab.shape == (n, 2) and int(tab[:, 1].max()) <= ops.SUMSQ_CHUNK
+    covered = torch.zeros(300000, dtype=torch.int32)
+    for off, cnt in tab.tolist():
+        assert off % 4 == 0
+        covered[off:off + cnt] += 1
+    want = torch.zeros_like(covered)
+    for a, b in ranges:
+        want[a:b] = 1
+    assert torch.equal(covered, want)
+    tab0, n0 = ops.sumsq_range_table([], 'cpu')
+    assert n0 == 0
